@@ -1,0 +1,152 @@
+/*
+ * librendernet_hip.so -- C ABI of the MI355X (gfx950) RenderNet forward render path.
+ *
+ * The reference (thunguyenphuoc/RenderNet) has no FFI layer: its boundary is the set of Python
+ * callables in tools/ and the TF1 Session contract.  Each entry point below
+ * replaces the TensorFlow op(s) one of those callables lowers to; the reference file:line is
+ * cited per function.  The Python host (rendernet_amd/) binds these with ctypes and mirrors
+ * the reference callables' names and arguments on top.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to float32, C-contiguous, channels-last
+ *     (3-D features [B,H,W,D,C], 2-D features [B,H,W,C]) -- the layout TF uses;
+ *   - caller owns every buffer; nothing is allocated, freed or synchronised inside;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - returns 0 on success, a negative RN_E_* code otherwise; never throws across the ABI;
+ *     rn_last_error() returns a per-thread message for the last failing call;
+ *   - re-entrant; no global mutable state besides that per-thread string.
+ */
+#ifndef RENDERNET_HIP_H
+#define RENDERNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RN_VERSION 100            /* 0.1.0 */
+
+/* error codes */
+#define RN_OK              0
+#define RN_E_INVALID      -1      /* bad argument / unsupported shape */
+#define RN_E_LAUNCH       -2      /* HIP launch error */
+#define RN_E_UNSUPPORTED  -3
+
+/* epilogue activation (applied as: v = acc + bias; act PReLU; v += residual; act sigmoid) */
+#define RN_ACT_NONE     0
+#define RN_ACT_PRELU    1         /* max(0,v) + alpha[c]*min(0,v)  -- tools/layer_util.py:27-45 */
+#define RN_ACT_SIGMOID  2         /* RenderNet_Shader.py:127,130 */
+
+/* weight-packing kinds for rn_pack_weights / rn_packed_weight_floats */
+#define RN_PACK_CONV        0     /* TF conv filter  [k0,k1,k2,Cin,Cout]  (2-D: k2 = 1)            */
+#define RN_PACK_CONVT_S1    1     /* TF conv_transpose filter [k0,k1,k2,Cout,Cin], stride 1:
+                                     becomes a flipped forward conv                               */
+#define RN_PACK_CONVT_S2    2     /* TF conv_transpose filter [4,4,(4,)Cout,Cin], stride 2:
+                                     becomes 2^nd sub-pixel phase filters of 2 taps per dim       */
+
+int rn_version(void);
+const char* rn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampler.  Replaces tf_rotation_resampling (tools/resampling_voxel_grid.py:616-632 ->
+ * :515-562, :564-614, :381-486) fused with tf_transform_voxel_to_match_image
+ * (tools/model_util.py:41-49) and the spatial crop of tf_random_crop_voxel_image
+ * (tools/model_util.py:95-98).
+ *
+ *   vox   [B,S,S,S,C]   source grid, addressed (dim1=z, dim2=y, dim3=x) as the reference does
+ *   pose  [B,3]         (azimuth, elevation, scale) radians  -- "view_name:0"
+ *   out   image_layout=1: [B,ph,pw,N,C] = X[b,h0+i,w0+j,k,c] with X = transform(resample(vox))
+ *         image_layout=0: [B,N,N,N,C] raw tf_rotation_resampling output (h0=w0=0, ph=pw=N)
+ * Semantics reproduced exactly: clamp-then-weight trilinear sampling, add_n order a..h.
+ * ---------------------------------------------------------------------------------------- */
+int rn_resample_fwd(const float* vox, const float* pose, float* out,
+                    int B, int S, int N, int C,
+                    int h0, int w0, int ph, int pw, int image_layout, void* stream);
+
+/* Same kernel, but the caller supplies the inverted 3x4 matrices M_inv [B,3,4]
+ * (tools/resampling_voxel_grid.py:601-602) instead of the pose.  Source coordinates are
+ * evaluated as ((m0*x + m1*y) + m2*z) + m3 with one rounding per operation, so the result is
+ * bit-reproducible against oracle/resample.py mode="ordered". */
+int rn_resample_affine_fwd(const float* vox, const float* m_inv, float* out,
+                           int B, int S, int N, int C,
+                           int h0, int w0, int ph, int pw, int image_layout, void* stream);
+
+/* pose [B,3] -> M_inv [B,3,4] (closed form of :526-602, evaluated in double). */
+int rn_pose_to_affine(const float* pose, float* m_inv, int B, int S, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing (TF layout -> kernel layout), done once at load time on the device.
+ * Packed layout: [phase][K/4][Npad][4] floats, K = taps*Cin, k = tap*Cin + c, Npad = Cout
+ * rounded up to a multiple of 32.  rn_packed_weight_floats returns the element count.
+ * kdims = {k0,k1,k2} (k2 = 1 for 2-D filters); ndim = 2 or 3.
+ * ---------------------------------------------------------------------------------------- */
+size_t rn_packed_weight_floats(int kind, int ndim, const int* kdims, int Cin, int Cout);
+int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, int Cout,
+                    const float* w_tf, float* w_packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions, TF "SAME" semantics, fused epilogue
+ *     y = act( conv(x) + bias ) (+ residual)       (sigmoid, if requested, is applied last)
+ * bias/alpha/residual may be NULL.  residual has the shape of y.
+ *
+ * rn_conv3d_fwd      replaces conv3d (tools/layer_util.py:228-265) + prelu (:27-45) +
+ *                    the residual tf.add (:73, RenderNet_Shader.py:64).
+ *                    x [B,H,W,D,Cin] -> y [B,ceil(H/s0),ceil(W/s1),ceil(D/s2),Cout]
+ * rn_conv2d_fwd      replaces conv2d / slim.conv2d (tools/layer_util.py:147-183, :101-104;
+ *                    RenderNet_Shader.py:83,87,98,102).  x [B,H,W,Cin] -> y [B,H/s,W/s,Cout]
+ * rn_conv2d_transpose_fwd replaces conv2d_transpose / slim.conv2d_transpose
+ *                    (tools/layer_util.py:186-226; RenderNet_Shader.py:106-129), k = 4, s in {1,2}.
+ *                    x [B,H,W,Cin] -> y [B,H*s,W*s,Cout]
+ * rn_conv3d_transpose_fwd replaces conv3d_transpose (tools/layer_util.py:269-309), k = 4.
+ * rn_projection_fwd  replaces projection_unit (tools/layer_util.py:8-22): reads the 3-D tensor
+ *                    x [B,H,W,D,C] directly as [B*H*W, D*C] (feature f = d*C + c; the reshape
+ *                    is free in channels-last), 1x1 conv F->F, bias, PReLU, one kernel.
+ * w_packed comes from rn_pack_weights with the matching kind.
+ * ---------------------------------------------------------------------------------------- */
+int rn_conv3d_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                  const float* residual, float* y,
+                  int B, int H, int W, int D, int Cin, int Cout,
+                  const int* ksize, const int* stride, int act, void* stream);
+
+int rn_conv2d_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                  const float* residual, float* y,
+                  int B, int H, int W, int Cin, int Cout,
+                  const int* ksize, const int* stride, int act, void* stream);
+
+int rn_conv2d_transpose_fwd(const float* x, const float* w_packed, const float* bias,
+                            const float* alpha, const float* residual, float* y,
+                            int B, int H, int W, int Cin, int Cout,
+                            int ksize, int stride, int act, void* stream);
+
+int rn_conv3d_transpose_fwd(const float* x, const float* w_packed, const float* bias,
+                            const float* alpha, const float* residual, float* y,
+                            int B, int H, int W, int D, int Cin, int Cout,
+                            int ksize, int stride, int act, void* stream);
+
+int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                      float* y, int B, int H, int W, int D, int C, void* stream);
+
+/* fully_connected (tools/layer_util.py:311-343): y[B,out] = act(x[B,in] @ w[in,out] + bias).
+ * w is the TF matrix unpacked ([in,out] row-major). */
+int rn_fully_connected_fwd(const float* x, const float* w, const float* bias, const float* alpha,
+                           float* y, int B, int in_features, int out_features, int act, void* stream);
+
+/* Stand-alone PReLU (tools/layer_util.py:27-45) for callers that do not use the fused
+ * epilogues: y = max(0,x) + alpha[c]*min(0,x), c = last (channel) dim of size C; n = #elements. */
+int rn_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Phong composite of the demo (tools/Phong_shading.py:202-228 black-background branch with
+ * mask, :162-200, :138-148).  normals [B,H,W,3] in [0,1]; light_dir [B,3] (not normalised),
+ * light_col [B,3]; out [B,H,W,3].
+ * ---------------------------------------------------------------------------------------- */
+int rn_phong_composite_fwd(const float* normals, const float* light_dir, const float* light_col,
+                           float ambient, float k_diffuse, float* out,
+                           int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENDERNET_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of librendernet_hip.so (include/rendernet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent, importing
+this module's `lib()` raises.  Tensors are torch CUDA(=HIP) tensors; only their device pointers
+and the current stream cross the ABI.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librendernet_hip.so")
+
+RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID = 0, 1, 2
+RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2 = 0, 1, 2
+
+_c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); must list every symbol include/rendernet_hip.h declares
+SIGNATURES = {
+    "rn_version": (_c_int, []),
+    "rn_last_error": (ctypes.c_char_p, []),
+    "rn_resample_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp]),
+    "rn_resample_affine_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp]),
+    "rn_pose_to_affine": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "rn_packed_weight_floats": (ctypes.c_size_t, [_c_int, _c_int, _ip, _c_int, _c_int]),
+    "rn_pack_weights": (_c_int, [_c_int, _c_int, _ip, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
+    "rn_conv3d_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [_ip, _ip, _c_int, _c_vp]),
+    "rn_conv2d_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_ip, _ip, _c_int, _c_vp]),
+    "rn_conv2d_transpose_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
+    "rn_conv3d_transpose_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 9 + [_c_vp]),
+    "rn_projection_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp]),
+    "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
+    "rn_prelu_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_int, _c_vp]),
+    "rn_phong_composite_fwd": (_c_int, [_c_vp] * 3 + [_c_f, _c_f, _c_vp] + [_c_int] * 3 + [_c_vp]),
+}
+
+_lib = None
+
+
+class RenderNetHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes library.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RenderNetHipError(
+                "librendernet_hip.so not found at %s -- build it with `python -m rendernet_amd.build` "
+                "(there is no CPU fallback for the render path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rn_last_error()
+        raise RenderNetHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ivec(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RenderNetHipError("expected a CUDA/HIP tensor, got device %s" % t.device)
+    if t.dtype.__str__() != "torch.float32" or not t.is_contiguous():
+        raise RenderNetHipError("expected a contiguous float32 tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

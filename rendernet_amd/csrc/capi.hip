@@ -1,0 +1,178 @@
+// C ABI of librendernet_hip.so: argument checking, TF "SAME" geometry, lowering of every conv
+// flavour to RnConvProblem, and the dispatch between the MFMA implicit-GEMM kernel and the
+// direct VALU kernel.  See include/rendernet_hip.h for the contract.
+#include "rn_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+int rn_set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int rn_check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rn_set_error(RN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return RN_OK;
+}
+
+extern "C" int rn_version(void) { return RN_VERSION; }
+extern "C" const char* rn_last_error(void) { return g_err; }
+
+// TF SAME: out = ceil(in/s); pad_total = max((out-1)*s + k - in, 0); pad_before = total/2
+static inline void same_geom(int in, int k, int s, int& out, int& pad_lo)
+{
+    out = (in + s - 1) / s;
+    int total = (out - 1) * s + k - in;
+    if (total < 0) total = 0;
+    pad_lo = total / 2;
+}
+
+static int dispatch(const RnConvProblem& p, hipStream_t st)
+{
+    if (rn_igemm_supported(p)) return rn_launch_conv_igemm(p, st);
+    return rn_launch_conv_direct(p, st);
+}
+
+static int conv_fwd_nd(const float* x, const float* w, const float* bias, const float* alpha,
+                       const float* residual, float* y, int B, const int* I, int Cin, int Cout,
+                       const int* k, const int* s, int act, hipStream_t st, const char* who)
+{
+    if (!x || !w || !y) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    if (B < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "%s: PReLU needs alpha", who);
+    RnConvProblem p;
+    p.x = x; p.w = w; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.Npad = rn_round_up(Cout, 32);
+    for (int d = 0; d < 3; ++d) {
+        if (I[d] < 1 || k[d] < 1 || s[d] < 1) return rn_set_error(RN_E_INVALID, "%s: bad geometry", who);
+        p.I[d] = I[d]; p.K[d] = k[d]; p.S[d] = s[d];
+        same_geom(I[d], k[d], s[d], p.O[d], p.P[d]);
+    }
+    p.os[2] = Cout;
+    p.os[1] = (long long)p.O[2] * Cout;
+    p.os[0] = (long long)p.O[1] * p.os[1];
+    p.os_b = (long long)p.O[0] * p.os[0];
+    p.out_off = 0;
+    p.act = act;
+    return dispatch(p, st);
+}
+
+extern "C" int rn_conv3d_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                             const float* residual, float* y, int B, int H, int W, int D, int Cin, int Cout,
+                             const int* ksize, const int* stride, int act, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv3d_fwd: null ksize/stride");
+    const int I[3] = {H, W, D};
+    return conv_fwd_nd(x, w_packed, bias, alpha, residual, y, B, I, Cin, Cout, ksize, stride, act,
+                       (hipStream_t)stream, "rn_conv3d_fwd");
+}
+
+extern "C" int rn_conv2d_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                             const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                             const int* ksize, const int* stride, int act, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv2d_fwd: null ksize/stride");
+    const int I[3] = {H, W, 1}, k[3] = {ksize[0], ksize[1], 1}, s[3] = {stride[0], stride[1], 1};
+    return conv_fwd_nd(x, w_packed, bias, alpha, residual, y, B, I, Cin, Cout, k, s, act,
+                       (hipStream_t)stream, "rn_conv2d_fwd");
+}
+
+// Transposed conv, TF SAME with output = in*s (input-gradient of the SAME forward conv):
+//   y[o] = sum_{i,k : i*s + k - pb = o} x[i] w[k],  pb = pad_before of the forward conv.
+// s = 1: forward conv with the filter flipped and pad_lo = k-1-pb.
+// s = 2, k = 4 (pb = 1): even outputs o=2q   use x[q-1]*w[3] + x[q]*w[1]   (2 taps, pad_lo 1)
+//                        odd  outputs o=2q+1 use x[q]*w[2]   + x[q+1]*w[0] (2 taps, pad_lo 0)
+// i.e. 2^nd sub-pixel phases, each a dense 2-tap-per-dim conv written with output stride 2.
+static int convT_nd(const float* x, const float* w, const float* bias, const float* alpha,
+                    const float* residual, float* y, int B, const int* I, int nd, int Cin, int Cout,
+                    int ksize, int stride, int act, hipStream_t st, const char* who)
+{
+    if (!x || !w || !y) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    if (B < 1 || Cin < 1 || Cout < 1 || ksize < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "%s: PReLU needs alpha", who);
+    RnConvProblem p;
+    p.x = x; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.Npad = rn_round_up(Cout, 32);
+    p.act = act;
+    int Ofull[3];
+    for (int d = 0; d < 3; ++d) {
+        p.I[d] = I[d]; p.S[d] = 1;
+        Ofull[d] = (d < nd) ? I[d] * stride : 1;
+    }
+    long long fs[3];   // full-resolution output strides
+    fs[2] = Cout; fs[1] = (long long)Ofull[2] * Cout; fs[0] = (long long)Ofull[1] * fs[1];
+    p.os_b = (long long)Ofull[0] * fs[0];
+    if (stride == 1) {
+        const int pb = (ksize - 1) / 2;
+        for (int d = 0; d < 3; ++d) {
+            p.K[d] = (d < nd) ? ksize : 1;
+            p.P[d] = (d < nd) ? ksize - 1 - pb : 0;
+            p.O[d] = Ofull[d];
+            p.os[d] = fs[d];
+        }
+        p.out_off = 0; p.w = w;
+        return dispatch(p, st);
+    }
+    if (stride != 2 || ksize != 4) return rn_set_error(RN_E_UNSUPPORTED, "%s: need (k=4,s=2) or s=1", who);
+    const int nphase = 1 << nd;
+    const int ktaps = 1 << nd;                       // 2 taps per dim
+    const size_t per_phase = (size_t)((ktaps * Cin + 3) / 4) * p.Npad * 4;
+    for (int ph = 0; ph < nphase; ++ph) {
+        p.out_off = 0;
+        for (int d = 0; d < 3; ++d) {
+            if (d < nd) {
+                const int bit = (ph >> (nd - 1 - d)) & 1;
+                p.K[d] = 2; p.P[d] = bit ? 0 : 1; p.O[d] = I[d];
+                p.os[d] = 2 * fs[d];
+                p.out_off += (long long)bit * fs[d];
+            } else {
+                p.K[d] = 1; p.P[d] = 0; p.O[d] = 1; p.os[d] = fs[d];
+            }
+        }
+        p.w = w + (size_t)ph * per_phase;
+        int rc = dispatch(p, st);
+        if (rc != RN_OK) return rc;
+    }
+    return RN_OK;
+}
+
+extern "C" int rn_conv2d_transpose_fwd(const float* x, const float* w_packed, const float* bias,
+                                       const float* alpha, const float* residual, float* y,
+                                       int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                       int act, void* stream)
+{
+    const int I[3] = {H, W, 1};
+    return convT_nd(x, w_packed, bias, alpha, residual, y, B, I, 2, Cin, Cout, ksize, stride, act,
+                    (hipStream_t)stream, "rn_conv2d_transpose_fwd");
+}
+
+extern "C" int rn_conv3d_transpose_fwd(const float* x, const float* w_packed, const float* bias,
+                                       const float* alpha, const float* residual, float* y,
+                                       int B, int H, int W, int D, int Cin, int Cout, int ksize, int stride,
+                                       int act, void* stream)
+{
+    const int I[3] = {H, W, D};
+    return convT_nd(x, w_packed, bias, alpha, residual, y, B, I, 3, Cin, Cout, ksize, stride, act,
+                    (hipStream_t)stream, "rn_conv3d_transpose_fwd");
+}
+
+// projection_unit (tools/layer_util.py:8-22): [B,H,W,D,C] is read as [B,H,W,1,D*C] -- the
+// reshape :20 costs nothing in channels-last -- and the 1x1 slim.conv2d + PReLU :21 is one
+// implicit-GEMM launch with M = B*H*W, K = N = D*C.
+extern "C" int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                                 float* y, int B, int H, int W, int D, int C, void* stream)
+{
+    if (D < 1 || C < 1) return rn_set_error(RN_E_INVALID, "rn_projection_fwd: bad sizes");
+    const int F = D * C;
+    const int I[3] = {H, W, 1}, k[3] = {1, 1, 1}, s[3] = {1, 1, 1};
+    return conv_fwd_nd(x, w_packed, bias, alpha, nullptr, y, B, I, F, F, k, s,
+                       alpha ? RN_ACT_PRELU : RN_ACT_NONE, (hipStream_t)stream, "rn_projection_fwd");
+}

@@ -1,0 +1,260 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves every conv of the RenderNet path with Cin % 16 == 0 (3-D convs of the
+// encoder, the projection unit's 1x1, all 2-D convs, transposed convs rewritten as forward
+// convs / sub-pixel phases).  GEMM view: M = B*O0*O1*O2 output positions, N = Cout,
+// K = taps*Cin with k = tap*Cin + c.  Replaces tf.nn.conv3d / tf.nn.conv2d / slim.conv2d /
+// conv2d_transpose call sites tools/layer_util.py:171,212,253,295 and RenderNet_Shader.py:83-129.
+//
+// Structure (per workgroup, BM x BN output tile, K walked in BK-channel slices of one tap):
+//   global --(16 B/lane, zero-filled where SAME padding applies)--> registers --> LDS (2 stages)
+//   LDS --ds_read_b128--> MFMA fragments: a lane reads 4 consecutive k of its row/column and
+//   feeds them to 4 successive 32x32x2 MFMAs (the k permutation is the same for A and B).
+//   A rows are padded by 4 floats (row stride 36 or 20 dwords) so that the 16-lane groups of a
+//   ds_read_b128 hit 16 distinct 16-B slots; B is stored [k/4][n][4] so lanes read consecutive
+//   16-B slots.  Epilogue (bias, PReLU, residual, sigmoid) is applied on the accumulators.
+//   blockIdx -> tile mapping is XCD-aware: each XCD (private 4 MiB L2) walks a contiguous run of
+//   tiles with the N tiles of one M tile adjacent, so A slices are fetched once per XCD.
+#include "rn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct IgemmArgs {
+    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y;
+    int M;
+    int I0, I1, I2, Cin;
+    int O0, O1, O2, Cout, Npad;
+    int K0, K1, K2, S0, S1, S2, P0, P1, P2;
+    long long os_b, os0, os1, os2, out_off;
+    int act, ctiles, nk, mtiles, ntiles;
+};
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+void conv_igemm_kernel(const IgemmArgs a)
+{
+    constexpr int NT = 64 * WM * WN;
+    constexpr int LDA = BK + 4;                 // padded A row (floats)
+    constexpr int WTM = BM / WM, WTN = BN / WN; // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32; // 32x32 MFMA tiles per wave
+    constexpr int TPR = BK / 4;                 // threads per A row (one float4 each)
+    constexpr int RPP = NT / TPR;               // A rows per pass
+    constexpr int APASS = BM / RPP;
+    constexpr int BF4 = (BK / 4) * BN;          // float4s in a B tile
+    constexpr int BPT = (BF4 + NT - 1) / NT;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);                   // [2][BM][LDA]
+    float* Bs = As + 2 * BM * LDA;                                // [2][BK/4][BN][4]
+    int4* rowinfo = reinterpret_cast<int4*>(Bs + 2 * BK * BN);    // [BM] {b, in0, in1, in2}
+    long long* outoff = reinterpret_cast<long long*>(rowinfo + BM); // [BM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware, bijective block -> tile map (block b runs on XCD b % 8)
+    int tile;
+    {
+        const int nb = a.mtiles * a.ntiles, id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, within = id >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tn_idx = tile % a.ntiles, tm_idx = tile / a.ntiles;
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+
+    // per-row metadata (output position -> input origin, output offset)
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        int4 ri; long long oo = -1;
+        if (m < a.M) {
+            int t = m;
+            const int o2 = t % a.O2; t /= a.O2;
+            const int o1 = t % a.O1; t /= a.O1;
+            const int o0 = t % a.O0; const int b = t / a.O0;
+            ri = make_int4(b, o0 * a.S0 - a.P0, o1 * a.S1 - a.P1, o2 * a.S2 - a.P2);
+            oo = a.out_off + b * a.os_b + o0 * a.os0 + o1 * a.os1 + o2 * a.os2;
+        } else {
+            ri = make_int4(-1, 0, 0, 0);
+        }
+        rowinfo[r] = ri; outoff[r] = oo;
+    }
+    __syncthreads();
+
+    const int arow = tid / TPR, acg = tid % TPR;
+    int rb[APASS], r0[APASS], r1[APASS], r2[APASS];
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+        const int4 ri = rowinfo[arow + p * RPP];
+        rb[p] = ri.x; r0[p] = ri.y; r1[p] = ri.z; r2[p] = ri.w;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // K-walk state: tap (t0,t1,t2) and channel slice
+    int t0 = 0, t1 = 0, t2 = 0, ct = 0;
+    long long aoff[APASS]; bool aok[APASS];
+    auto tap_setup = [&]() {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int i0 = r0[p] + t0, i1 = r1[p] + t1, i2 = r2[p] + t2;
+            aok[p] = rb[p] >= 0 && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 &&
+                     (unsigned)i2 < (unsigned)a.I2;
+            aoff[p] = ((((long long)rb[p] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cin + acg * 4;
+        }
+    };
+    tap_setup();
+
+    float4 ra[APASS], rbv[BPT];
+    auto gload = [&](int kt) {
+        const int c0 = ct * BK;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            ra[p] = aok[p] ? *reinterpret_cast<const float4*>(a.x + aoff[p] + c0)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* wk = a.w + ((size_t)kt * (BK / 4) * a.Npad + n0) * 4;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int idx = tid + i * NT;
+            if (BF4 % NT == 0 || idx < BF4) {
+                const int r = idx / BN, j = idx % BN;
+                rbv[i] = *reinterpret_cast<const float4*>(wk + ((size_t)r * a.Npad + j) * 4);
+            }
+        }
+        // advance the K-walk
+        if (++ct == a.ctiles) {
+            ct = 0;
+            if (++t2 == a.K2) { t2 = 0; if (++t1 == a.K1) { t1 = 0; ++t0; } }
+            tap_setup();
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Ab = As + buf * BM * LDA;
+        float* Bb = Bs + buf * BK * BN;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p)
+            *reinterpret_cast<float4*>(Ab + (arow + p * RPP) * LDA + acg * 4) = ra[p];
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int idx = tid + i * NT;
+            if (BF4 % NT == 0 || idx < BF4) *reinterpret_cast<float4*>(Bb + idx * 4) = rbv[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < a.nk; ++kt) {
+        const bool more = kt + 1 < a.nk;
+        if (more) gload(kt + 1);
+
+        const float* Ab = As + cur * BM * LDA + (wm * WTM + li) * LDA + lh * 4;
+        const float* Bb = Bs + cur * BK * BN + (lh * BN + wn * WTN + li) * 4;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(Bb + (kb * 2 * BN + j * 32) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + li;
+        const bool nok = n < a.Cout;
+        const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+        const float av = (a.alpha && nok) ? a.alpha[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long oo = outoff[row];
+                if (oo >= 0 && nok) {
+                    float v = acc[i][j][r] + bv;
+                    if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+                    if (a.res) v += a.res[oo + n];
+                    if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                    a.y[oo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_cfg(IgemmArgs& a, hipStream_t st)
+{
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = a.Npad / BN;
+    a.ctiles = a.Cin / BK;
+    a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
+    const size_t lds = (size_t)2 * BM * (BK + 4) * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long long nb = (long long)a.mtiles * a.ntiles;
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: bad grid %lld", nb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * WM * WN), lds, st, a);
+    return rn_check_launch("conv_igemm");
+}
+
+bool rn_igemm_supported(const RnConvProblem& p)
+{
+    return p.Cin % 16 == 0 && p.Cout >= 16 && p.Npad % 32 == 0;
+}
+
+int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
+{
+    if (!rn_igemm_supported(p)) return rn_set_error(RN_E_UNSUPPORTED, "conv_igemm: Cin=%d Cout=%d", p.Cin, p.Cout);
+    IgemmArgs a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y;
+    const long long M = (long long)p.B * p.O[0] * p.O[1] * p.O[2];
+    if (M <= 0 || M > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: M=%lld", M);
+    a.M = (int)M;
+    a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.Cin = p.Cin;
+    a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2]; a.Cout = p.Cout; a.Npad = p.Npad;
+    a.K0 = p.K[0]; a.K1 = p.K[1]; a.K2 = p.K[2];
+    a.S0 = p.S[0]; a.S1 = p.S[1]; a.S2 = p.S[2];
+    a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = p.P[2];
+    a.os_b = p.os_b; a.os0 = p.os[0]; a.os1 = p.os[1]; a.os2 = p.os[2]; a.out_off = p.out_off;
+    a.act = p.act;
+    const bool k32 = p.Cin % 32 == 0;
+    if (p.Npad % 128 == 0) {
+        return k32 ? launch_cfg<128, 128, 32, 2, 2>(a, st) : launch_cfg<128, 128, 16, 2, 2>(a, st);
+    } else if (p.Npad % 64 == 0) {
+        return k32 ? launch_cfg<128, 64, 32, 2, 2>(a, st) : launch_cfg<128, 64, 16, 2, 2>(a, st);
+    }
+    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, st) : launch_cfg<128, 32, 16, 4, 1>(a, st);
+}

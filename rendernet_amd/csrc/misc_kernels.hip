@@ -1,0 +1,204 @@
+// Weight packing, fully-connected and the demo's Phong composite (all memory-bound helpers).
+#include "rn_common.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: TF filter layout -> [phase][ceil(K/4)][Npad][4], k = tap*Cin + c.
+//   RN_PACK_CONV     : w_tf[k0,k1,k2,Cin,Cout]                  (tools/layer_util.py:162,243)
+//   RN_PACK_CONVT_S1 : w_tf[k0,k1,k2,Cout,Cin], taps flipped    (tools/layer_util.py:201,284)
+//   RN_PACK_CONVT_S2 : w_tf[4,4,(4),Cout,Cin] -> 2^nd phases of 2 taps per dim:
+//                      phase 0 (even outputs) uses filter taps {3,1}, phase 1 (odd) taps {2,0}
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w_tf; float* w_packed;
+    int kind, ndim, K0, K1, K2, E0, E1, E2, Cin, Cout, Npad, Kq, nphase;
+};
+
+__global__ void pack_weights_kernel(const PackArgs a)
+{
+    const size_t per_phase = (size_t)a.Kq * a.Npad * 4;
+    const size_t total = per_phase * a.nphase;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int phase = (int)(idx / per_phase);
+        size_t rem = idx - (size_t)phase * per_phase;
+        const int r = (int)(rem & 3); rem >>= 2;
+        const int n = (int)(rem % a.Npad);
+        const int kq = (int)(rem / a.Npad);
+        const int k = kq * 4 + r;
+        const int Keff = a.E0 * a.E1 * a.E2 * a.Cin;
+        float v = 0.f;
+        if (k < Keff && n < a.Cout) {
+            const int c = k % a.Cin;
+            int tap = k / a.Cin;
+            const int t2 = tap % a.E2; tap /= a.E2;
+            const int t1 = tap % a.E1; const int t0 = tap / a.E1;
+            if (a.kind == RN_PACK_CONV) {
+                v = a.w_tf[((((size_t)t0 * a.K1 + t1) * a.K2 + t2) * a.Cin + c) * a.Cout + n];
+            } else {
+                int s0, s1, s2;
+                if (a.kind == RN_PACK_CONVT_S1) {
+                    s0 = a.K0 - 1 - t0; s1 = a.K1 - 1 - t1; s2 = a.K2 - 1 - t2;
+                } else {
+                    // phase bits, most significant = dim 0
+                    int p0, p1, p2;
+                    if (a.ndim == 3) { p0 = (phase >> 2) & 1; p1 = (phase >> 1) & 1; p2 = phase & 1; }
+                    else { p0 = (phase >> 1) & 1; p1 = phase & 1; p2 = 0; }
+                    s0 = (p0 ? 2 : 3) - 2 * t0;
+                    s1 = (p1 ? 2 : 3) - 2 * t1;
+                    s2 = (a.ndim == 3) ? (p2 ? 2 : 3) - 2 * t2 : 0;
+                }
+                v = a.w_tf[((((size_t)s0 * a.K1 + s1) * a.K2 + s2) * a.Cout + n) * a.Cin + c];
+            }
+        }
+        a.w_packed[idx] = v;
+    }
+}
+
+static int pack_geometry(int kind, int ndim, const int* kdims, int Cin, int Cout, PackArgs& a)
+{
+    if (!kdims || (ndim != 2 && ndim != 3) || Cin < 1 || Cout < 1)
+        return rn_set_error(RN_E_INVALID, "pack: bad arguments");
+    a.kind = kind; a.ndim = ndim;
+    a.K0 = kdims[0]; a.K1 = kdims[1]; a.K2 = (ndim == 3) ? kdims[2] : 1;
+    if (a.K0 < 1 || a.K1 < 1 || a.K2 < 1) return rn_set_error(RN_E_INVALID, "pack: bad kernel dims");
+    a.E0 = a.K0; a.E1 = a.K1; a.E2 = a.K2; a.nphase = 1;
+    if (kind == RN_PACK_CONVT_S2) {
+        if (a.K0 != 4 || a.K1 != 4 || (ndim == 3 && a.K2 != 4))
+            return rn_set_error(RN_E_UNSUPPORTED, "pack: stride-2 transposed conv needs k=4");
+        a.E0 = 2; a.E1 = 2; a.E2 = (ndim == 3) ? 2 : 1; a.nphase = (ndim == 3) ? 8 : 4;
+    } else if (kind != RN_PACK_CONV && kind != RN_PACK_CONVT_S1) {
+        return rn_set_error(RN_E_INVALID, "pack: unknown kind %d", kind);
+    }
+    a.Cin = Cin; a.Cout = Cout; a.Npad = rn_round_up(Cout, 32);
+    a.Kq = (a.E0 * a.E1 * a.E2 * Cin + 3) / 4;
+    return RN_OK;
+}
+
+extern "C" size_t rn_packed_weight_floats(int kind, int ndim, const int* kdims, int Cin, int Cout)
+{
+    PackArgs a;
+    if (pack_geometry(kind, ndim, kdims, Cin, Cout, a) != RN_OK) return 0;
+    return (size_t)a.nphase * a.Kq * a.Npad * 4;
+}
+
+extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, int Cout,
+                               const float* w_tf, float* w_packed, void* stream)
+{
+    PackArgs a;
+    int rc = pack_geometry(kind, ndim, kdims, Cin, Cout, a);
+    if (rc != RN_OK) return rc;
+    if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
+    a.w_tf = w_tf; a.w_packed = w_packed;
+    const size_t total = (size_t)a.nphase * a.Kq * a.Npad * 4;
+    const unsigned nb = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    return rn_check_launch("pack_weights");
+}
+
+// ---------------------------------------------------------------------------------------------
+// fully_connected (tools/layer_util.py:311-343): y = act(x @ w + bias).  HBM-bound on w
+// ([in,out], 104 MB for the texture decoder's 199 -> 131072): one thread per output column,
+// columns coalesced across lanes, the <= 8 batch rows of a chunk accumulate in registers,
+// x is read with wave-uniform addresses.
+// ---------------------------------------------------------------------------------------------
+template <int BC>
+__global__ __launch_bounds__(256)
+void fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+               const float* __restrict__ alpha, float* __restrict__ y, int B, int in_f, int out_f, int act)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = blockIdx.y * BC;
+    if (col >= out_f) return;
+    float acc[BC];
+#pragma unroll
+    for (int i = 0; i < BC; ++i) acc[i] = 0.f;
+    for (int k = 0; k < in_f; ++k) {
+        const float wv = w[(size_t)k * out_f + col];
+#pragma unroll
+        for (int i = 0; i < BC; ++i)
+            if (b0 + i < B) acc[i] = fmaf(x[(size_t)(b0 + i) * in_f + k], wv, acc[i]);
+    }
+    const float bv = bias ? bias[col] : 0.f;
+    const float av = alpha ? alpha[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < BC; ++i) {
+        if (b0 + i < B) {
+            float v = acc[i] + bv;
+            if (act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+            if (act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+            y[(size_t)(b0 + i) * out_f + col] = v;
+        }
+    }
+}
+
+extern "C" int rn_fully_connected_fwd(const float* x, const float* w, const float* bias, const float* alpha,
+                                      float* y, int B, int in_features, int out_features, int act, void* stream)
+{
+    if (!x || !w || !y || B < 1 || in_features < 1 || out_features < 1)
+        return rn_set_error(RN_E_INVALID, "rn_fully_connected_fwd: bad argument");
+    dim3 grid((out_features + 255) / 256, (B + 7) / 8);
+    hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, alpha, y, B,
+                       in_features, out_features, act);
+    return rn_check_launch("fully_connected");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone PReLU (tools/layer_util.py:27-45); the hot path uses the fused conv epilogues.
+// ---------------------------------------------------------------------------------------------
+__global__ void prelu_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                             float* __restrict__ y, size_t n, int C)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = fmaxf(v, 0.f) + alpha[i % C] * fminf(v, 0.f);
+    }
+}
+
+extern "C" int rn_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, int C, void* stream)
+{
+    if (!x || !alpha || !y || C < 1) return rn_set_error(RN_E_INVALID, "rn_prelu_fwd: bad argument");
+    if (n == 0) return RN_OK;
+    const size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(prelu_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, (hipStream_t)stream,
+                       x, alpha, y, n, C);
+    return rn_check_launch("prelu");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phong composite (tools/Phong_shading.py:202-228, :162-200, :138-148), black background + mask:
+//   n = (img-0.5)/|img-0.5| ; d = clip(k_d * max(n . l^, 0) * col, 0, 1)
+//   mask = sigmoid(255*|img| - 150) ; out = clip(mask*(ambient + d) + (1-mask), 0, 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void phong_kernel(const float* __restrict__ img, const float* __restrict__ light_dir,
+                             const float* __restrict__ light_col, float ambient, float k_diffuse,
+                             float* __restrict__ out, int B, int HW)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)B * HW) return;
+    const int b = (int)(p / HW);
+    const float r = img[p * 3 + 0], g = img[p * 3 + 1], bl = img[p * 3 + 2];
+    float lx = light_dir[b * 3 + 0], ly = light_dir[b * 3 + 1], lz = light_dir[b * 3 + 2];
+    const float ln = sqrtf(lx * lx + ly * ly + lz * lz);
+    lx /= ln; ly /= ln; lz /= ln;
+    const float nx = r - 0.5f, ny = g - 0.5f, nz = bl - 0.5f;
+    const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+    float d = fmaxf((nx / nn) * lx + (ny / nn) * ly + (nz / nn) * lz, 0.f);
+    const float m = 1.f / (1.f + expf(-(255.f * sqrtf(r * r + g * g + bl * bl) - 150.f)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float dc = fminf(fmaxf(k_diffuse * (d * light_col[b * 3 + c]), 0.f), 1.f);
+        out[p * 3 + c] = fminf(fmaxf(m * (ambient + dc) + (1.f - m), 0.f), 1.f);
+    }
+}
+
+extern "C" int rn_phong_composite_fwd(const float* normals, const float* light_dir, const float* light_col,
+                                      float ambient, float k_diffuse, float* out, int B, int H, int W, void* stream)
+{
+    if (!normals || !light_dir || !light_col || !out || B < 1 || H < 1 || W < 1)
+        return rn_set_error(RN_E_INVALID, "rn_phong_composite_fwd: bad argument");
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(phong_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       normals, light_dir, light_col, ambient, k_diffuse, out, B, H * W);
+    return rn_check_launch("phong_composite");
+}

@@ -1,0 +1,235 @@
+// Pose-conditioned trilinear voxel resampler, fused with the voxel->image axis transform and
+// the spatial crop.  Replaces tf_rotation_resampling (tools/resampling_voxel_grid.py:616-632:
+// pose -> matrices :515-562, inverse warp :564-614, 8-gather interpolation :381-486),
+// tf_transform_voxel_to_match_image (tools/model_util.py:41-49) and the voxel half of
+// tf_random_crop_voxel_image (tools/model_util.py:95-98) -- one kernel, one pass over HBM:
+// reads the S^3 source (L2-resident: 1 MiB per item at S=64), writes the N^3 target once,
+// directly in the network's input layout.  None of the reference's temporaries (homogeneous
+// meshgrid [B,4,N^3], transformed coords [B,3,N^3], 8 gathered tensors, 8 weight tensors)
+// is materialised.
+//
+// Semantics reproduced exactly: x0=floor(x), x1=x0+1, BOTH clamped to
+// [0,S-1], weights computed from the CLAMPED indices, products ((wx*wy)*wz)*I, sum order
+// a,b,c,d,e,f,g,h; every operation individually rounded (no FMA contraction), so the affine
+// entry point is bit-exact against the NumPy oracle evaluated in the same order.
+#include "rn_common.h"
+#include <math.h>
+
+struct ResampleArgs {
+    const float* vox;     // [B,S,S,S,C]
+    const float* mat;     // FROM_POSE ? pose [B,3] : m_inv [B,12]
+    float* out;
+    int B, S, N, C;
+    int h0, w0, ph, pw;
+    int image_layout;
+};
+
+__device__ __forceinline__ void pose_to_affine_dev(const float* pose, int S, int N, float* m /*12*/)
+{
+    // closed form of inverse(T_new_inv * Sc * (Rot_Z*Rot_Y) * T) rows 0:3
+    // (tools/resampling_voxel_grid.py:526-602): p_src = (1/s) R^T (p_out - N/2) + S/2
+    const double az = (double)pose[0] - 1.5707963267948966;
+    const double el = (double)pose[1];
+    const double is = 1.0 / (double)pose[2];
+    const double ca = cos(az), sa = sin(az), ce = cos(el), se = sin(el);
+    const double rt[3][3] = {{ce * ca, -se * ca, sa}, {se, ce, 0.0}, {-ce * sa, se * sa, ca}};
+    const double hn = 0.5 * N, hs = 0.5 * S;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double a0 = rt[r][0] * is, a1 = rt[r][1] * is, a2 = rt[r][2] * is;
+        m[r * 4 + 0] = (float)a0; m[r * 4 + 1] = (float)a1; m[r * 4 + 2] = (float)a2;
+        m[r * 4 + 3] = (float)(hs - (a0 + a1 + a2) * hn);
+    }
+}
+
+__global__ void pose_to_affine_kernel(const float* pose, float* m_inv, int B, int S, int N)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) pose_to_affine_dev(pose + 3 * b, S, N, m_inv + 12 * b);
+}
+
+// one source coordinate: ((m0*x + m1*y) + m2*z) + m3, one rounding per op
+__device__ __forceinline__ float coord(float m0, float m1, float m2, float m3, float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m0, x), __fmul_rn(m1, y)), __fmul_rn(m2, z)), m3);
+}
+
+template <int CT>   // CT = compile-time channel count (1, 4) or 0 for a runtime loop
+__device__ __forceinline__ void sample_point(const float* __restrict__ vb, int S, int C,
+                                             float x, float y, float z, float* __restrict__ o)
+{
+    const int mx = S - 1;
+    int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    x0 = min(max(x0, 0), mx); x1 = min(max(x1, 0), mx);
+    y0 = min(max(y0, 0), mx); y1 = min(max(y1, 0), mx);
+    z0 = min(max(z0, 0), mx); z1 = min(max(z1, 0), mx);
+    const float ax = __fsub_rn((float)x1, x), bx = __fsub_rn(x, (float)x0);
+    const float ay = __fsub_rn((float)y1, y), by = __fsub_rn(y, (float)y0);
+    const float az = __fsub_rn((float)z1, z), bz = __fsub_rn(z, (float)z0);
+    const float wa = __fmul_rn(__fmul_rn(ax, ay), az);
+    const float wb = __fmul_rn(__fmul_rn(ax, by), az);
+    const float wc = __fmul_rn(__fmul_rn(bx, ay), az);
+    const float wd = __fmul_rn(__fmul_rn(bx, by), az);
+    const float we = __fmul_rn(__fmul_rn(ax, ay), bz);
+    const float wf = __fmul_rn(__fmul_rn(ax, by), bz);
+    const float wg = __fmul_rn(__fmul_rn(bx, ay), bz);
+    const float wh = __fmul_rn(__fmul_rn(bx, by), bz);
+    const int S2 = S * S;
+    const int ia = z0 * S2 + y0 * S + x0, ib = z0 * S2 + y1 * S + x0;
+    const int ic = z0 * S2 + y0 * S + x1, id = z0 * S2 + y1 * S + x1;
+    const int ie = z1 * S2 + y0 * S + x0, iff = z1 * S2 + y1 * S + x0;
+    const int ig = z1 * S2 + y0 * S + x1, ih = z1 * S2 + y1 * S + x1;
+    const int nc = CT ? CT : C;
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+        float v = __fmul_rn(wa, vb[(size_t)ia * nc + c]);
+        v = __fadd_rn(v, __fmul_rn(wb, vb[(size_t)ib * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(wc, vb[(size_t)ic * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(wd, vb[(size_t)id * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(we, vb[(size_t)ie * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(wf, vb[(size_t)iff * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(wg, vb[(size_t)ig * nc + c]));
+        v = __fadd_rn(v, __fmul_rn(wh, vb[(size_t)ih * nc + c]));
+        o[c] = v;
+    }
+}
+
+// Grid: blockIdx.x walks (b, i, j-group); each thread owns 4 consecutive depth samples k of one
+// (i, j) line, so a wave writes 1 KiB contiguous (C=1) and the 8 gathers of neighbouring lanes
+// fall into neighbouring source cells.
+template <int CT, bool FROM_POSE>
+__global__ __launch_bounds__(256)
+void resample_kernel(const ResampleArgs a)
+{
+    __shared__ float msh[12];
+    const int N = a.N;
+    const int kthreads = N / 4;                      // threads per depth line
+    const int lines_per_block = 256 / kthreads;      // (i,j) lines per block
+    const long long nlines = (long long)a.B * a.ph * a.pw;
+    const long long line0 = (long long)blockIdx.x * lines_per_block;
+    // all lines of a block belong to one batch item (pw*ph multiple of lines_per_block is
+    // enforced by the launcher)
+    const int b = (int)(line0 / ((long long)a.ph * a.pw));
+    if (threadIdx.x == 0) {
+        if (FROM_POSE) pose_to_affine_dev(a.mat + 3 * b, a.S, N, msh);
+        else for (int q = 0; q < 12; ++q) msh[q] = a.mat[12 * b + q];
+    }
+    __syncthreads();
+    const long long line = line0 + threadIdx.x / kthreads;
+    if (line >= nlines) return;
+    const int k0 = (threadIdx.x % kthreads) * 4;
+    const int ij = (int)(line - (long long)b * a.ph * a.pw);
+    const int i = ij / a.pw + a.h0, j = ij % a.pw + a.w0;
+
+    const float m00 = msh[0], m01 = msh[1], m02 = msh[2], m03 = msh[3];
+    const float m10 = msh[4], m11 = msh[5], m12 = msh[6], m13 = msh[7];
+    const float m20 = msh[8], m21 = msh[9], m22 = msh[10], m23 = msh[11];
+
+    // output grid point of element (i,j,k):  image layout X[b,i,j,k] = R[b, z=j, y=N-1-i, x=k]
+    // (tools/model_util.py:47-48); raw layout R[b, z=i, y=j, x=k].
+    const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
+    const float gz = a.image_layout ? (float)j : (float)i;
+    const float* vb = a.vox + (size_t)b * a.S * a.S * a.S * (CT ? CT : a.C);
+    const int nc = CT ? CT : a.C;
+    float* op = a.out + ((size_t)line * N + k0) * nc;
+
+    if (CT == 1) {
+        float r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gx = (float)(k0 + q);
+            sample_point<1>(vb, a.S, 1, coord(m00, m01, m02, m03, gx, gy, gz),
+                            coord(m10, m11, m12, m13, gx, gy, gz), coord(m20, m21, m22, m23, gx, gy, gz), &r[q]);
+        }
+        *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+    } else if (CT == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gx = (float)(k0 + q);
+            float r[4];
+            sample_point<4>(vb, a.S, 4, coord(m00, m01, m02, m03, gx, gy, gz),
+                            coord(m10, m11, m12, m13, gx, gy, gz), coord(m20, m21, m22, m23, gx, gy, gz), r);
+            *reinterpret_cast<float4*>(op + q * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    } else {
+        for (int q = 0; q < 4; ++q) {
+            const float gx = (float)(k0 + q);
+            const float xs = coord(m00, m01, m02, m03, gx, gy, gz);
+            const float ys = coord(m10, m11, m12, m13, gx, gy, gz);
+            const float zs = coord(m20, m21, m22, m23, gx, gy, gz);
+            for (int c0 = 0; c0 < nc; c0 += 8) {   // runtime channel count, chunks of <= 8
+                float r[8];
+                const int cc = min(8, nc - c0);
+                // generic path: per-channel gathers
+                const int mx = a.S - 1;
+                int x0 = (int)floorf(xs), y0 = (int)floorf(ys), z0 = (int)floorf(zs);
+                int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+                x0 = min(max(x0, 0), mx); x1 = min(max(x1, 0), mx);
+                y0 = min(max(y0, 0), mx); y1 = min(max(y1, 0), mx);
+                z0 = min(max(z0, 0), mx); z1 = min(max(z1, 0), mx);
+                const float ax = __fsub_rn((float)x1, xs), bx = __fsub_rn(xs, (float)x0);
+                const float ay = __fsub_rn((float)y1, ys), by = __fsub_rn(ys, (float)y0);
+                const float az = __fsub_rn((float)z1, zs), bz = __fsub_rn(zs, (float)z0);
+                const float w8[8] = {__fmul_rn(__fmul_rn(ax, ay), az), __fmul_rn(__fmul_rn(ax, by), az),
+                                     __fmul_rn(__fmul_rn(bx, ay), az), __fmul_rn(__fmul_rn(bx, by), az),
+                                     __fmul_rn(__fmul_rn(ax, ay), bz), __fmul_rn(__fmul_rn(ax, by), bz),
+                                     __fmul_rn(__fmul_rn(bx, ay), bz), __fmul_rn(__fmul_rn(bx, by), bz)};
+                const int S2 = a.S * a.S;
+                const int i8[8] = {z0 * S2 + y0 * a.S + x0, z0 * S2 + y1 * a.S + x0, z0 * S2 + y0 * a.S + x1,
+                                   z0 * S2 + y1 * a.S + x1, z1 * S2 + y0 * a.S + x0, z1 * S2 + y1 * a.S + x0,
+                                   z1 * S2 + y0 * a.S + x1, z1 * S2 + y1 * a.S + x1};
+                for (int c = 0; c < cc; ++c) {
+                    float v = __fmul_rn(w8[0], vb[(size_t)i8[0] * nc + c0 + c]);
+                    for (int e = 1; e < 8; ++e) v = __fadd_rn(v, __fmul_rn(w8[e], vb[(size_t)i8[e] * nc + c0 + c]));
+                    r[c] = v;
+                }
+                for (int c = 0; c < cc; ++c) op[(size_t)q * nc + c0 + c] = r[c];
+            }
+        }
+    }
+}
+
+template <bool FROM_POSE>
+static int launch_resample(const ResampleArgs& a, hipStream_t st)
+{
+    if (a.B <= 0 || a.S < 2 || a.N < 4 || a.C < 1) return rn_set_error(RN_E_INVALID, "resample: bad dims");
+    if (a.N % 4 != 0 || a.N / 4 > 256 || 256 % (a.N / 4) != 0)
+        return rn_set_error(RN_E_INVALID, "resample: N=%d must be a power of two in [4,1024]", a.N);
+    if (a.h0 < 0 || a.w0 < 0 || a.ph < 1 || a.pw < 1 || a.h0 + a.ph > a.N || a.w0 + a.pw > a.N)
+        return rn_set_error(RN_E_INVALID, "resample: crop window out of range");
+    if (!a.image_layout && (a.h0 || a.w0 || a.ph != a.N || a.pw != a.N))
+        return rn_set_error(RN_E_INVALID, "resample: crop needs image_layout=1");
+    const int lpb = 256 / (a.N / 4);
+    if (((long long)a.ph * a.pw) % lpb != 0)
+        return rn_set_error(RN_E_INVALID, "resample: ph*pw=%d must be a multiple of %d", a.ph * a.pw, lpb);
+    const long long nb = (long long)a.B * a.ph * a.pw / lpb;
+    if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
+    if (a.C == 1) hipLaunchKernelGGL((resample_kernel<1, FROM_POSE>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else if (a.C == 4) hipLaunchKernelGGL((resample_kernel<4, FROM_POSE>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resample_kernel<0, FROM_POSE>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    return rn_check_launch("resample");
+}
+
+extern "C" int rn_resample_fwd(const float* vox, const float* pose, float* out, int B, int S, int N, int C,
+                               int h0, int w0, int ph, int pw, int image_layout, void* stream)
+{
+    if (!vox || !pose || !out) return rn_set_error(RN_E_INVALID, "rn_resample_fwd: null pointer");
+    ResampleArgs a{vox, pose, out, B, S, N, C, h0, w0, ph, pw, image_layout};
+    return launch_resample<true>(a, (hipStream_t)stream);
+}
+
+extern "C" int rn_resample_affine_fwd(const float* vox, const float* m_inv, float* out, int B, int S, int N, int C,
+                                      int h0, int w0, int ph, int pw, int image_layout, void* stream)
+{
+    if (!vox || !m_inv || !out) return rn_set_error(RN_E_INVALID, "rn_resample_affine_fwd: null pointer");
+    ResampleArgs a{vox, m_inv, out, B, S, N, C, h0, w0, ph, pw, image_layout};
+    return launch_resample<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int rn_pose_to_affine(const float* pose, float* m_inv, int B, int S, int N, void* stream)
+{
+    if (!pose || !m_inv || B <= 0) return rn_set_error(RN_E_INVALID, "rn_pose_to_affine: bad argument");
+    hipLaunchKernelGGL(pose_to_affine_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, m_inv, B, S, N);
+    return rn_check_launch("pose_to_affine");
+}

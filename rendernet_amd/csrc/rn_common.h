@@ -1,0 +1,37 @@
+// Internal declarations shared by the HIP translation units of librendernet_hip.so (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/rendernet_hip.h"
+
+// Generic "gridded" convolution problem: every conv / transposed-conv phase / 1x1 projection of
+// the path is lowered to this one description (channels-last everywhere).
+//   out[b, o0, o1, o2, n] = epi( sum_{t0,t1,t2,c} x[b, o0*S0-P0+t0, o1*S1-P1+t1, o2*S2-P2+t2, c]
+//                                                * Wp[(t0*K1+t1)*K2+t2][c][n] )
+// out-of-range input coordinates contribute zero (TF SAME).  The output element lives at
+//   y + out_off + b*os_b + o0*os[0] + o1*os[1] + o2*os[2] + n          (elements)
+// which lets a stride-2 transposed conv be written as 2^nd interleaved sub-pixel phases.
+struct RnConvProblem {
+    const float* x;
+    const float* w;          // packed [K/4][Npad][4]
+    const float* bias;       // [Cout] or null
+    const float* alpha;      // [Cout] or null (PReLU)
+    const float* residual;   // same addressing as y, or null
+    float* y;
+    int B, I[3], Cin;        // input  [B, I0, I1, I2, Cin]
+    int O[3], Cout, Npad;    // output grid visited by this launch, channels, padded channels
+    int K[3], S[3], P[3];    // taps, stride, pad_lo
+    long long os_b, os[3], out_off;
+    int act;
+};
+
+int rn_set_error(int code, const char* fmt, ...);
+int rn_check_launch(const char* what);
+
+// launchers implemented in the kernel translation units
+int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st);     // conv_igemm.hip  (MFMA)
+int rn_launch_conv_direct(const RnConvProblem& p, hipStream_t st);    // conv_direct.hip (VALU)
+bool rn_igemm_supported(const RnConvProblem& p);
+
+static inline int rn_round_up(int a, int b) { return (a + b - 1) / b * b; }

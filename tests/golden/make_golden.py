@@ -1,0 +1,61 @@
+"""Generate the golden vectors under tests/golden/ with the CPU oracle (run in the build
+container: `python tests/golden/make_golden.py`).  The reference itself cannot be executed
+(TensorFlow 1.x is not installable here), so these vectors pin the HIP path to the
+oracle restatement, not to TF outputs -- "parity unpinned" in the sense of oracle/__init__.py.
+
+  tiny_shader.npz             tiny spec (16^3 -> 32^3 -> 128^2), 3 frames, perturbed weights seed 1234
+  full_chair_demo_pose.npz    reference-size net, binvox/chair.binvox at the demo default pose
+                              (RenderNet_demo.py:81-98), 128x128 centre crop of logits and output
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import rendernet as ON                     # noqa: E402
+from oracle import resample as OR                      # noqa: E402
+from oracle.io_phong import read_binvox                # noqa: E402
+from rendernet_amd.shader import ShaderSpec, tiny_spec, init_shader_weights   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def pose(az, el, r):
+    return np.array([az * np.pi / 180.0, (90 - el) * np.pi / 180.0, 3.3 / r], np.float32)
+
+
+def tiny():
+    spec = tiny_spec(1)
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    rng = np.random.default_rng(2024)
+    vox = (rng.random((3, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    poses = np.stack([pose(250, 60, 3.3), pose(15, 35, 2.9), pose(200, 70, 4.1)])
+    taps = {}
+    x = OR.net_input(vox, poses, 16, 32, mode="tf")
+    out = ON.rendernet_forward(x, w, taps, spec.n_res1, spec.n_res2, spec.n_res3)
+    np.savez_compressed(os.path.join(HERE, "tiny_shader.npz"), seed=1234, vox=vox, poses=poses, output=out,
+                        tap_enc3=taps["enc3"], tap_enc4=taps["enc4"], tap_enc6=taps["enc6"],
+                        tap_logits=taps["logits"])
+
+
+def full():
+    spec = ShaderSpec().check()
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox = read_binvox(os.path.join(ROOT, "binvox", "chair.binvox")).astype(np.float32)[None, ..., None]
+    p = pose(250, 60, 3.3)[None]
+    x = OR.net_input(vox, p, 64, 128, mode="tf")
+    taps = {}
+    out = ON.rendernet_forward(x, w, taps)
+    np.savez_compressed(os.path.join(HERE, "full_chair_demo_pose.npz"),
+                        output_crop=out[0, 192:320, 192:320, 0], logits_crop=taps["logits"][0, 192:320, 192:320, 0],
+                        net_in_sum=np.float64(x.sum()), enc3_skip_absmean=np.float64(np.abs(taps["enc3_skip"]).mean()),
+                        enc4_absmean=np.float64(np.abs(taps["enc4"]).mean()))
+
+
+if __name__ == "__main__":
+    tiny()
+    full()
+    print("golden vectors written to", HERE)

@@ -1,0 +1,196 @@
+"""Parity of every conv flavour (through the C ABI) against oracle/layers.py.  -m gpu.
+fp32 tolerance: max|got-want| <= 1e-4 * max|want| (exact-fp32 MFMA = fmaf chain; the oracle is
+oneDNN fp32 with a different summation order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as OL
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _dev(a):
+    return None if a is None else torch.as_tensor(a).cuda()
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def _close(got, want, what):
+    got = got.cpu().numpy()
+    want = want.numpy() if isinstance(want, torch.Tensor) else want
+    assert got.shape == tuple(want.shape), (what, got.shape, want.shape)
+    err = np.abs(got - want).max()
+    ref = np.abs(want).max()
+    assert err <= RTOL * ref + 1e-6, "%s: max err %g vs max |ref| %g" % (what, err, ref)
+
+
+def _xavier(rng, shape):
+    rf = int(np.prod(shape[:-2]))
+    lim = np.sqrt(6.0 / ((shape[-2] + shape[-1]) * rf))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+# (B, H, W, D, Cin, Cout, k, stride) -- covers: direct stem (Cin 1/5/8), igemm BN=32/64/128 with
+# BK=16/32, ragged M (not a multiple of 128), strided depth with (0,1) padding, k=4 (pad 1,2), k=5 s2
+CONV3D_CASES = [
+    (2, 16, 16, 16, 1, 8, 5, (2, 2, 2)),        # e_conv1
+    (1, 12, 10, 16, 5, 8, 5, (2, 2, 2)),        # texture-net stem, ragged
+    (2, 8, 8, 8, 8, 16, 3, (1, 1, 2)),          # e_conv2
+    (2, 8, 8, 4, 16, 32, 3, (1, 1, 1)),         # e_conv3 (BK=16, BN=32)
+    (2, 8, 8, 4, 32, 32, 3, (1, 1, 1)),         # res1 (BK=32, BN=32)
+    (1, 5, 7, 3, 32, 32, 3, (1, 1, 1)),         # ragged M = 105
+    (1, 6, 6, 6, 16, 16, 3, (1, 1, 1)),         # texture 16-ch trunk (Cout 16 -> Npad 32)
+    (1, 8, 8, 8, 8, 4, 4, (1, 1, 1)),           # texture decoder conv3d k4 (pad 1,2), direct
+    (1, 6, 6, 6, 32, 64, 3, (1, 1, 1)),         # BN=64
+    (1, 4, 4, 4, 64, 128, 3, (2, 2, 2)),        # BN=128, stride 2
+]
+
+
+@pytest.mark.parametrize("case", CONV3D_CASES)
+def test_conv3d(case):
+    from rendernet_amd import ops
+    B, H, W, D, Cin, Cout, k, s = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, D, Cin)
+    w = _xavier(rng, (k, k, k, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    # plain
+    _close(ops.conv3d(_dev(x), pw, _dev(b), stride=s), OL.conv3d(x, w, b, s), "conv3d")
+    # bias + PReLU
+    want = OL.prelu(OL.conv3d(x, w, b, s), alpha)
+    _close(ops.conv3d(_dev(x), pw, _dev(b), _dev(alpha), stride=s), want, "conv3d+prelu")
+    # bias + residual
+    y0 = OL.conv3d(x, w, b, s)
+    res = _rand(rng, *y0.shape)
+    _close(ops.conv3d(_dev(x), pw, _dev(b), None, _dev(res), stride=s), y0 + torch.from_numpy(res), "conv3d+res")
+    # no bias
+    _close(ops.conv3d(_dev(x), pw, None, stride=s), OL.conv3d(x, w, None, s), "conv3d nobias")
+
+
+CONV2D_CASES = [
+    (2, 16, 16, 256, 256, 3, (1, 1)),      # res2-like (BN=128, BK=32)
+    (1, 9, 11, 128, 64, 3, (1, 1)),        # ragged M, BN=64
+    (2, 8, 8, 256, 128, 4, (1, 1)),        # e_conv5-like 4x4 (pad 1,2)
+    (1, 8, 8, 64, 32, 4, (1, 1)),          # BN=32
+    (1, 16, 16, 48, 96, 3, (1, 1)),        # Cin multiple of 16 only (BK=16), Cout 96 -> Npad 96 (BN=32)
+    (1, 16, 16, 32, 32, 3, (2, 2)),        # strided 2-D conv
+    (1, 12, 12, 3, 8, 3, (1, 1)),          # direct path, Cin=3
+    (2, 8, 8, 1024, 128, 1, (1, 1)),       # 1x1, long K
+]
+
+
+@pytest.mark.parametrize("case", CONV2D_CASES)
+def test_conv2d(case):
+    from rendernet_amd import ops
+    B, H, W, Cin, Cout, k, s = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (k, k, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    y0 = OL.conv2d(x, w, b, s)
+    _close(ops.conv2d(_dev(x), pw, _dev(b), stride=s), y0, "conv2d")
+    res = _rand(rng, *y0.shape)
+    want = OL.prelu(y0, alpha) + torch.from_numpy(res)
+    _close(ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res), stride=s), want, "conv2d+prelu+res")
+    _close(ops.conv2d(_dev(x), pw, _dev(b), stride=s, sigmoid=True), torch.sigmoid(y0), "conv2d+sigmoid")
+
+
+CONVT2D_CASES = [
+    (2, 8, 8, 256, 128, 2),    # e_conv7
+    (1, 16, 16, 128, 128, 1),  # e_conv7_1
+    (1, 16, 16, 128, 64, 2),   # e_conv8
+    (1, 9, 7, 64, 32, 2),      # e_conv9, ragged
+    (1, 16, 16, 32, 16, 1),    # e_conv10 (Cout 16 -> Npad 32)
+    (2, 16, 16, 16, 1, 1),     # e_conv11 greyscale (direct)
+    (1, 16, 16, 16, 3, 1),     # e_conv11 RGB (direct)
+    (1, 8, 8, 16, 3, 2),       # texture heads: stride-2 to 3 channels (direct, phases)
+]
+
+
+@pytest.mark.parametrize("case", CONVT2D_CASES)
+def test_conv2d_transpose(case):
+    from rendernet_amd import ops
+    B, H, W, Cin, Cout, s = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (4, 4, Cout, Cin))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv_transpose(_dev(w), s)
+    y0 = OL.conv2d_transpose(x, w, b, (s, s))
+    _close(ops.conv2d_transpose(_dev(x), pw, _dev(b), stride=(s, s)), y0, "convT")
+    _close(ops.conv2d_transpose(_dev(x), pw, _dev(b), _dev(alpha), stride=(s, s)), OL.prelu(y0, alpha), "convT+prelu")
+    _close(ops.conv2d_transpose(_dev(x), pw, _dev(b), stride=(s, s), sigmoid=True), torch.sigmoid(y0), "convT+sigmoid")
+
+
+@pytest.mark.parametrize("case", [(1, 6, 6, 6, 4, 4, 1), (1, 5, 6, 4, 4, 8, 2), (1, 4, 4, 4, 16, 16, 2)])
+def test_conv3d_transpose(case):
+    from rendernet_amd import ops
+    B, H, W, D, Cin, Cout, s = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, D, Cin)
+    w = _xavier(rng, (4, 4, 4, Cout, Cin))
+    b = _rand(rng, Cout) * 0.1
+    pw = ops.pack_conv_transpose(_dev(w), s)
+    _close(ops.conv3d_transpose(_dev(x), pw, _dev(b), stride=(s, s, s)), OL.conv3d_transpose(x, w, b, (s, s, s)), "convT3d")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 8, 32), (1, 5, 7, 4, 16), (1, 4, 4, 32, 32)])
+def test_projection_unit(case):
+    """Depth-flatten + 1x1 conv + PReLU in one kernel, feature index f = d*C + c."""
+    from rendernet_amd import ops
+    B, H, W, D, C = case
+    F = D * C
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, D, C)
+    w = _xavier(rng, (1, 1, F, F))
+    b = _rand(rng, F) * 0.1
+    alpha = rng.uniform(0, 0.25, F).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    _close(ops.projection(_dev(x), pw, _dev(b), _dev(alpha)), OL.projection_unit(x, w, b, alpha), "projection")
+
+
+def test_fully_connected_and_prelu():
+    from rendernet_amd import ops
+    rng = np.random.default_rng(11)
+    x = _rand(rng, 5, 199)
+    w = _rand(rng, 199, 1000) * 0.02
+    b = _rand(rng, 1000) * 0.1
+    alpha = rng.uniform(0, 0.25, 1000).astype(np.float32)
+    _close(ops.fully_connected(_dev(x), _dev(w), _dev(b), _dev(alpha)), OL.prelu(OL.fully_connected(x, w, b), alpha), "fc")
+    t = _rand(rng, 3, 7, 5, 24)
+    a = rng.uniform(0, 0.25, 24).astype(np.float32)
+    _close(ops.prelu(_dev(t), _dev(a)), OL.prelu(t, a), "prelu")
+
+
+def test_asymmetric_weights_catch_transposes():
+    """A = I check with an asymmetric B: a 1x1 conv with an identity-like input must return the
+    filter rows themselves (catches row/col swaps in the MFMA C/D mapping)."""
+    from rendernet_amd import ops
+    Cin, Cout = 64, 128
+    x = np.zeros((1, 8, 8, Cin), np.float32)
+    for p in range(64):
+        x[0, p // 8, p % 8, p] = 1.0
+    w = (np.arange(Cin)[:, None] * 1000 + np.arange(Cout)[None, :]).astype(np.float32).reshape(1, 1, Cin, Cout)
+    pw = ops.pack_conv(_dev(w))
+    got = ops.conv2d(_dev(x), pw).cpu().numpy().reshape(64, Cout)
+    assert np.array_equal(got, w.reshape(Cin, Cout))
+
+
+def test_bad_arguments_raise():
+    from rendernet_amd import ops
+    from rendernet_amd._lib import RenderNetHipError
+    w = torch.zeros((3, 3, 16, 16), device="cuda")
+    pw = ops.pack_conv(w)
+    with pytest.raises(RenderNetHipError):
+        ops.conv2d(torch.zeros((1, 4, 4, 8), device="cuda"), pw)       # channel mismatch
+    with pytest.raises(RenderNetHipError):
+        ops.conv2d(torch.zeros((1, 4, 4, 16)), pw)                     # CPU tensor: no fallback

@@ -1,0 +1,111 @@
+"""Parity of the HIP resampler (through the C ABI) against oracle/resample.py.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import demo_pose
+from oracle import resample as OR
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(a).cuda()
+
+
+def _poses(n, seed=0):
+    rng = np.random.default_rng(seed)
+    p = np.stack([rng.uniform(0, 2 * np.pi, n), rng.uniform(0.2, 2.6, n), rng.uniform(0.75, 1.3, n)], 1)
+    return p.astype(np.float32)
+
+
+def test_affine_bit_exact_raw_layout(fixtures_vox):
+    """rn_resample_affine_fwd evaluates the same operations in the same order as the oracle's
+    'ordered' mode: bit-for-bit equality on all five fixtures (integer-exact bar for byte-identical
+    arithmetic, not a tolerance)."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    poses = np.stack([demo_pose(), demo_pose(10, 20, 2.8), demo_pose(123, 75, 4.2), demo_pose(300, 45, 3.0),
+                      demo_pose(77, 10, 3.6)])
+    m_inv = OR.inverse_affine(poses, 64, 128)
+    want = OR.resampling_affine(fixtures_vox, m_inv, 128, mode="ordered")
+    got = tf_resampling_affine(_dev(fixtures_vox), _dev(m_inv), 128, image_layout=False).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "max |diff| = %g" % np.abs(got - want).max()
+
+
+def test_affine_bit_exact_image_layout_and_crop(fixtures_vox):
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    poses = _poses(5, 3)
+    m_inv = OR.inverse_affine(poses, 64, 128)
+    want = OR.transform_voxel_to_match_image(OR.resampling_affine(fixtures_vox, m_inv, 128, mode="ordered"))
+    got = tf_resampling_affine(_dev(fixtures_vox), _dev(m_inv), 128, image_layout=True).cpu().numpy()
+    assert np.array_equal(got, want)
+    # crop window (tools/model_util.py:95-98) folded into the kernel
+    r, c, p = 40, 8, 64
+    gotc = tf_resampling_affine(_dev(fixtures_vox), _dev(m_inv), 128, image_layout=True, window=(r, c, p, p))
+    assert np.array_equal(gotc.cpu().numpy(), want[:, r:r + p, c:c + p])
+
+
+def test_pose_path_matches_tf_oracle(fixtures_vox):
+    """rn_resample_fwd (pose -> closed-form matrix in-kernel) against the TF-faithful oracle
+    (float32 matrix chain + LU inverse + matmul).  The sampler is discontinuous at x=0- and
+    x=(S-1)-, so a ~1e-6 coordinate difference may flip isolated samples next to
+    occupied border voxels: tolerance 2e-4 on all but <= 1e-5 of the samples."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_rotation_resampling
+    poses = np.stack([demo_pose(250 + 15 * i, 60, 3.3) for i in range(5)])
+    want = OR.rotation_resampling(fixtures_vox, poses, 64, 128, mode="tf")
+    got = tf_rotation_resampling(_dev(fixtures_vox), _dev(poses), 64, 128).cpu().numpy()
+    d = np.abs(got - want)
+    frac = float((d > 2e-4).mean())
+    assert frac <= 1e-5, "fraction of samples off by > 2e-4: %g (max %g)" % (frac, d.max())
+    assert abs(float(got.sum()) - float(want.sum())) / float(want.sum()) < 1e-4
+
+
+def test_pose_to_affine_closed_form():
+    from rendernet_amd import ops
+    poses = _poses(16, 1)
+    want = OR.inverse_affine(poses, 64, 128)
+    got = ops.pose_to_affine(_dev(poses), 64, 128).cpu().numpy()
+    assert np.abs(got[:, :, :3] - want[:, :, :3]).max() < 1e-6
+    assert np.abs(got[:, :, 3] - want[:, :, 3]).max() < 2e-5
+
+
+def test_multichannel_and_small_grids():
+    """C = 4 (texture grids, RenderNet_Texture_Face_Normal.py:169-171), C = 5 (generic path), and
+    ragged sizes 16^3 -> 32^3 / 32^3 -> 64^3."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    rng = np.random.default_rng(5)
+    for S, N, C in ((16, 32, 4), (32, 64, 1), (16, 32, 5), (8, 16, 2)):
+        vox = rng.standard_normal((3, S, S, S, C)).astype(np.float32)
+        m_inv = OR.inverse_affine(_poses(3, S), S, N)
+        want = OR.transform_voxel_to_match_image(OR.resampling_affine(vox, m_inv, N, mode="ordered"))
+        got = tf_resampling_affine(_dev(vox), _dev(m_inv), N, image_layout=True).cpu().numpy()
+        assert np.array_equal(got, want), (S, N, C, np.abs(got - want).max())
+
+
+def test_known_answers_identity_like_pose(fixtures_vox):
+    """az = pi/2, el = 0, s = 1 makes R the identity: out[32:95]^3 == in[:63]^3 exactly and the
+    last source plane contributes nothing."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    m = np.zeros((5, 3, 4), np.float32)
+    m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = 1.0
+    m[:, :, 3] = -32.0
+    got = tf_resampling_affine(_dev(fixtures_vox), _dev(m), 128, image_layout=False).cpu().numpy()
+    assert np.array_equal(got[:, 32:95, 32:95, 32:95], fixtures_vox[:, :63, :63, :63])
+    inner = got[:, 32:96, 32:96, 32:96].copy()
+    got[:, 32:95, 32:95, 32:95] = 0
+    assert np.all(got == 0), "everything outside [0,S-1) must cancel to exactly 0 for this pose"
+    assert np.all(inner[:, 63] == 0) and np.all(inner[:, :, 63] == 0) and np.all(inner[:, :, :, 63] == 0)
+
+
+def test_argument_errors():
+    from rendernet_amd import ops
+    from rendernet_amd._lib import RenderNetHipError
+    vox = torch.zeros((1, 8, 8, 8, 1), device="cuda")
+    pose = torch.zeros((1, 3), device="cuda")
+    with pytest.raises(RenderNetHipError):
+        ops.resample(vox, pose, new_size=12)            # not a supported grid size
+    with pytest.raises(RenderNetHipError):
+        ops.resample(vox, pose, new_size=16, window=(8, 8, 16, 16))   # window outside the grid
+    with pytest.raises(RenderNetHipError):
+        ops.resample(vox.cpu(), pose.cpu(), new_size=16)  # no CPU path
