@@ -48,7 +48,20 @@ def cpu_baseline(weights, frames=2):
     from oracle import rendernet as ON
     from oracle import resample as OR
     vox, poses = synthetic_batch(frames)
-    cores = os.cpu_count() or 1
+    # pick the thread count that runs the dominant conv fastest on this box (all cores of a large
+    # host oversubscribe oneDNN on a batch this small)
+    import torch.nn.functional as F
+    ncpu = os.cpu_count() or 1
+    xx, ww = torch.randn(1, 1024, 64, 64), torch.randn(1024, 1024, 3, 3)
+    best, cores = None, 1
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(th)
+        F.conv2d(xx[:, :, :16], ww, padding=1)
+        t0 = time.time()
+        F.conv2d(xx, ww, padding=1)
+        dt = time.time() - t0
+        if best is None or dt < best:
+            best, cores = dt, th
     torch.set_num_threads(cores)
     t0 = time.time()
     x = OR.net_input(vox, poses, 64, 128)

@@ -19,6 +19,9 @@ SOURCES = ["capi.hip", "conv_igemm.hip", "conv_direct.hip", "resample.hip", "mis
 HEADERS = ["rn_common.h", os.path.join("..", "..", "include", "rendernet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# the resampler must round after every multiply and add (bit parity with the reference's op-by-op
+# TF graph): hipcc's default -ffp-contract=fast would fuse them into FMAs
+EXTRA_FLAGS = {"resample.hip": ["-ffp-contract=off"]}
 
 
 def lib_path():
@@ -42,15 +45,15 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         stamp = obj + ".sha"
-        dig = _digest([src] + hdrs)
+        dig = _digest([src] + hdrs) + "|" + " ".join(EXTRA_FLAGS.get(s, []))
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
-        jobs.append((src, obj, stamp, dig))
+        jobs.append((src, obj, stamp, dig, EXTRA_FLAGS.get(s, [])))
 
     def compile_one(job):
-        src, obj, stamp, dig = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        src, obj, stamp, dig, extra = job
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -15,6 +15,10 @@
 #include "rn_common.h"
 #include <math.h>
 
+// One rounding per multiply and per add, as in the reference's op-by-op graph: no FMA contraction
+// anywhere in this file (also enforced with -ffp-contract=off in rendernet_amd/build.py).
+#pragma clang fp contract(off)
+
 struct ResampleArgs {
     const float* vox;     // [B,S,S,S,C]
     const float* mat;     // FROM_POSE ? pose [B,3] : m_inv [B,12]
