@@ -1,0 +1,155 @@
+"""CPU-side checks: binvox reader, C-ABI symbol export, host logic (variable names, shapes,
+parameter count, pose convention, CLI surface), weight packing geometry.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import BINVOX_DIR, FIXTURES, ROOT
+
+
+def test_binvox_fixtures_decode(fixtures_vox):
+    """Occupancy counts of the five shipped fixtures, product reader == oracle reader."""
+    from rendernet_amd.tools import binvox_rw
+    want = {"chair": 5277, "bunny": 57835, "table": 61087, "suzanne": 30270, "teapot": 27933}
+    for i, n in enumerate(FIXTURES):
+        with open(os.path.join(BINVOX_DIR, n + ".binvox"), "rb") as f:
+            v = binvox_rw.read_as_3d_array(f)
+        assert v.dims == [64, 64, 64] and v.axis_order == "xyz" and v.data.dtype == bool
+        assert int(v.data.sum()) == want[n]
+        assert np.array_equal(v.data.astype(np.float32), fixtures_vox[i, ..., 0])
+    occ = np.argwhere(fixtures_vox[0, ..., 0] > 0)
+    assert (occ.min(0) == [17, 0, 12]).all() and (occ.max(0) == [46, 63, 51]).all()     # chair bbox
+
+
+def test_binvox_rejects_garbage(tmp_path):
+    from rendernet_amd.tools import binvox_rw
+    p = tmp_path / "bad.binvox"
+    p.write_bytes(b"#notbinvox 1\n")
+    with open(p, "rb") as f, pytest.raises(IOError):
+        binvox_rw.read_as_3d_array(f)
+    p.write_bytes(b"#binvox 1\ndim 4 4 4\ntranslate 0 0 0\nscale 1\ndata\n\x01\x05")
+    with open(p, "rb") as f, pytest.raises(IOError):
+        binvox_rw.read_as_3d_array(f)                 # decodes to 5 voxels, header says 64
+    # fix_coords=False keeps the file's xzy order
+    payload = bytes([1, 3, 0, 61])
+    p.write_bytes(b"#binvox 1\ndim 4 4 4\ntranslate 0 0 0\nscale 1\ndata\n" + payload)
+    with open(p, "rb") as f:
+        a = binvox_rw.read_as_3d_array(f, fix_coords=False)
+    with open(p, "rb") as f:
+        b = binvox_rw.read_as_3d_array(f)
+    assert a.axis_order == "xzy" and np.array_equal(np.transpose(a.data, (0, 2, 1)), b.data)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads and exports exactly the functions include/rendernet_hip.h declares,
+    and the ctypes binding table lists each of them."""
+    from rendernet_amd import _lib
+    from rendernet_amd.build import build
+    so = build(verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "rendernet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    assert L.rn_version() == 100
+    # geometry helper is pure host code: [phase][ceil(K/4)][Npad][4]
+    n = L.rn_packed_weight_floats(_lib.RN_PACK_CONV, 3, _lib.ivec([5, 5, 5]), 1, 8)
+    assert n == 1 * 32 * 32 * 4                               # K=125 -> 32 quads, Npad 32
+    n = L.rn_packed_weight_floats(_lib.RN_PACK_CONVT_S2, 2, _lib.ivec([4, 4]), 256, 128)
+    assert n == 4 * (4 * 256 // 4) * 128 * 4
+    assert L.rn_packed_weight_floats(_lib.RN_PACK_CONVT_S2, 2, _lib.ivec([3, 3]), 8, 8) == 0
+    assert b"k=4" in L.rn_last_error()
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    from rendernet_amd import ops
+    from rendernet_amd._lib import RenderNetHipError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RenderNetHipError):
+        ops.resample(torch.zeros(1, 8, 8, 8, 1), torch.zeros(1, 3), 16)
+    from rendernet_amd.shader import Renderer, tiny_spec
+    with pytest.raises(RuntimeError):
+        Renderer(tiny_spec(), device="cpu")
+
+
+def test_variable_names_and_parameter_count():
+    """TF variable names and the 237,270,425-parameter total (App. B)."""
+    from rendernet_amd.shader import ShaderSpec, shader_variable_shapes, init_shader_weights, tiny_spec
+    shapes = shader_variable_shapes(ShaderSpec().check())
+    names = [n for n, _, _ in shapes]
+    assert len(names) == len(set(names))
+    assert sum(int(np.prod(s)) for _, s, _ in shapes) == 237270425
+    for must in ("encoder/e_conv1/e_conv1/weights", "encoder/e_conv1/alpha", "encoder/res1_7/con1_3X3/weights",
+                 "encoder/res1_7/conv2_3x3/biases", "encoder/res1_skip/con1_3X3/weights",
+                 "encoder/projection_unit/Conv/weights", "encoder/projection_unit/alpha",
+                 "encoder/res2_10/alpha", "encoder/res2_skip/con1_3X3/biases", "encoder/e_conv5/e_conv5/weights",
+                 "encoder/res3_5/conv2_3x3/weights", "encoder/e_conv7_1/e_conv7_1/weights", "encoder/e_conv11/weights"):
+        assert must in names, must
+    d = dict((n, s) for n, s, _ in shapes)
+    assert d["encoder/e_conv1/e_conv1/weights"] == [5, 5, 5, 1, 8]
+    assert d["encoder/e_conv7/e_conv7/weights"] == [4, 4, 128, 256]          # [kh,kw,Cout,Cin]
+    assert d["encoder/projection_unit/Conv/weights"] == [1, 1, 1024, 1024]
+    w = init_shader_weights(tiny_spec(3), seed=5)
+    assert w["encoder/e_conv11/weights"].shape == (4, 4, 3, 16)
+    assert np.all(w["encoder/e_conv1/e_conv1/biases"] == np.float32(0.001))   # tools/layer_util.py:142
+    assert np.all(w["encoder/res2_1/con1_3X3/biases"] == 0) and np.all(w["encoder/e_conv5/alpha"] == 0)
+    lim = np.sqrt(6.0 / (125 * (1 + 8)))
+    assert np.abs(w["encoder/e_conv1/e_conv1/weights"]).max() <= lim
+    w2 = init_shader_weights(tiny_spec(3), seed=5)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)                         # seeded
+
+
+def test_variable_store_scopes_on_cpu():
+    from rendernet_amd import variables as V
+    st = V.VariableStore("cpu", seed=0)
+    with st.variable_scope("encoder"):
+        with st.variable_scope("e_conv1"):
+            v, name = st.get_variable("weights", [3, 3, 2, 4], V.xavier_initializer())
+            assert name == "encoder/e_conv1/weights" and tuple(v.shape) == (3, 3, 2, 4)
+            v2, _ = st.get_variable("weights", [3, 3, 2, 4], V.xavier_initializer())
+            assert v2 is v
+            with pytest.raises(ValueError):
+                st.get_variable("weights", [1, 1, 2, 4], V.xavier_initializer())
+    with pytest.raises(KeyError):
+        st.get_variable("missing")
+    sd = st.state_dict()
+    st2 = V.VariableStore("cpu")
+    st2.load_state_dict(sd)
+    assert st2.num_parameters() == 72
+
+
+def test_pose_convention_and_demo_cli_surface():
+    """RenderNet_demo.py:33-38 pose parameters and :72-108 flags."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("RenderNet_demo", os.path.join(ROOT, "RenderNet_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    p = demo.compute_pose_param(250, 60, 3.3)
+    assert p.shape == (1, 3)
+    assert np.allclose(p[0], [250 * np.pi / 180, 30 * np.pi / 180, 1.0])
+    args = demo.build_parser().parse_args([])
+    assert (args.azimuth, args.elevation, args.light_azimuth, args.light_elevation, args.radius) == (250, 60, 250, 60, 3.3)
+    assert args.render_dir == "./render" and args.rotate is False
+    assert demo.build_parser().parse_args(["--rotate", "True"]).rotate is True
+    from oracle.io_phong import compute_pose_param as ocp
+    assert np.allclose(ocp(123, 45, 2.9), demo.compute_pose_param(123, 45, 2.9))
+
+
+def test_phong_light_and_oracle_composite():
+    from rendernet_amd.tools.Phong_shading import generate_light_pos
+    from oracle import io_phong as OP
+    assert np.allclose(generate_light_pos(60, 250), OP.generate_light_pos(60, 250))
+    l = generate_light_pos(90, 90)
+    assert np.allclose(l, [[0, 0, -1]], atol=1e-7) or np.allclose(l, [[-6.1e-17, 6.1e-17, -1]], atol=1e-6)
+    img = np.random.default_rng(0).uniform(0, 1, (1, 4, 4, 3))
+    out = OP.np_phong_composite(img, OP.generate_light_pos(60, 250), np.array([[1., 1., 1.]]), 0.1, 0.9)
+    assert out.shape == img.shape and out.min() >= 0 and out.max() <= 1
