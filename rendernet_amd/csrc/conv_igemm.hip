@@ -19,10 +19,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmArgs {
     const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y;
     int M;
+    unsigned x_bytes;
     int I0, I1, I2, Cin;
     int O0, O1, O2, Cout, Npad;
     int K0, K1, K2, S0, S1, S2, P0, P1, P2;
@@ -100,65 +102,66 @@ void conv_igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // A is fetched through a buffer resource: SAME-padding taps and rows past M get a byte offset
+    // >= 2^31 (beyond num_records), for which the hardware returns zeros -- no branches, no selects.
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
     // K-walk state: tap (t0,t1,t2) and channel slice
     int t0 = 0, t1 = 0, t2 = 0, ct = 0;
-    long long aoff[APASS]; bool aok[APASS];
-    auto tap_setup = [&]() {
-#pragma unroll
-        for (int p = 0; p < APASS; ++p) {
-            const int i0 = r0[p] + t0, i1 = r1[p] + t1, i2 = r2[p] + t2;
-            aok[p] = rb[p] >= 0 && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 &&
-                     (unsigned)i2 < (unsigned)a.I2;
-            aoff[p] = ((((long long)rb[p] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cin + acg * 4;
-        }
-    };
-    tap_setup();
+    unsigned aoff[APASS];
+#define RN_TAP_SETUP()                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < APASS; ++p) {                                                  \
+        const int i0 = r0[p] + t0, i1 = r1[p] + t1, i2 = r2[p] + t2;                                     \
+        const bool ok = rb[p] >= 0 && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 &&  \
+                        (unsigned)i2 < (unsigned)a.I2;                                                   \
+        const unsigned e = (unsigned)(((rb[p] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * (unsigned)a.Cin;  \
+        aoff[p] = ok ? (e + acg * 4) * 4u : OOB;                                                         \
+    }
+    RN_TAP_SETUP();
 
-    float4 ra[APASS], rbv[BPT];
-    auto gload = [&](int kt) {
-        const int c0 = ct * BK;
-#pragma unroll
-        for (int p = 0; p < APASS; ++p) {
-            ra[p] = aok[p] ? *reinterpret_cast<const float4*>(a.x + aoff[p] + c0)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* wk = a.w + ((size_t)kt * (BK / 4) * a.Npad + n0) * 4;
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) {
-            const int idx = tid + i * NT;
-            if (BF4 % NT == 0 || idx < BF4) {
-                const int r = idx / BN, j = idx % BN;
-                rbv[i] = *reinterpret_cast<const float4*>(wk + ((size_t)r * a.Npad + j) * 4);
-            }
-        }
-        // advance the K-walk
-        if (++ct == a.ctiles) {
-            ct = 0;
-            if (++t2 == a.K2) { t2 = 0; if (++t1 == a.K1) { t1 = 0; ++t0; } }
-            tap_setup();
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* Ab = As + buf * BM * LDA;
-        float* Bb = Bs + buf * BK * BN;
-#pragma unroll
-        for (int p = 0; p < APASS; ++p)
-            *reinterpret_cast<float4*>(Ab + (arow + p * RPP) * LDA + acg * 4) = ra[p];
-#pragma unroll
-        for (int i = 0; i < BPT; ++i) {
-            const int idx = tid + i * NT;
-            if (BF4 % NT == 0 || idx < BF4) *reinterpret_cast<float4*>(Bb + idx * 4) = rbv[i];
-        }
-    };
+    u32x4 ra[APASS];
+    f32x4 rbv[BPT];
+    // global -> registers for K-tile kt (then advance the K-walk)
+#define RN_GLOAD(kt)                                                                                     \
+    {                                                                                                    \
+        const unsigned c0b = (unsigned)ct * (BK * 4);                                                    \
+        _Pragma("unroll") for (int p = 0; p < APASS; ++p)                                                \
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[p] + c0b, 0, 0);                   \
+        const float* wk = a.w + ((size_t)(kt) * (BK / 4) * a.Npad + n0) * 4;                             \
+        _Pragma("unroll") for (int i = 0; i < BPT; ++i) {                                                \
+            const int idx = tid + i * NT;                                                                \
+            if (BF4 % NT == 0 || idx < BF4)                                                              \
+                rbv[i] = *reinterpret_cast<const f32x4*>(wk + ((size_t)(idx / BN) * a.Npad + idx % BN) * 4); \
+        }                                                                                                \
+        if (++ct == a.ctiles) {                                                                          \
+            ct = 0;                                                                                      \
+            if (++t2 == a.K2) { t2 = 0; if (++t1 == a.K1) { t1 = 0; ++t0; } }                            \
+            RN_TAP_SETUP();                                                                              \
+        }                                                                                                \
+    }
+    // registers -> LDS stage `buf`
+#define RN_LSTORE(buf)                                                                                   \
+    {                                                                                                    \
+        float* Ab_ = As + (buf) * BM * LDA;                                                              \
+        float* Bb_ = Bs + (buf) * BK * BN;                                                               \
+        _Pragma("unroll") for (int p = 0; p < APASS; ++p)                                                \
+            *reinterpret_cast<u32x4*>(Ab_ + (arow + p * RPP) * LDA + acg * 4) = ra[p];                   \
+        _Pragma("unroll") for (int i = 0; i < BPT; ++i) {                                                \
+            const int idx = tid + i * NT;                                                                \
+            if (BF4 % NT == 0 || idx < BF4) *reinterpret_cast<f32x4*>(Bb_ + idx * 4) = rbv[i];         \
+        }                                                                                                \
+    }
 
-    gload(0);
-    lstore(0);
+    RN_GLOAD(0);
+    RN_LSTORE(0);
     __syncthreads();
 
     int cur = 0;
     for (int kt = 0; kt < a.nk; ++kt) {
         const bool more = kt + 1 < a.nk;
-        if (more) gload(kt + 1);
+        if (more) RN_GLOAD(kt + 1);
 
         const float* Ab = As + cur * BM * LDA + (wm * WTM + li) * LDA + lh * 4;
         const float* Bb = Bs + cur * BK * BN + (lh * BN + wn * WTN + li) * 4;
@@ -180,10 +183,13 @@ void conv_igemm_kernel(const IgemmArgs a)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
 
-        if (more) lstore(cur ^ 1);
+        if (more) RN_LSTORE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef RN_TAP_SETUP
+#undef RN_GLOAD
+#undef RN_LSTORE
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -243,6 +249,9 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
     const long long M = (long long)p.B * p.O[0] * p.O[1] * p.O[2];
     if (M <= 0 || M > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: M=%lld", M);
     a.M = (int)M;
+    const long long xb = (long long)p.B * p.I[0] * p.I[1] * p.I[2] * p.Cin * 4;
+    if (xb >= 0x80000000LL) return rn_set_error(RN_E_UNSUPPORTED, "conv_igemm: input of %lld bytes exceeds the 2 GiB buffer window", xb);
+    a.x_bytes = (unsigned)xb;
     a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.Cin = p.Cin;
     a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2]; a.Cout = p.Cout; a.Npad = p.Npad;
     a.K0 = p.K[0]; a.K1 = p.K[1]; a.K2 = p.K[2];
