@@ -4,6 +4,7 @@
 #include "rn_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -37,6 +38,8 @@ static inline void same_geom(int in, int k, int s, int& out, int& pad_lo)
 
 static int dispatch(const RnConvProblem& p, hipStream_t st)
 {
+    static const bool no_drun = getenv("RN_NO_DRUN") != nullptr;
+    if (!no_drun && rn_drun_supported(p)) return rn_launch_conv3d_drun(p, st);
     if (rn_igemm_supported(p)) return rn_launch_conv_igemm(p, st);
     return rn_launch_conv_direct(p, st);
 }

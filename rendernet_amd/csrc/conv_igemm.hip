@@ -16,6 +16,7 @@
 //   blockIdx -> tile mapping is XCD-aware: each XCD (private 4 MiB L2) walks a contiguous run of
 //   tiles with the N tiles of one M tile adjacent, so A slices are fetched once per XCD.
 #include "rn_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,8 +33,8 @@ struct IgemmArgs {
     int act, ctiles, nk, mtiles, ntiles;
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN)
+template <int BM, int BN, int BK, int WM, int WN, int VAR = 0>
+__global__ __launch_bounds__(64 * WM * WN, (VAR >= 2 ? 3 : 1))
 void conv_igemm_kernel(const IgemmArgs a)
 {
     constexpr int NT = 64 * WM * WN;
@@ -167,6 +168,7 @@ void conv_igemm_kernel(const IgemmArgs a)
         const float* Bb = Bs + cur * BK * BN + (lh * BN + wn * WTN + li) * 4;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
+            if ((VAR & 1) && kb == BK / 8 - 1 && more) RN_LSTORE(cur ^ 1);
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -183,7 +185,7 @@ void conv_igemm_kernel(const IgemmArgs a)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
 
-        if (more) RN_LSTORE(cur ^ 1);
+        if (!(VAR & 1) && more) RN_LSTORE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -216,7 +218,7 @@ void conv_igemm_kernel(const IgemmArgs a)
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int VAR = 0>
 static int launch_cfg(IgemmArgs& a, hipStream_t st)
 {
     a.mtiles = (a.M + BM - 1) / BM;
@@ -224,7 +226,7 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st)
     a.ctiles = a.Cin / BK;
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * (BK + 4) * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, VAR>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -260,10 +262,17 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
     a.os_b = p.os_b; a.os0 = p.os[0]; a.os1 = p.os[1]; a.os2 = p.os[2]; a.out_off = p.out_off;
     a.act = p.act;
     const bool k32 = p.Cin % 32 == 0;
+    // VAR bit0: write the next K-tile into LDS before the last MFMA group instead of after it (the
+    // ds_writes then issue under the MFMAs); VAR>=2: BK=16 at >=3 waves/SIMD.  Measured on res2
+    // (B=24): VAR0 129.3, VAR1 133.4, VAR2 134.2, VAR3 133.6 TFLOP/s -- VAR1 is the default.
+    static const int variant = getenv("RN_IGEMM_VARIANT") ? atoi(getenv("RN_IGEMM_VARIANT")) : 1;
     if (p.Npad % 128 == 0) {
-        return k32 ? launch_cfg<128, 128, 32, 2, 2>(a, st) : launch_cfg<128, 128, 16, 2, 2>(a, st);
+        if (variant == 0 && k32) return launch_cfg<128, 128, 32, 2, 2, 0>(a, st);
+        if (variant == 2) return launch_cfg<128, 128, 16, 2, 2, 2>(a, st);
+        if (variant == 3) return launch_cfg<128, 128, 16, 2, 2, 3>(a, st);
+        return k32 ? launch_cfg<128, 128, 32, 2, 2, 1>(a, st) : launch_cfg<128, 128, 16, 2, 2, 1>(a, st);
     } else if (p.Npad % 64 == 0) {
-        return k32 ? launch_cfg<128, 64, 32, 2, 2>(a, st) : launch_cfg<128, 64, 16, 2, 2>(a, st);
+        return k32 ? launch_cfg<128, 64, 32, 2, 2, 1>(a, st) : launch_cfg<128, 64, 16, 2, 2, 1>(a, st);
     }
-    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, st) : launch_cfg<128, 32, 16, 4, 1>(a, st);
+    return k32 ? launch_cfg<128, 32, 32, 4, 1, 1>(a, st) : launch_cfg<128, 32, 16, 4, 1, 1>(a, st);
 }

@@ -33,5 +33,7 @@ int rn_check_launch(const char* what);
 int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st);     // conv_igemm.hip  (MFMA)
 int rn_launch_conv_direct(const RnConvProblem& p, hipStream_t st);    // conv_direct.hip (VALU)
 bool rn_igemm_supported(const RnConvProblem& p);
+int rn_launch_conv3d_drun(const RnConvProblem& p, hipStream_t st);     // conv3d_drun.hip (MFMA, 3^3 s1, N=32)
+bool rn_drun_supported(const RnConvProblem& p);
 
 static inline int rn_round_up(int a, int b) { return (a + b - 1) / b * b; }
