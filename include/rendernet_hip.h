@@ -60,10 +60,18 @@ const char* rn_last_error(void);
  *   out   image_layout=1: [B,ph,pw,N,C] = X[b,h0+i,w0+j,k,c] with X = transform(resample(vox))
  *         image_layout=0: [B,N,N,N,C] raw tf_rotation_resampling output (h0=w0=0, ph=pw=N)
  * Semantics reproduced exactly: clamp-then-weight trilinear sampling, add_n order a..h.
+ *
+ * workspace: optional device scratch of rn_resample_workspace_bytes(B,S,C) bytes (per-item matrix +
+ * occupancy bitmap).  With it (and C in {1,4}, S in {16,32,64,128}, N%32==0, ph%8==0, pw%8==0) the
+ * tiled kernel runs: empty tiles are zero-filled at HBM speed and only occupied tiles are sampled,
+ * from LDS.  Without it (NULL) a simple one-kernel path with identical results is used.
  * ---------------------------------------------------------------------------------------- */
+size_t rn_resample_workspace_bytes(int B, int S, int C);
+
 int rn_resample_fwd(const float* vox, const float* pose, float* out,
                     int B, int S, int N, int C,
-                    int h0, int w0, int ph, int pw, int image_layout, void* stream);
+                    int h0, int w0, int ph, int pw, int image_layout,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same kernel, but the caller supplies the inverted 3x4 matrices M_inv [B,3,4]
  * (tools/resampling_voxel_grid.py:601-602) instead of the pose.  Source coordinates are
@@ -71,7 +79,8 @@ int rn_resample_fwd(const float* vox, const float* pose, float* out,
  * bit-reproducible against oracle/resample.py mode="ordered". */
 int rn_resample_affine_fwd(const float* vox, const float* m_inv, float* out,
                            int B, int S, int N, int C,
-                           int h0, int w0, int ph, int pw, int image_layout, void* stream);
+                           int h0, int w0, int ph, int pw, int image_layout,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* pose [B,3] -> M_inv [B,3,4] (closed form of :526-602, evaluated in double). */
 int rn_pose_to_affine(const float* pose, float* m_inv, int B, int S, int N, void* stream);

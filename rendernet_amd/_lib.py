@@ -20,8 +20,9 @@ _ip = ctypes.POINTER(ctypes.c_int)
 SIGNATURES = {
     "rn_version": (_c_int, []),
     "rn_last_error": (ctypes.c_char_p, []),
-    "rn_resample_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp]),
-    "rn_resample_affine_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp]),
+    "rn_resample_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "rn_resample_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp, ctypes.c_size_t, _c_vp]),
+    "rn_resample_affine_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp, ctypes.c_size_t, _c_vp]),
     "rn_pose_to_affine": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "rn_packed_weight_floats": (ctypes.c_size_t, [_c_int, _c_int, _ip, _c_int, _c_int]),
     "rn_pack_weights": (_c_int, [_c_int, _c_int, _ip, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),

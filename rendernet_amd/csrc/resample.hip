@@ -14,6 +14,7 @@
 // entry point is bit-exact against the NumPy oracle evaluated in the same order.
 #include "rn_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 // One rounding per multiply and per add, as in the reference's op-by-op graph: no FMA contraction
 // anywhere in this file (also enforced with -ffp-contract=off in rendernet_amd/build.py).
@@ -215,20 +216,55 @@ static int launch_resample(const ResampleArgs& a, hipStream_t st)
     return rn_check_launch("resample");
 }
 
-extern "C" int rn_resample_fwd(const float* vox, const float* pose, float* out, int B, int S, int N, int C,
-                               int h0, int w0, int ph, int pw, int image_layout, void* stream)
+// tiled production path (resample_tiled.hip)
+bool rn_resample_tiled_supported(int B, int S, int N, int C, int ph, int pw);
+size_t rn_resample_tiled_workspace(int B, int S);
+int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool from_pose, float* out,
+                             int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout,
+                             void* workspace, hipStream_t st);
+
+template <bool FROM_POSE>
+static int resample_entry(const float* vox, const float* mat, float* out, int B, int S, int N, int C,
+                          int h0, int w0, int ph, int pw, int image_layout, void* workspace,
+                          size_t workspace_bytes, void* stream, const char* who)
 {
-    if (!vox || !pose || !out) return rn_set_error(RN_E_INVALID, "rn_resample_fwd: null pointer");
-    ResampleArgs a{vox, pose, out, B, S, N, C, h0, w0, ph, pw, image_layout};
-    return launch_resample<true>(a, (hipStream_t)stream);
+    if (!vox || !mat || !out) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    ResampleArgs a{vox, mat, out, B, S, N, C, h0, w0, ph, pw, image_layout};
+    static const bool force_simple = getenv("RN_RESAMPLE_SIMPLE") != nullptr;
+    if (!force_simple && workspace && B > 0 && rn_resample_tiled_supported(B, S, N, C, ph, pw) &&
+        workspace_bytes >= rn_resample_tiled_workspace(B, S)) {
+        // same argument checks as the simple path
+        if (h0 < 0 || w0 < 0 || ph < 1 || pw < 1 || h0 + ph > N || w0 + pw > N)
+            return rn_set_error(RN_E_INVALID, "resample: crop window out of range");
+        if (!image_layout && (h0 || w0 || ph != N || pw != N))
+            return rn_set_error(RN_E_INVALID, "resample: crop needs image_layout=1");
+        return rn_launch_resample_tiled(vox, mat, FROM_POSE, out, B, S, N, C, h0, w0, ph, pw, image_layout,
+                                        workspace, (hipStream_t)stream);
+    }
+    return launch_resample<FROM_POSE>(a, (hipStream_t)stream);
+}
+
+extern "C" size_t rn_resample_workspace_bytes(int B, int S, int C)
+{
+    (void)C;
+    if (B < 1 || S < 4 || S % 4) return 0;
+    return rn_resample_tiled_workspace(B, S);
+}
+
+extern "C" int rn_resample_fwd(const float* vox, const float* pose, float* out, int B, int S, int N, int C,
+                               int h0, int w0, int ph, int pw, int image_layout,
+                               void* workspace, size_t workspace_bytes, void* stream)
+{
+    return resample_entry<true>(vox, pose, out, B, S, N, C, h0, w0, ph, pw, image_layout, workspace,
+                                workspace_bytes, stream, "rn_resample_fwd");
 }
 
 extern "C" int rn_resample_affine_fwd(const float* vox, const float* m_inv, float* out, int B, int S, int N, int C,
-                                      int h0, int w0, int ph, int pw, int image_layout, void* stream)
+                                      int h0, int w0, int ph, int pw, int image_layout,
+                                      void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!vox || !m_inv || !out) return rn_set_error(RN_E_INVALID, "rn_resample_affine_fwd: null pointer");
-    ResampleArgs a{vox, m_inv, out, B, S, N, C, h0, w0, ph, pw, image_layout};
-    return launch_resample<false>(a, (hipStream_t)stream);
+    return resample_entry<false>(vox, m_inv, out, B, S, N, C, h0, w0, ph, pw, image_layout, workspace,
+                                 workspace_bytes, stream, "rn_resample_affine_fwd");
 }
 
 extern "C" int rn_pose_to_affine(const float* pose, float* m_inv, int B, int S, int N, void* stream)

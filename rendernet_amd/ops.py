@@ -5,6 +5,8 @@ as TF holds them, launches on torch's current stream and allocates its output fr
 caching allocator.  These are `torch.autograd.Function`s (forward implemented in HIP; the
 backward of the training step -- SURVEY.md K13 -- is not built yet and raises).
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -64,9 +66,13 @@ class _Resample(_ForwardOnly):
         B, S, C = vox.shape[0], vox.shape[1], vox.shape[4]
         h0, w0, ph, pw = window
         out = torch.empty((B, ph, pw, N, C), dtype=torch.float32, device=vox.device)
-        fn = L.lib().rn_resample_affine_fwd if affine else L.lib().rn_resample_fwd
-        L.check(fn(L.ptr(vox), L.ptr(pose), L.ptr(out), B, S, N, C, h0, w0, ph, pw,
-                   1 if image_layout else 0, L.stream_ptr()), "rn_resample_fwd")
+        lib = L.lib()
+        nws = int(lib.rn_resample_workspace_bytes(B, S, C))
+        ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=vox.device) if nws else None
+        fn = lib.rn_resample_affine_fwd if affine else lib.rn_resample_fwd
+        L.check(fn(L.ptr(vox), L.ptr(pose), L.ptr(out), B, S, N, C, h0, w0, ph, pw, 1 if image_layout else 0,
+                   ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, nws, L.stream_ptr()),
+                "rn_resample_fwd")
         return out
 
 

@@ -71,12 +71,19 @@ def main():
 
     # resampler
     if not args.only or "resample" in args.only:
-        vox = (torch.rand((B, 64, 64, 64, 1), device=dev, generator=g) < 0.2).float()
-        pose = torch.tensor([[4.36 + 0.26 * i, 0.52, 1.0] for i in range(B)], device=dev)
-        ms = timeit(lambda: ops.resample(vox, pose, 128), args.iters)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import synthetic_batch
+        vox_np, pose_np = synthetic_batch(B)                 # the 5 shipped fixtures, bench poses
+        vox = torch.as_tensor(vox_np).cuda()
+        pose = torch.as_tensor(pose_np).cuda()
+        ms = timeit(lambda: ops.resample(vox, pose, 128), max(args.iters, 20))
         gb = B * 9437184 / (ms * 1e-3) / 1e9
         rows.append(("resample", ms, gb, 1, ms))
-        print("%-12s %9.3f ms  %7.1f GB/s algorithmic" % ("resample", ms, gb), flush=True)
+        print("%-12s %9.3f ms  %7.1f GB/s algorithmic (fixtures)" % ("resample", ms, gb), flush=True)
+        voxd = (torch.rand((B, 64, 64, 64, 1), device=dev, generator=g) < 0.2).float()
+        msd = timeit(lambda: ops.resample(voxd, pose, 128), max(args.iters, 20))
+        print("%-12s %9.3f ms  %7.1f GB/s algorithmic (20%% random-dense volume: worst case, every cell occupied)"
+              % ("resample-dense", msd, B * 9437184 / (msd * 1e-3) / 1e9), flush=True)
 
     conv_case("e_conv1", "conv3d", (B, 128, 128, 128, 1), (5, 5, 5, 1, 8), (2, 2, 2), 1)
     conv_case("e_conv2", "conv3d", (B, 64, 64, 64, 8), (3, 3, 3, 8, 16), (1, 1, 2), 1)
