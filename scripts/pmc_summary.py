@@ -31,11 +31,15 @@ def main():
         for k in names:
             print("    %-28s %.4g" % (k, c[k]))
         if "GRBM_GUI_ACTIVE" in c and dur > 0:
-            clk = c["GRBM_GUI_ACTIVE"] / (dur * 1e-9) / 1e9
-            print("    -> effective clock %.3f GHz" % clk)
+            # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs of the MI355X
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            clk = cyc / (dur * 1e-9) / 1e9
+            print("    -> effective clock %.3f GHz (GRBM_GUI_ACTIVE/8 / duration)" % clk)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-                print("    -> MFMA busy / (GUI_ACTIVE * 256 CU * 4 SIMD) = %.3f ; /(256 CU) = %.3f" % (
-                    c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024), c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 256)))
+                # busy cycles are summed over the 1024 SIMDs (256 CUs x 4); one 32x32x2 f32 MFMA = 64 cycles
+                util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+                print("    -> MFMA utilisation = MFMA_BUSY / (cycles * 1024 SIMDs) = %.3f  (= %.1f TFLOP/s fp32 at this clock)"
+                      % (util, util * 1024 * 64 * clk * 1e9 / 1e12))
 
 
 if __name__ == "__main__":
