@@ -168,7 +168,7 @@ def main():
                                    "cycled, 64^3 -> 128^3 -> 512x512, seeded random weights (237.3M params)",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "batch-sharded x%d, no collective" % world},
             "fraction_of_fp32_conv_roofline": round(fps / world * GMAC_PER_FRAME * 2e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "roofline": {"kernel": "conv_igemm_kernel<128,128,32,2,2,1> on res2 3x3 1024->1024 @64x64xB",
+            "roofline": {"kernel": "conv_igemm_glds_kernel<0> (128x128x32 tile, LDS-DMA) on res2 3x3 1024->1024 @64x64xB",
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,

@@ -52,6 +52,14 @@ def tiny_spec(out_ch=1):
                       w6=64, w7=32, w7_1=32, w8=32, w9=16, w10=16, out_ch=out_ch).check()
 
 
+def stress_spec(out_ch=1):
+    """BASELINE config 5: 128^3 voxels -> 256^3 -> 1024x1024.  The reference net hard-codes its widths for a
+    depth-128 input (RenderNet_Shader.py:71-129); at depth 256 the projection unit emits 64*32 = 2048
+    features, so every 2-D width doubles (16 280 GMAC/frame, 3.79 GB of weights)."""
+    return ShaderSpec(size=128, new_size=256, w_res2=2048, w5=1024, w6=512, w7=256, w7_1=256, w8=128, w9=64,
+                      w10=32, out_ch=out_ch).check()
+
+
 def shader_variable_shapes(spec):
     """[(tf_name, shape, kind)] for every variable of the graph, in creation order.
     kind: 'w3' hand-rolled conv3d filter (xavier), 'b3' its bias (0.001), 'ws' slim filter (xavier),

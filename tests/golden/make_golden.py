@@ -55,7 +55,26 @@ def full():
                         enc4_absmean=np.float64(np.abs(taps["enc4"]).mean()))
 
 
+def stress():
+    """BASELINE config 5 (128^3 -> 256^3 -> 1024^2), one frame: chair upsampled x2 (nearest), demo pose."""
+    from rendernet_amd.shader import stress_spec
+    spec = stress_spec(1)
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox = read_binvox(os.path.join(ROOT, "binvox", "chair.binvox")).astype(np.float32)
+    vox = vox.repeat(2, 0).repeat(2, 1).repeat(2, 2)[None, ..., None]
+    p = pose(250, 60, 3.3)[None]
+    x = OR.net_input(vox, p, 128, 256, mode="tf")
+    taps = {}
+    out = ON.rendernet_forward(x, w, taps)
+    np.savez_compressed(os.path.join(HERE, "stress_chair_demo_pose.npz"),
+                        output_crop=out[0, 448:576, 448:576, 0], logits_crop=taps["logits"][0, 448:576, 448:576, 0],
+                        net_in_sum=np.float64(x.sum()), enc4_absmean=np.float64(np.abs(taps["enc4"]).mean()))
+
+
 if __name__ == "__main__":
+    if "stress" in sys.argv:
+        stress()
+        sys.exit(0)
     tiny()
     full()
     print("golden vectors written to", HERE)
