@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 100            /* 0.1.0 */
+#define RN_VERSION 110            /* 0.1.1: training step */
 
 /* error codes */
 #define RN_OK              0
@@ -154,6 +154,86 @@ int rn_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, int C, 
 int rn_phong_composite_fwd(const float* normals, const float* light_dir, const float* light_col,
                            float ambient, float k_diffuse, float* out,
                            int B, int H, int W, void* stream);
+
+/* ==========================================================================================
+ * Training step (BASELINE config 4).  Replaces what TensorFlow's autodiff derives from
+ * `tf.train.AdamOptimizer(...).minimize(recon_loss)` (RenderNet_Shader.py:159-167) for the ops of
+ * tools/layer_util.py: per conv flavour a forward that also emits the pre-activation, the input
+ * gradient (dgrad), the filter gradient (wgrad); the backward of the fused epilogue; the loss;
+ * the Adam update.  Same conventions as above (device pointers, stream-ordered, caller-owned).
+ * ========================================================================================== */
+
+/* Forward entry points of the section above with one extra output: `preact` (shape of y, may be
+ * NULL) receives z = conv(x) + bias, the value BEFORE PReLU / residual / sigmoid, which the PReLU
+ * backward needs (tools/layer_util.py:27-45: d/dalpha = sum dy*min(z,0) is lost once z is clipped). */
+int rn_conv3d_fwd_train(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                        const float* residual, float* y, float* preact,
+                        int B, int H, int W, int D, int Cin, int Cout,
+                        const int* ksize, const int* stride, int act, void* stream);
+int rn_conv2d_fwd_train(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                        const float* residual, float* y, float* preact,
+                        int B, int H, int W, int Cin, int Cout,
+                        const int* ksize, const int* stride, int act, void* stream);
+int rn_conv2d_transpose_fwd_train(const float* x, const float* w_packed, const float* bias,
+                                  const float* alpha, const float* residual, float* y, float* preact,
+                                  int B, int H, int W, int Cin, int Cout,
+                                  int ksize, int stride, int act, void* stream);
+int rn_conv3d_transpose_fwd_train(const float* x, const float* w_packed, const float* bias,
+                                  const float* alpha, const float* residual, float* y, float* preact,
+                                  int B, int H, int W, int D, int Cin, int Cout,
+                                  int ksize, int stride, int act, void* stream);
+
+/* Backward of the fused epilogue  y = sigmoid?( prelu?(z) + residual ),  z = conv + bias, rows [M,C]:
+ *   dt = dy * y*(1-y) if act has RN_ACT_SIGMOID (needs y);  the residual's gradient is dt;
+ *   dz = dt * (z > 0 ? 1 : alpha[c]) and dalpha[c] += sum_rows dt*min(z,0) if RN_ACT_PRELU (needs z);
+ *   dbias[c] += sum_rows dz.
+ * dz may alias dy or be NULL; dbias / dalpha are ACCUMULATED (atomics) and may be NULL. */
+int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
+                    float* dz, float* dbias, float* dalpha, size_t M, int C, int act, void* stream);
+
+/* Input gradients (tf.nn.conv*_backprop_input).  H,W(,D) are the FORWARD INPUT sizes of the layer.
+ *   rn_conv{2,3}d_dgrad            dz [B,ceil(H/s)..,Cout] -> dx [B,H,W(,D),Cin].  stride 1: pack the
+ *                                  layer's TF filter with RN_PACK_CONVT_S1 (a conv filter [k..,Cin,Cout]
+ *                                  read as a transposed-conv filter); strided (Cin <= 16): pack it with
+ *                                  RN_PACK_CONV.
+ *   rn_conv{2,3}d_transpose_dgrad  dz [B,H*s,W*s(,D*s),Cout] -> dx [B,H,W(,D),Cin]; pack the layer's TF
+ *                                  filter [k..,Cout,Cin] with RN_PACK_CONV (read as a conv filter
+ *                                  [k.., in=Cout, out=Cin]). */
+int rn_conv3d_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W, int D,
+                    int Cin, int Cout, const int* ksize, const int* stride, void* stream);
+int rn_conv2d_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W,
+                    int Cin, int Cout, const int* ksize, const int* stride, void* stream);
+int rn_conv2d_transpose_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W,
+                              int Cin, int Cout, int ksize, int stride, void* stream);
+int rn_conv3d_transpose_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W, int D,
+                              int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* Filter gradients (tf.nn.conv*_backprop_filter), written in the TF layout of the layer's filter
+ * ([k..,Cin,Cout] for convs, [k..,Cout,Cin] for transposed convs) and ACCUMULATED into dw with fp32
+ * atomics: zero dw (or keep a running gradient in it) before the call.  x is the layer's forward
+ * input, dz the gradient w.r.t. its pre-activation. */
+int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
+                    int Cin, int Cout, const int* ksize, const int* stride, void* stream);
+int rn_conv2d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
+                    int Cin, int Cout, const int* ksize, const int* stride, void* stream);
+int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
+                              int Cin, int Cout, int ksize, int stride, void* stream);
+int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
+                              int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* Reconstruction loss and d(loss)/d(pred)  (RenderNet_Shader.py:159-163).
+ *   mode 0: binary cross-entropy  sum_elems -(t*log(1e-6+p) + (1-t)*log(1e-6+1-p)) / divisor   (divisor = batch)
+ *   mode 1: mean squared error    sum_elems (t-p)^2 / divisor                                  (divisor = #elements)
+ * *loss_sum (double, device) is ACCUMULATED; dpred (may be NULL) gets the gradient.  With the batch
+ * sharded over ranks pass the GLOBAL divisor: per-rank values and gradients then simply add up. */
+int rn_loss_fwd_bwd(const float* pred, const float* target, float* dpred, double* loss_sum,
+                    size_t n, double divisor, int mode, void* stream);
+
+/* tf.train.AdamOptimizer update (RenderNet_Shader.py:166) on a flat buffer of n floats:
+ *   g' = grad_scale*g;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t * m / (sqrt(v) + eps)
+ * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) is computed by the caller (TF's formulation).  16-byte aligned. */
+int rn_adam_step(float* param, const float* grad, float* m, float* v, size_t n,
+                 float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

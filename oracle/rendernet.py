@@ -11,7 +11,8 @@ from . import layers as L
 
 
 def _g(w, name):
-    return torch.from_numpy(np.ascontiguousarray(w[name]))
+    v = w[name]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
 
 
 def res_block_3d(x, w, scope):
@@ -34,13 +35,20 @@ def rendernet_forward(models_in, w, taps=None, n_res1=10, n_res2=10, n_res3=5):
     """RenderNet_Shader.py:32-131.  models_in [B,H,W,D,1] (the resampled, image-aligned voxel
     grid).  Returns the sigmoid output [B,4H,4W,ch]; if `taps` is a dict it is filled with the
     named intermediate tensors (numpy)."""
-    def tap(name, t):
-        if taps is not None:
-            taps[name] = t.numpy().copy()
-        return t
-
     with torch.no_grad():
         x = torch.from_numpy(np.ascontiguousarray(models_in, dtype=np.float32))
+        return rendernet_forward_torch(x, w, taps, n_res1, n_res2, n_res3).numpy()
+
+
+def rendernet_forward_torch(x, w, taps=None, n_res1=10, n_res2=10, n_res3=5):
+    """The graph itself on torch tensors (differentiable when `w` holds tensors that require grad:
+    oracle/train.py derives the reference's gradients from it with torch's CPU autograd)."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach().numpy().copy()
+        return t
+
+    if True:
         e = "encoder/"
         enc1 = L.prelu(L.conv3d(x, _g(w, e + "e_conv1/e_conv1/weights"), _g(w, e + "e_conv1/e_conv1/biases"),
                                 (2, 2, 2)), _g(w, e + "e_conv1/alpha"))                      # :36-39
@@ -83,4 +91,4 @@ def rendernet_forward(models_in, w, taps=None, n_res1=10, n_res2=10, n_res3=5):
         logits = tap("logits", L.conv2d_transpose(net, _g(w, e + "e_conv11/weights"),
                                                   _g(w, e + "e_conv11/biases"), (1, 1)))     # :125-129
         out = tap("output", L.sigmoid(logits))                                               # :127/:130
-        return out.numpy()
+        return out

@@ -34,6 +34,22 @@ SIGNATURES = {
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "rn_prelu_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_int, _c_vp]),
     "rn_phong_composite_fwd": (_c_int, [_c_vp] * 3 + [_c_f, _c_f, _c_vp] + [_c_int] * 3 + [_c_vp]),
+    # training step
+    "rn_conv3d_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_ip, _ip, _c_int, _c_vp]),
+    "rn_conv2d_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 5 + [_ip, _ip, _c_int, _c_vp]),
+    "rn_conv2d_transpose_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 8 + [_c_vp]),
+    "rn_conv3d_transpose_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),
+    "rn_epilogue_bwd": (_c_int, [_c_vp] * 7 + [ctypes.c_size_t, _c_int, _c_int, _c_vp]),
+    "rn_conv3d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
+    "rn_conv3d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
+    "rn_conv3d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
+    "rn_conv3d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
+    "rn_loss_fwd_bwd": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t, ctypes.c_double, _c_int, _c_vp]),
+    "rn_adam_step": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t] + [_c_f] * 5 + [_c_vp]),
 }
 
 _lib = None

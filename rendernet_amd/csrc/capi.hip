@@ -46,13 +46,13 @@ static int dispatch(const RnConvProblem& p, hipStream_t st)
 
 static int conv_fwd_nd(const float* x, const float* w, const float* bias, const float* alpha,
                        const float* residual, float* y, int B, const int* I, int Cin, int Cout,
-                       const int* k, const int* s, int act, hipStream_t st, const char* who)
+                       const int* k, const int* s, int act, hipStream_t st, const char* who, float* preact = nullptr)
 {
     if (!x || !w || !y) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
     if (B < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "%s: PReLU needs alpha", who);
     RnConvProblem p;
-    p.x = x; p.w = w; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y;
+    p.x = x; p.w = w; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y; p.preact = preact;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.Npad = rn_round_up(Cout, 32);
     for (int d = 0; d < 3; ++d) {
         if (I[d] < 1 || k[d] < 1 || s[d] < 1) return rn_set_error(RN_E_INVALID, "%s: bad geometry", who);
@@ -96,13 +96,13 @@ extern "C" int rn_conv2d_fwd(const float* x, const float* w_packed, const float*
 // i.e. 2^nd sub-pixel phases, each a dense 2-tap-per-dim conv written with output stride 2.
 static int convT_nd(const float* x, const float* w, const float* bias, const float* alpha,
                     const float* residual, float* y, int B, const int* I, int nd, int Cin, int Cout,
-                    int ksize, int stride, int act, hipStream_t st, const char* who)
+                    int ksize, int stride, int act, hipStream_t st, const char* who, float* preact = nullptr)
 {
     if (!x || !w || !y) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
     if (B < 1 || Cin < 1 || Cout < 1 || ksize < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "%s: PReLU needs alpha", who);
     RnConvProblem p;
-    p.x = x; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y;
+    p.x = x; p.bias = bias; p.alpha = alpha; p.residual = residual; p.y = y; p.preact = preact;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.Npad = rn_round_up(Cout, 32);
     p.act = act;
     int Ofull[3];
@@ -178,4 +178,161 @@ extern "C" int rn_projection_fwd(const float* x, const float* w_packed, const fl
     const int I[3] = {H, W, 1}, k[3] = {1, 1, 1}, s[3] = {1, 1, 1};
     return conv_fwd_nd(x, w_packed, bias, alpha, nullptr, y, B, I, F, F, k, s,
                        alpha ? RN_ACT_PRELU : RN_ACT_NONE, (hipStream_t)stream, "rn_projection_fwd");
+}
+
+
+// =================================================================================================
+// Training step (RenderNet_Shader.py:159-167): forward entry points that also emit the pre-activation,
+// input gradients (dgrad) and filter gradients (wgrad) of every conv flavour.
+// =================================================================================================
+extern "C" int rn_conv3d_fwd_train(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                                   const float* residual, float* y, float* preact, int B, int H, int W, int D,
+                                   int Cin, int Cout, const int* ksize, const int* stride, int act, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv3d_fwd_train: null ksize/stride");
+    const int I[3] = {H, W, D};
+    return conv_fwd_nd(x, w_packed, bias, alpha, residual, y, B, I, Cin, Cout, ksize, stride, act,
+                       (hipStream_t)stream, "rn_conv3d_fwd_train", preact);
+}
+
+extern "C" int rn_conv2d_fwd_train(const float* x, const float* w_packed, const float* bias, const float* alpha,
+                                   const float* residual, float* y, float* preact, int B, int H, int W,
+                                   int Cin, int Cout, const int* ksize, const int* stride, int act, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv2d_fwd_train: null ksize/stride");
+    const int I[3] = {H, W, 1}, k[3] = {ksize[0], ksize[1], 1}, s[3] = {stride[0], stride[1], 1};
+    return conv_fwd_nd(x, w_packed, bias, alpha, residual, y, B, I, Cin, Cout, k, s, act,
+                       (hipStream_t)stream, "rn_conv2d_fwd_train", preact);
+}
+
+extern "C" int rn_conv2d_transpose_fwd_train(const float* x, const float* w_packed, const float* bias,
+                                             const float* alpha, const float* residual, float* y, float* preact,
+                                             int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                             int act, void* stream)
+{
+    const int I[3] = {H, W, 1};
+    return convT_nd(x, w_packed, bias, alpha, residual, y, B, I, 2, Cin, Cout, ksize, stride, act,
+                    (hipStream_t)stream, "rn_conv2d_transpose_fwd_train", preact);
+}
+
+extern "C" int rn_conv3d_transpose_fwd_train(const float* x, const float* w_packed, const float* bias,
+                                             const float* alpha, const float* residual, float* y, float* preact,
+                                             int B, int H, int W, int D, int Cin, int Cout, int ksize, int stride,
+                                             int act, void* stream)
+{
+    const int I[3] = {H, W, D};
+    return convT_nd(x, w_packed, bias, alpha, residual, y, B, I, 3, Cin, Cout, ksize, stride, act,
+                    (hipStream_t)stream, "rn_conv3d_transpose_fwd_train", preact);
+}
+
+// dgrad of a SAME forward conv: dx[i] = sum_{o,t : o*s - pb + t = i} dz[o] * w[t]  (= TF's
+// conv*_backprop_input).  stride 1: a forward conv over dz with the flipped filter and
+// pad_lo = k-1-pb (w packed with RN_PACK_CONVT_S1 from the SAME TF tensor -- a conv filter
+// [k..,Cin,Cout] read as a transposed-conv filter [k..,Cout_T=Cin,Cin_T=Cout]); strided: direct gather
+// kernel over the forward pack (RN_PACK_CONV), Cin <= 16.
+static int conv_dgrad_nd(const float* dz, const float* w, float* dx, int B, const int* I, int Cin, int Cout,
+                         const int* k, const int* s, hipStream_t st, const char* who)
+{
+    if (!dz || !w || !dx) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    if (B < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
+    int O[3], P[3];
+    bool unit = true;
+    for (int d = 0; d < 3; ++d) {
+        if (I[d] < 1 || k[d] < 1 || s[d] < 1) return rn_set_error(RN_E_INVALID, "%s: bad geometry", who);
+        same_geom(I[d], k[d], s[d], O[d], P[d]);
+        unit = unit && s[d] == 1;
+    }
+    if (!unit) return rn_launch_conv_dgrad_direct(dz, w, dx, B, I, Cin, O, Cout, k, s, P, st);
+    RnConvProblem p;
+    p.x = dz; p.w = w; p.bias = nullptr; p.alpha = nullptr; p.residual = nullptr; p.y = dx; p.preact = nullptr;
+    p.B = B; p.Cin = Cout; p.Cout = Cin; p.Npad = rn_round_up(Cin, 32);
+    for (int d = 0; d < 3; ++d) {
+        p.I[d] = O[d]; p.O[d] = I[d]; p.K[d] = k[d]; p.S[d] = 1; p.P[d] = k[d] - 1 - P[d];
+    }
+    p.os[2] = Cin;
+    p.os[1] = (long long)I[2] * Cin;
+    p.os[0] = (long long)I[1] * p.os[1];
+    p.os_b = (long long)I[0] * p.os[0];
+    p.out_off = 0; p.act = RN_ACT_NONE;
+    return dispatch(p, st);
+}
+
+extern "C" int rn_conv3d_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W, int D,
+                               int Cin, int Cout, const int* ksize, const int* stride, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv3d_dgrad: null ksize/stride");
+    const int I[3] = {H, W, D};
+    return conv_dgrad_nd(dz, w_packed, dx, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_dgrad");
+}
+
+extern "C" int rn_conv2d_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W,
+                               int Cin, int Cout, const int* ksize, const int* stride, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv2d_dgrad: null ksize/stride");
+    const int I[3] = {H, W, 1}, k[3] = {ksize[0], ksize[1], 1}, s[3] = {stride[0], stride[1], 1};
+    return conv_dgrad_nd(dz, w_packed, dx, B, I, Cin, Cout, k, s, (hipStream_t)stream, "rn_conv2d_dgrad");
+}
+
+// dgrad of a transposed conv y = convT(x, w[k..,Cout,Cin], stride s): the SAME forward conv over dz
+// [B, H*s, W*s(, D*s), Cout] with that TF tensor read as a conv filter [k.., in = Cout, out = Cin]
+// (packed with RN_PACK_CONV), stride s.
+extern "C" int rn_conv2d_transpose_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W,
+                                         int Cin, int Cout, int ksize, int stride, void* stream)
+{
+    const int I[3] = {H * stride, W * stride, 1}, k[3] = {ksize, ksize, 1}, s[3] = {stride, stride, 1};
+    return conv_fwd_nd(dz, w_packed, nullptr, nullptr, nullptr, dx, B, I, Cout, Cin, k, s, RN_ACT_NONE,
+                       (hipStream_t)stream, "rn_conv2d_transpose_dgrad");
+}
+
+extern "C" int rn_conv3d_transpose_dgrad(const float* dz, const float* w_packed, float* dx, int B, int H, int W, int D,
+                                         int Cin, int Cout, int ksize, int stride, void* stream)
+{
+    const int I[3] = {H * stride, W * stride, D * stride}, k[3] = {ksize, ksize, ksize}, s[3] = {stride, stride, stride};
+    return conv_fwd_nd(dz, w_packed, nullptr, nullptr, nullptr, dx, B, I, Cout, Cin, k, s, RN_ACT_NONE,
+                       (hipStream_t)stream, "rn_conv3d_transpose_dgrad");
+}
+
+// wgrad: dw (TF layout, ACCUMULATED -- zero it first) of a SAME forward conv ...
+static int conv_wgrad_nd(const float* x, const float* dz, float* dw, int B, const int* I, int Cin, int Cout,
+                         const int* k, const int* s, hipStream_t st, const char* who)
+{
+    if (!x || !dz || !dw) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    int O[3], P[3];
+    for (int d = 0; d < 3; ++d) {
+        if (I[d] < 1 || k[d] < 1 || s[d] < 1) return rn_set_error(RN_E_INVALID, "%s: bad geometry", who);
+        same_geom(I[d], k[d], s[d], O[d], P[d]);
+    }
+    return rn_launch_conv_wgrad(x, dz, dw, B, I, Cin, O, Cout, k, s, P, st);
+}
+
+extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
+                               int Cin, int Cout, const int* ksize, const int* stride, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv3d_wgrad: null ksize/stride");
+    const int I[3] = {H, W, D};
+    return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_wgrad");
+}
+
+extern "C" int rn_conv2d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
+                               int Cin, int Cout, const int* ksize, const int* stride, void* stream)
+{
+    if (!ksize || !stride) return rn_set_error(RN_E_INVALID, "rn_conv2d_wgrad: null ksize/stride");
+    const int I[3] = {H, W, 1}, k[3] = {ksize[0], ksize[1], 1}, s[3] = {stride[0], stride[1], 1};
+    return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, k, s, (hipStream_t)stream, "rn_conv2d_wgrad");
+}
+
+// ... and of a transposed conv (dw in TF layout [k..,Cout,Cin]): the roles swap -- the full-resolution
+// dz [B,H*s,W*s,Cout] is the "input" of the equivalent forward conv and x [B,H,W,Cin] its output grid.
+extern "C" int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
+                                         int Cin, int Cout, int ksize, int stride, void* stream)
+{
+    const int I[3] = {H * stride, W * stride, 1}, k[3] = {ksize, ksize, 1}, s[3] = {stride, stride, 1};
+    return conv_wgrad_nd(dz, x, dw, B, I, Cout, Cin, k, s, (hipStream_t)stream, "rn_conv2d_transpose_wgrad");
+}
+
+extern "C" int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
+                                         int Cin, int Cout, int ksize, int stride, void* stream)
+{
+    const int I[3] = {H * stride, W * stride, D * stride}, k[3] = {ksize, ksize, ksize}, s[3] = {stride, stride, stride};
+    return conv_wgrad_nd(dz, x, dw, B, I, Cout, Cin, k, s, (hipStream_t)stream, "rn_conv3d_transpose_wgrad");
 }

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct DrunArgs {
-    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y;
+    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y; float* z;
     unsigned x_bytes, w_bytes;
     int ncols;            // B*H*W
     int H, W, D, Cout;
@@ -191,6 +191,7 @@ void conv3d_k3_drun_kernel(const DrunArgs a)
                 if (d < a.D) {
                     const long long oo = cbase + d * a.os2 + n;
                     float v = acc[r] + bv;
+                    if (a.z) a.z[oo] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
                     if (a.res) v += a.res[oo];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -364,6 +365,7 @@ void conv3d_k3_drun_dma_kernel(const DrunArgs a)
                 if (d < a.D) {
                     const long long oo = cbase + d * a.os2 + n;
                     float v = (acc[r] + acc1[r]) + bv;
+                    if (a.z) a.z[oo] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
                     if (a.res) v += a.res[oo];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -395,7 +397,7 @@ int rn_launch_conv3d_drun(const RnConvProblem& p, hipStream_t st)
 {
     if (!rn_drun_supported(p)) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_drun: unsupported problem");
     DrunArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
     a.x_bytes = (unsigned)((long long)p.B * p.I[0] * p.I[1] * p.I[2] * p.Cin * 4);
     a.w_bytes = (unsigned)((27 * p.Cin / 4) * 32 * 16);
     const long long ncols = (long long)p.B * p.I[0] * p.I[1];

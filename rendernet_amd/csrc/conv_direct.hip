@@ -9,7 +9,7 @@
 #include "rn_common.h"
 
 struct DirectArgs {
-    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y;
+    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y; float* z;
     long long M;
     int I0, I1, I2, Cin;
     int O0, O1, O2, Cout, Npad;
@@ -80,6 +80,7 @@ void conv_direct_kernel(const DirectArgs a)
     for (int n = 0; n < CO; ++n) {
         if (n < a.Cout) {
             float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
+            if (a.z) a.z[oo + n] = v;
             if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
             if (a.res) v += a.res[oo + n];
             if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -108,7 +109,7 @@ static int launch_direct(const DirectArgs& a, hipStream_t st)
 int rn_launch_conv_direct(const RnConvProblem& p, hipStream_t st)
 {
     DirectArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
     a.M = (long long)p.B * p.O[0] * p.O[1] * p.O[2];
     if (a.M <= 0) return rn_set_error(RN_E_INVALID, "conv_direct: empty problem");
     a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.Cin = p.Cin;

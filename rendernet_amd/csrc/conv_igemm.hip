@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmArgs {
-    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y;
+    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y; float* z;
     int M;
     unsigned x_bytes, w_bytes;
     int I0, I1, I2, Cin;
@@ -231,6 +231,7 @@ void conv_igemm_kernel(const IgemmArgs a)
                 const long long oo = outoff[row];
                 if (oo >= 0 && nok) {
                     float v = acc[i][j][r] + bv;
+                    if (a.z) a.z[oo + n] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
                     if (a.res) v += a.res[oo + n];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -402,6 +403,7 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
                 const long long oo = outoff[row];
                 if (oo >= 0 && nok) {
                     float v = acc[i][j][r] + bv;
+                    if (a.z) a.z[oo + n] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
                     if (a.res) v += a.res[oo + n];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -474,6 +476,7 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
                 q.x = p.x + (size_t)b0 * (per_item / 4);
                 q.y = p.y + (size_t)b0 * p.os_b;
                 if (p.residual) q.residual = p.residual + (size_t)b0 * p.os_b;
+                if (p.preact) q.preact = p.preact + (size_t)b0 * p.os_b;
                 const int rc = rn_launch_conv_igemm(q, st);
                 if (rc != RN_OK) return rc;
             }
@@ -481,7 +484,7 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
         }
     }
     IgemmArgs a;
-    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
     const long long M = (long long)p.B * p.O[0] * p.O[1] * p.O[2];
     if (M <= 0 || M > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: M=%lld", M);
     a.M = (int)M;

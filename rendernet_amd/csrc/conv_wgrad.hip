@@ -1,0 +1,310 @@
+// Filter gradient of every convolution flavour of the path on the gfx950 matrix cores, exact fp32
+// (v_mfma_f32_32x32x2_f32).  This is the wgrad leg of the training step that TensorFlow's autodiff
+// derives for tf.nn.conv3d / conv2d / conv2d_transpose (tools/layer_util.py:171,212,253;
+// RenderNet_Shader.py:165-167 `AdamOptimizer(...).minimize(recon_loss)`).
+//
+// One formulation serves forward convs and transposed convs:
+//     dw[t0,t1,t2][ca][cg] += sum_{b,o0,o1,o2} A[b, o0*S0-P0+t0, o1*S1-P1+t1, o2*S2-P2+t2, ca] * G[b,o0,o1,o2,cg]
+//   forward conv  y = conv(x, w[k..,Cin,Cout]):            A = x,  G = dz           (dw in TF layout [k..,Cin,Cout])
+//   transposed    y = convT(x, w[k..,Cout,Cin]), stride s: A = dz, G = x            (dw in TF layout [k..,Cout,Cin])
+// out-of-range A coordinates contribute zero (TF SAME).
+//
+// GEMM view per tap: out[Ca x Cg] = A_tap^T [Ca x M] * G [M x Cg], M = B*O0*O1*O2 positions.  Both
+// operands are "reduction-major" in memory (a position is a contiguous channel run), so tiles go
+// global -> LDS with buffer_load_dwordx4 ... lds exactly as they lie ([BK positions][BM|BN channels],
+// no transpose, no staging VGPRs) and MFMA fragments are conflict-free ds_read_b32 rows (lanes 0-31 =
+// 32 consecutive channels of position k, lanes 32-63 = position k+1).  SAME padding, the channel tail
+// and the end of the reduction range come from the buffer bounds check (offset >= 2^31 -> zeros).
+// The reduction is split over `nsplit` workgroups per (tap, tile) -- and over the waves of a workgroup
+// for narrow tiles -- and partial tiles are accumulated into dw with hardware fp32 atomics, so dw must
+// be zero-initialised (or hold the running gradient) on entry.  blockIdx%8 = split%8 keeps the
+// workgroups that stream the same positions on one XCD (one L2).
+#include "rn_common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float* a; const float* g; float* dw;
+    unsigned a_bytes, g_bytes;
+    int I0, I1, I2, Ca;
+    int O0, O1, O2, Cg;
+    int K0, K1, K2, S0, S1, S2, P0, P1, P2;
+    int M;                       // positions in the reduction
+    int mtiles, ntiles, nsplit, kchunk;
+};
+
+template <int BM, int BN, int BK, int WM, int WN, int WK>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_kernel(const WgradArgs a)
+{
+    static_assert(WM * WN * WK == 4, "4 waves");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int CA = BM / 4, CG = BN / 4;          // 16-B chunks per tile row
+    constexpr int RA = 64 / CA, RG = 64 / CG;        // rows per wave DMA instruction
+    constexpr int IAW = BK / RA / 4, IGW = BK / RG / 4;   // DMA instructions per wave per stage
+    static_assert(IAW >= 1 && IGW >= 1 && TM >= 1 && TN >= 1, "tile shape");
+    constexpr int ASZ = BK * BM, GSZ = BK * BN;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);      // [2][BK][BM]
+    float* Gs = As + 2 * ASZ;                        // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+
+    int id = blockIdx.x;
+    const int split = id % a.nsplit; id /= a.nsplit;
+    const int tn = id % a.ntiles; id /= a.ntiles;
+    const int tm = id % a.mtiles; const int tap = id / a.mtiles;
+    const int t2 = tap % a.K2, t1 = (tap / a.K2) % a.K1, t0 = tap / (a.K2 * a.K1);
+    const int ca0 = tm * BM, cg0 = tn * BN;
+    const int kbeg = split * a.kchunk;
+    const int kend = min(a.M, kbeg + a.kchunk);
+    if (kbeg >= kend) return;
+    const int nstage = (kend - kbeg + BK - 1) / BK;
+
+    // mixed-radix digits of BK over (b, o0, o1, o2): the per-stage position advance
+    int d2 = BK % a.O2, rr = BK / a.O2;
+    int d1 = rr % a.O1; rr /= a.O1;
+    int d0 = rr % a.O0; const int db = rr / a.O0;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.g_bytes, 0x00020000);
+
+    // A rows owned by this lane: instruction q of this wave covers rows (wave*IAW+q)*RA + lane/CA
+    int pb[IAW], p0[IAW], p1[IAW], p2[IAW], ppos[IAW];
+    const int achunk = lane % CA;
+    const bool a_ch_ok = ca0 + achunk * 4 < a.Ca;
+#pragma unroll
+    for (int q = 0; q < IAW; ++q) {
+        int pos = kbeg + (wave * IAW + q) * RA + lane / CA;
+        ppos[q] = pos;
+        p2[q] = pos % a.O2; pos /= a.O2;
+        p1[q] = pos % a.O1; pos /= a.O1;
+        p0[q] = pos % a.O0; pb[q] = pos / a.O0;
+    }
+    int gpos[IGW];
+    const int gchunk = lane % CG;
+    const bool g_ch_ok = cg0 + gchunk * 4 < a.Cg;
+#pragma unroll
+    for (int q = 0; q < IGW; ++q) gpos[q] = kbeg + (wave * IGW + q) * RG + lane / CG;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+#define RN_WG_DMA(stage)                                                                                  \
+    {                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < IAW; ++q) {                                                 \
+            const int i0 = p0[q] * a.S0 - a.P0 + t0, i1 = p1[q] * a.S1 - a.P1 + t1,                        \
+                      i2 = p2[q] * a.S2 - a.P2 + t2;                                                      \
+            const bool ok = a_ch_ok && ppos[q] < kend && (unsigned)i0 < (unsigned)a.I0 &&                 \
+                            (unsigned)i1 < (unsigned)a.I1 && (unsigned)i2 < (unsigned)a.I2;               \
+            const unsigned e = (unsigned)(((pb[q] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * (unsigned)a.Ca \
+                               + (unsigned)(ca0 + achunk * 4);                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc,                                               \
+                (lds_void*)(As + (stage) * ASZ + (wave * IAW + q) * RA * BM), 16, ok ? e * 4u : OOB, 0, 0, 0); \
+            /* advance this row by BK positions */                                                        \
+            ppos[q] += BK;                                                                                \
+            int c;                                                                                        \
+            p2[q] += d2; c = p2[q] >= a.O2; p2[q] -= c ? a.O2 : 0;                                        \
+            p1[q] += d1 + c; c = p1[q] >= a.O1; p1[q] -= c ? a.O1 : 0;                                    \
+            p0[q] += d0 + c; c = p0[q] >= a.O0; p0[q] -= c ? a.O0 : 0;                                    \
+            pb[q] += db + c;                                                                              \
+        }                                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < IGW; ++q) {                                                 \
+            const bool ok = g_ch_ok && gpos[q] < kend;                                                    \
+            const unsigned e = (unsigned)gpos[q] * (unsigned)a.Cg + (unsigned)(cg0 + gchunk * 4);         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc,                                               \
+                (lds_void*)(Gs + (stage) * GSZ + (wave * IGW + q) * RG * BN), 16, ok ? e * 4u : OOB, 0, 0, 0); \
+            gpos[q] += BK;                                                                                \
+        }                                                                                                 \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    RN_WG_DMA(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) RN_WG_DMA(cur ^ 1);
+        const float* Ab = As + cur * ASZ + lh * BM + wm * WTM + li;
+        const float* Gb = Gs + cur * GSZ + lh * BN + wn * WTN + li;
+#pragma unroll 8
+        for (int kk = 0; kk < BK / 2 / WK; ++kk) {
+            const int ks = kk * WK + wk;
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Gb[ks * 2 * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef RN_WG_DMA
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* dwt = a.dw + (size_t)tap * a.Ca * a.Cg;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cg = cg0 + wn * WTN + j * 32 + li;
+        if (cg >= a.Cg) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ca = ca0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ca < a.Ca) unsafeAtomicAdd(dwt + (size_t)ca * a.Cg + cg, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Narrow-input variant (Ca*taps <= 1024 threads, Cg <= 16): e_conv1 (Cin = 1|5, 125 taps, 8 outputs),
+// the wgrad of e_conv11 (A = dz with 1|3 channels).  One thread owns one (tap, ca) pair and CGT
+// accumulators; the workgroup walks a chunk of positions, every thread gathering its own A sample
+// while the G row is a wave-uniform (broadcast) load.
+// ------------------------------------------------------------------------------------------------
+template <int CGT>
+__global__ __launch_bounds__(1024)
+void conv_wgrad_small_kernel(const WgradArgs a)
+{
+    const int taps = a.K0 * a.K1 * a.K2;
+    const int t = threadIdx.x;
+    const bool live = t < taps * a.Ca;
+    const int ca = live ? t % a.Ca : 0, tap = live ? t / a.Ca : 0;
+    const int t2 = tap % a.K2, t1 = (tap / a.K2) % a.K1, t0 = tap / (a.K2 * a.K1);
+    const int kbeg = blockIdx.x * a.kchunk;
+    const int kend = min(a.M, kbeg + a.kchunk);
+    float acc[CGT];
+#pragma unroll
+    for (int n = 0; n < CGT; ++n) acc[n] = 0.f;
+    int pos = kbeg;
+    int o2 = pos % a.O2; pos /= a.O2;
+    int o1 = pos % a.O1; pos /= a.O1;
+    int o0 = pos % a.O0; int b = pos / a.O0;
+    for (int p = kbeg; p < kend; ++p) {
+        const int i0 = o0 * a.S0 - a.P0 + t0, i1 = o1 * a.S1 - a.P1 + t1, i2 = o2 * a.S2 - a.P2 + t2;
+        float av = 0.f;
+        if (live && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 && (unsigned)i2 < (unsigned)a.I2)
+            av = a.a[((((size_t)b * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Ca + ca];
+        const float* gp = a.g + (size_t)p * a.Cg;
+#pragma unroll
+        for (int n = 0; n < CGT; ++n)
+            if (n < a.Cg) acc[n] = fmaf(av, gp[n], acc[n]);
+        if (++o2 == a.O2) { o2 = 0; if (++o1 == a.O1) { o1 = 0; if (++o0 == a.O0) { o0 = 0; ++b; } } }
+    }
+    if (live) {
+        float* d = a.dw + ((size_t)tap * a.Ca + ca) * a.Cg;
+#pragma unroll
+        for (int n = 0; n < CGT; ++n)
+            if (n < a.Cg) unsafeAtomicAdd(d + n, acc[n]);
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int WK>
+static int launch_wgrad(WgradArgs& a, hipStream_t st)
+{
+    const int taps = a.K0 * a.K1 * a.K2;
+    a.mtiles = (a.Ca + BM - 1) / BM;
+    a.ntiles = (a.Cg + BN - 1) / BN;
+    const long long tiles = (long long)taps * a.mtiles * a.ntiles;
+    // enough workgroups to fill 256 CUs x 2 several times over, in multiples of 8 (one split residue
+    // class per XCD), but never fewer than 4 stages of reduction per workgroup
+    long long ns = (3072 + tiles - 1) / tiles;
+    ns = (ns + 7) / 8 * 8;
+    const long long max_ns = (a.M + 4LL * BK - 1) / (4LL * BK);
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    long long kc = (a.M + ns - 1) / ns;
+    kc = (kc + BK - 1) / BK * BK;
+    ns = (a.M + kc - 1) / kc;
+    a.nsplit = (int)ns; a.kchunk = (int)kc;
+    const long long nb = tiles * ns;
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: bad grid %lld", nb);
+    const size_t lds = (size_t)2 * BK * (BM + BN) * 4;
+    auto kern = conv_wgrad_kernel<BM, BN, BK, WM, WN, WK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch("conv_wgrad");
+}
+
+// A [B,I0,I1,I2,Ca], G [B,O0,O1,O2,Cg] -> dw [K0,K1,K2,Ca,Cg] (accumulated)
+int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const int* I, int Ca,
+                         const int* O, int Cg, const int* K, const int* S, const int* P, hipStream_t st)
+{
+    if (!A || !G || !dw) return rn_set_error(RN_E_INVALID, "conv_wgrad: null pointer");
+    if (B < 1 || Ca < 1 || Cg < 1) return rn_set_error(RN_E_INVALID, "conv_wgrad: bad sizes");
+    const long long a_item = (long long)I[0] * I[1] * I[2] * Ca * 4;
+    const long long g_item = (long long)O[0] * O[1] * O[2] * Cg * 4;
+    if (a_item >= 0x80000000LL || g_item >= 0x80000000LL)
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wgrad: one batch item exceeds the 2 GiB buffer window");
+    if (a_item * B >= 0x80000000LL || g_item * B >= 0x80000000LL) {
+        // operands are addressed with 32-bit byte offsets (upper half = hardware zero-fill): the
+        // gradient is additive over the batch, so process batch chunks that fit the window
+        const long long big = a_item > g_item ? a_item : g_item;
+        const int chunk = (int)(0x7fffffffLL / big);
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+            const int rc = rn_launch_conv_wgrad(A + (size_t)b0 * (a_item / 4), G + (size_t)b0 * (g_item / 4), dw,
+                                                nb, I, Ca, O, Cg, K, S, P, st);
+            if (rc != RN_OK) return rc;
+        }
+        return RN_OK;
+    }
+    WgradArgs a;
+    a.a = A; a.g = G; a.dw = dw;
+    a.a_bytes = (unsigned)(a_item * B); a.g_bytes = (unsigned)(g_item * B);
+    a.I0 = I[0]; a.I1 = I[1]; a.I2 = I[2]; a.Ca = Ca;
+    a.O0 = O[0]; a.O1 = O[1]; a.O2 = O[2]; a.Cg = Cg;
+    a.K0 = K[0]; a.K1 = K[1]; a.K2 = K[2];
+    a.S0 = S[0]; a.S1 = S[1]; a.S2 = S[2];
+    a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2];
+    const long long M = (long long)B * O[0] * O[1] * O[2];
+    if (M <= 0 || M > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: M=%lld", M);
+    a.M = (int)M;
+    const int taps = K[0] * K[1] * K[2];
+    if (Ca % 4 != 0 || Cg % 4 != 0 || Ca < 8) {
+        // narrow path: one thread per (tap, ca)
+        if ((long long)taps * Ca > 1024 || Cg > 16)
+            return rn_set_error(RN_E_UNSUPPORTED, "conv_wgrad: Ca=%d Cg=%d taps=%d has no kernel", Ca, Cg, taps);
+        long long nblk = 4096;
+        long long kc = (M + nblk - 1) / nblk;
+        if (kc < 64) kc = 64;
+        nblk = (M + kc - 1) / kc;
+        a.kchunk = (int)kc; a.nsplit = (int)nblk; a.mtiles = a.ntiles = 1;
+        const int nt = (taps * Ca + 63) / 64 * 64;
+        if (Cg <= 8) hipLaunchKernelGGL(conv_wgrad_small_kernel<8>, dim3((unsigned)nblk), dim3(nt), 0, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_small_kernel<16>, dim3((unsigned)nblk), dim3(nt), 0, st, a);
+        return rn_check_launch("conv_wgrad_small");
+    }
+    const bool wide_m = Ca > 32, wide_n = Cg > 32;
+    if (wide_m && wide_n) return launch_wgrad<128, 128, 32, 2, 2, 1>(a, st);
+    if (wide_m) return launch_wgrad<128, 32, 64, 2, 1, 2>(a, st);
+    if (wide_n) return launch_wgrad<32, 128, 64, 1, 2, 2>(a, st);
+    return launch_wgrad<32, 32, 128, 1, 1, 4>(a, st);
+}

@@ -19,6 +19,7 @@ struct RnConvProblem {
     const float* alpha;      // [Cout] or null (PReLU)
     const float* residual;   // same addressing as y, or null
     float* y;
+    float* preact;           // optional second output z = conv + bias (before PReLU/residual/sigmoid), or null
     int B, I[3], Cin;        // input  [B, I0, I1, I2, Cin]
     int O[3], Cout, Npad;    // output grid visited by this launch, channels, padded channels
     int K[3], S[3], P[3];    // taps, stride, pad_lo
@@ -35,5 +36,10 @@ int rn_launch_conv_direct(const RnConvProblem& p, hipStream_t st);    // conv_di
 bool rn_igemm_supported(const RnConvProblem& p);
 int rn_launch_conv3d_drun(const RnConvProblem& p, hipStream_t st);     // conv3d_drun.hip (MFMA, 3^3 s1, N=32)
 bool rn_drun_supported(const RnConvProblem& p);
+
+int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const int* I, int Ca,
+                         const int* O, int Cg, const int* K, const int* S, const int* P, hipStream_t st);   // conv_wgrad.hip
+int rn_launch_conv_dgrad_direct(const float* dz, const float* w_fwd_packed, float* dx, int B, const int* I, int Cin,
+                                const int* O, int Cout, const int* K, const int* S, const int* P, hipStream_t st); // train_kernels.hip
 
 static inline int rn_round_up(int a, int b) { return (a + b - 1) / b * b; }

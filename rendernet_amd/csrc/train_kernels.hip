@@ -1,0 +1,326 @@
+// Memory-bound kernels of the training step (RenderNet_Shader.py:159-167): backward of the fused conv
+// epilogue (bias / PReLU / sigmoid), the reconstruction loss and its gradient, TF's Adam update, and
+// the input gradient of the channel-starved strided stem conv (e_conv2) that has no MFMA shape.
+#include "rn_common.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------
+// Backward of  y = sigmoid?( prelu?(z) + residual ),  z = conv + bias   (tools/layer_util.py:27-45,
+// :133-144; the residual's gradient is dy itself -- after the sigmoid factor -- and needs no kernel):
+//     dt = dy * y*(1-y)            if sigmoid   (needs y)
+//     dz = dt * (z > 0 ? 1 : alpha[c]),  dalpha[c] += sum dt * min(z, 0)      if PReLU  (needs z)
+//     dbias[c] += sum dz
+// Rows are [M, C] channels-last.  dz may alias dy.  dbias/dalpha are accumulated with atomics.
+// ---------------------------------------------------------------------------------------------
+struct EpiBwdArgs {
+    const float* dy; const float* z; const float* y; const float* alpha;
+    float* dz; float* dbias; float* dalpha;
+    long long M; int C; int act; int rows_per_block;
+};
+
+// fast path: C % 4 == 0 and (256 % (C/4) == 0 or (C/4) % 256 == 0): a thread owns one float4 channel
+// group for its whole life, so its partial sums stay in registers
+__global__ __launch_bounds__(256)
+void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
+{
+    __shared__ float red[2][256 * 4];
+    const int G = a.C >> 2;                         // float4 groups per row
+    const int gper = G < 256 ? G : 256;             // groups handled by one block column
+    const int g = blockIdx.y * 256 + (threadIdx.x % gper);
+    const int rsub = threadIdx.x / gper, rstep = 256 / gper;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_block;
+    const long long r1 = r0 + a.rows_per_block < a.M ? r0 + a.rows_per_block : a.M;
+    float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.act & RN_ACT_PRELU) al = reinterpret_cast<const float4*>(a.alpha)[g];
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, sa[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + rsub; r < r1; r += rstep) {
+        const size_t e = (size_t)r * G + g;
+        float4 d = reinterpret_cast<const float4*>(a.dy)[e];
+        float dv[4] = {d.x, d.y, d.z, d.w};
+        if (a.act & RN_ACT_SIGMOID) {
+            const float4 yv = reinterpret_cast<const float4*>(a.y)[e];
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dv[q] *= yy[q] * (1.f - yy[q]);
+        }
+        if (a.act & RN_ACT_PRELU) {
+            const float4 zv = reinterpret_cast<const float4*>(a.z)[e];
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            const float aa[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sa[q] += dv[q] * fminf(zz[q], 0.f);
+                dv[q] = zz[q] > 0.f ? dv[q] : dv[q] * aa[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sb[q] += dv[q];
+        if (a.dz) reinterpret_cast<float4*>(a.dz)[e] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+    // reduce the rstep row-lanes of each channel group through LDS, then one atomic per channel
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[0][threadIdx.x * 4 + q] = sb[q]; red[1][threadIdx.x * 4 + q] = sa[q]; }
+    __syncthreads();
+    if (threadIdx.x < gper) {
+        float tb[4] = {0.f, 0.f, 0.f, 0.f}, ta[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < rstep; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tb[q] += red[0][(s * gper + threadIdx.x) * 4 + q];
+                ta[q] += red[1][(s * gper + threadIdx.x) * 4 + q];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (a.dbias) unsafeAtomicAdd(a.dbias + g * 4 + q, tb[q]);
+            if ((a.act & RN_ACT_PRELU) && a.dalpha) unsafeAtomicAdd(a.dalpha + g * 4 + q, ta[q]);
+        }
+    }
+}
+
+// generic path (any C <= 1024, e.g. the 1|3-channel image head): LDS accumulators
+__global__ __launch_bounds__(256)
+void epilogue_bwd_gen_kernel(const EpiBwdArgs a)
+{
+    __shared__ float sb[1024], sa[1024];
+    for (int c = threadIdx.x; c < a.C; c += 256) { sb[c] = 0.f; sa[c] = 0.f; }
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * a.rows_per_block * a.C;
+    long long e1 = e0 + (long long)a.rows_per_block * a.C;
+    if (e1 > a.M * a.C) e1 = a.M * a.C;
+    // C == 1: plain block reduction instead of same-address LDS atomics
+    float loc_b = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int c = (int)(e % a.C);
+        float d = a.dy[e];
+        if (a.act & RN_ACT_SIGMOID) { const float yv = a.y[e]; d *= yv * (1.f - yv); }
+        if (a.act & RN_ACT_PRELU) {
+            const float zv = a.z[e];
+            atomicAdd(&sa[c], d * fminf(zv, 0.f));
+            d = zv > 0.f ? d : d * a.alpha[c];
+        }
+        if (a.C == 1) loc_b += d; else atomicAdd(&sb[c], d);
+        if (a.dz) a.dz[e] = d;
+    }
+    if (a.C == 1) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) loc_b += __shfl_xor(loc_b, s);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sb[0], loc_b);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        if (a.dbias) unsafeAtomicAdd(a.dbias + c, sb[c]);
+        if ((a.act & RN_ACT_PRELU) && a.dalpha) unsafeAtomicAdd(a.dalpha + c, sa[c]);
+    }
+}
+
+extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
+                               float* dz, float* dbias, float* dalpha, size_t M, int C, int act, void* stream)
+{
+    if (!dy || M < 1 || C < 1) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: bad arguments");
+    if ((act & RN_ACT_PRELU) && (!z || !alpha)) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: PReLU needs z and alpha");
+    if ((act & RN_ACT_SIGMOID) && !y) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: sigmoid needs y");
+    EpiBwdArgs a{dy, z, y, alpha, dz, dbias, dalpha, (long long)M, C, act, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const int G = C / 4;
+    if (C % 4 == 0 && ((G <= 256 && 256 % G == 0) || G % 256 == 0)) {
+        const int gy = G <= 256 ? 1 : G / 256;
+        const int rstep = G < 256 ? 256 / G : 1;
+        long long rpb = ((long long)M + 2047) / 2048;                 // ~2048 row blocks
+        rpb = (rpb + rstep - 1) / rstep * rstep;
+        if (rpb < 4 * rstep) rpb = 4 * rstep;
+        a.rows_per_block = (int)rpb;
+        const long long nb = ((long long)M + rpb - 1) / rpb;
+        hipLaunchKernelGGL(epilogue_bwd_vec_kernel, dim3((unsigned)nb, gy), dim3(256), 0, st, a);
+    } else {
+        if (C > 1024) return rn_set_error(RN_E_UNSUPPORTED, "rn_epilogue_bwd: C=%d", C);
+        long long rpb = ((long long)M + 4095) / 4096;
+        if (rpb < 256) rpb = 256;
+        a.rows_per_block = (int)rpb;
+        const long long nb = ((long long)M + rpb - 1) / rpb;
+        hipLaunchKernelGGL(epilogue_bwd_gen_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+    }
+    return rn_check_launch("rn_epilogue_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reconstruction loss and its gradient w.r.t. the prediction (RenderNet_Shader.py:159-163).
+//   mode 0 (greyscale): loss = mean_b( -sum_{hwc} t*log(1e-6+p) + (1-t)*log(1e-6+1-p) )
+//   mode 1 (RGB):       loss = mean over all elements (t-p)^2   (tf.losses.mean_squared_error)
+// loss_sum (double, device) is accumulated: the caller zeroes it and reads loss = *loss_sum.
+// `divisor` is the denominator of the mean: the batch size (mode 0) or the element count (mode 1) --
+// the GLOBAL one when ranks each hold a shard, so that the sum of the per-rank gradients (and of the
+// per-rank loss_sum values) is the gradient (value) of the global mean.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void loss_kernel(const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ dp,
+                 double* __restrict__ loss_sum, size_t n, int mode, float inv_div)
+{
+    double loc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float pv = p[i], tv = t[i];
+        if (mode == 0) {
+            const float a0 = 1e-6f + pv, a1 = 1e-6f + 1.f - pv;
+            loc += (double)(-(tv * logf(a0) + (1.f - tv) * logf(a1)));
+            if (dp) dp[i] = -(tv / a0 - (1.f - tv) / a1) * inv_div;
+        } else {
+            const float d = pv - tv;
+            loc += (double)(d * d);
+            if (dp) dp[i] = 2.f * d * inv_div;
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) loc += __shfl_xor(loc, s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = loc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (part[0] + part[1] + part[2] + part[3]) * (double)inv_div);
+}
+
+extern "C" int rn_loss_fwd_bwd(const float* pred, const float* target, float* dpred, double* loss_sum,
+                               size_t n, double divisor, int mode, void* stream)
+{
+    if (!pred || !target || !loss_sum || n < 1 || !(divisor > 0.0) || (mode != 0 && mode != 1))
+        return rn_set_error(RN_E_INVALID, "rn_loss_fwd_bwd: bad arguments");
+    const float inv_div = (float)(1.0 / divisor);
+    size_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, target, dpred,
+                       loss_sum, n, mode, inv_div);
+    return rn_check_launch("rn_loss_fwd_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer (RenderNet_Shader.py:166) over one flat parameter buffer:
+//   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= lr_t * m / (sqrt(v) + eps)
+// with lr_t = lr * sqrt(1-b2^t)/(1-b1^t) computed by the caller (TF's formulation: eps is NOT scaled).
+// grad_scale multiplies g first (1 for summed shard gradients of a global-mean loss).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 size_t n4, size_t n, float lr_t, float b1, float b2, float eps, float gs)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; const float* gg = &gv.x; float* mm = &mv.x; float* vq = &vv.x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gq = gg[q] * gs;
+            mm[q] = b1 * mm[q] + (1.f - b1) * gq;
+            vq[q] = b2 * vq[q] + (1.f - b2) * gq * gq;
+            pp[q] -= lr_t * mm[q] / (sqrtf(vq[q]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        if (i < n) {
+            const float gq = g[i] * gs;
+            const float mq = b1 * m[i] + (1.f - b1) * gq;
+            const float vq = b2 * v[i] + (1.f - b2) * gq * gq;
+            m[i] = mq; v[i] = vq;
+            p[i] -= lr_t * mq / (sqrtf(vq) + eps);
+        }
+    }
+}
+
+extern "C" int rn_adam_step(float* param, const float* grad, float* m, float* v, size_t n,
+                            float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream)
+{
+    if (!param || !grad || !m || !v || n < 1) return rn_set_error(RN_E_INVALID, "rn_adam_step: bad arguments");
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15)
+        return rn_set_error(RN_E_INVALID, "rn_adam_step: buffers must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
+                       n4, n, lr_t, beta1, beta2, eps, grad_scale);
+    return rn_check_launch("rn_adam_step");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input gradient of a forward conv by direct gather, for the strided / channel-starved stem
+// (e_conv2: 3^3, stride (1,1,2), 8 -> 16; RenderNet_Shader.py:40-43):
+//     dx[b,i,c] = sum_{t, n : (i + P - t) % S == 0, o = (i+P-t)/S in range} dz[b,o,n] * w[t][c][n]
+// One thread owns one input position and all (<= CI) input channels.  The filter comes in the
+// forward-packed layout ([K/4][Npad][4], k = tap*Cin + c) and is staged in LDS as [tap][n][CI].
+// ---------------------------------------------------------------------------------------------
+struct DgradDirectArgs {
+    const float* dz; const float* w; float* dx;
+    long long Mi;
+    int I0, I1, I2, Cin, O0, O1, O2, Cout, Npad;
+    int K0, K1, K2, S0, S1, S2, P0, P1, P2;
+};
+
+template <int CI>
+__global__ __launch_bounds__(256)
+void conv_dgrad_direct_kernel(const DgradDirectArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);          // [taps][Cout][CI]
+    const int taps = a.K0 * a.K1 * a.K2;
+    for (int i = threadIdx.x; i < taps * a.Cout * CI; i += blockDim.x) {
+        const int c = i % CI, n = (i / CI) % a.Cout, tap = i / (CI * a.Cout);
+        const int k = tap * a.Cin + c;
+        wl[i] = (c < a.Cin) ? a.w[((size_t)(k >> 2) * a.Npad + n) * 4 + (k & 3)] : 0.f;
+    }
+    __syncthreads();
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.Mi) return;
+    long long t = m;
+    const int i2 = (int)(t % a.I2); t /= a.I2;
+    const int i1 = (int)(t % a.I1); t /= a.I1;
+    const int i0 = (int)(t % a.I0); const int b = (int)(t / a.I0);
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+    for (int t0 = 0; t0 < a.K0; ++t0) {
+        const int u0 = i0 + a.P0 - t0;
+        if (u0 < 0 || u0 % a.S0 != 0 || u0 / a.S0 >= a.O0) continue;
+        for (int t1 = 0; t1 < a.K1; ++t1) {
+            const int u1 = i1 + a.P1 - t1;
+            if (u1 < 0 || u1 % a.S1 != 0 || u1 / a.S1 >= a.O1) continue;
+            for (int t2 = 0; t2 < a.K2; ++t2) {
+                const int u2 = i2 + a.P2 - t2;
+                if (u2 < 0 || u2 % a.S2 != 0 || u2 / a.S2 >= a.O2) continue;
+                const float* gp = a.dz + ((((long long)b * a.O0 + u0 / a.S0) * a.O1 + u1 / a.S1) * a.O2 + u2 / a.S2) * a.Cout;
+                const float* wp = wl + (size_t)((t0 * a.K1 + t1) * a.K2 + t2) * a.Cout * CI;
+                for (int n = 0; n < a.Cout; ++n) {
+                    const float gv = gp[n];
+#pragma unroll
+                    for (int c = 0; c < CI; ++c) acc[c] = fmaf(gv, wp[n * CI + c], acc[c]);
+                }
+            }
+        }
+    }
+    float* op = a.dx + m * a.Cin;
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+        if (c < a.Cin) op[c] = acc[c];
+}
+
+int rn_launch_conv_dgrad_direct(const float* dz, const float* w_fwd_packed, float* dx, int B, const int* I, int Cin,
+                                const int* O, int Cout, const int* K, const int* S, const int* P, hipStream_t st)
+{
+    DgradDirectArgs a;
+    a.dz = dz; a.w = w_fwd_packed; a.dx = dx;
+    a.Mi = (long long)B * I[0] * I[1] * I[2];
+    a.I0 = I[0]; a.I1 = I[1]; a.I2 = I[2]; a.Cin = Cin;
+    a.O0 = O[0]; a.O1 = O[1]; a.O2 = O[2]; a.Cout = Cout; a.Npad = rn_round_up(Cout, 32);
+    a.K0 = K[0]; a.K1 = K[1]; a.K2 = K[2]; a.S0 = S[0]; a.S1 = S[1]; a.S2 = S[2];
+    a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2];
+    if (Cin > 16) return rn_set_error(RN_E_UNSUPPORTED, "conv_dgrad_direct: Cin=%d > 16", Cin);
+    const int CI = Cin <= 4 ? 4 : (Cin <= 8 ? 8 : 16);
+    const size_t lds = (size_t)K[0] * K[1] * K[2] * Cout * CI * 4;
+    if (lds > 64 * 1024) return rn_set_error(RN_E_UNSUPPORTED, "conv_dgrad_direct: filter %zu B exceeds LDS budget", lds);
+    const long long nb = (a.Mi + 255) / 256;
+    if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_dgrad_direct: grid too large");
+    if (CI == 4) hipLaunchKernelGGL(conv_dgrad_direct_kernel<4>, dim3((unsigned)nb), dim3(256), lds, st, a);
+    else if (CI == 8) hipLaunchKernelGGL(conv_dgrad_direct_kernel<8>, dim3((unsigned)nb), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(conv_dgrad_direct_kernel<16>, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch("conv_dgrad_direct");
+}

@@ -2,9 +2,14 @@
 
 Every function takes/returns contiguous float32 torch tensors on the HIP device, channels-last
 as TF holds them, launches on torch's current stream and allocates its output from torch's
-caching allocator.  These are `torch.autograd.Function`s (forward implemented in HIP; the
-backward of the training step -- SURVEY.md K13 -- is not built yet and raises).
+caching allocator.  The conv family are `torch.autograd.Function`s whose forward AND backward are
+HIP kernels behind the C ABI (dgrad / wgrad / epilogue backward); torch's autograd engine only
+orders the calls.  Parameter gradients do not travel through autograd: inside a `training(...)`
+context each backward accumulates them straight into the gradient views the context maps the
+parameter tensors to (one flat buffer, see rendernet_amd/train.py) and reports completion so that
+gradient buckets can be all-reduced while the rest of the backward is still running.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -35,8 +40,27 @@ class PackedWeight:
         if n == 0:
             raise L.RenderNetHipError("rn_packed_weight_floats: %s" % lib.rn_last_error().decode())
         self.data = torch.empty(n, dtype=torch.float32, device=w_tf.device)
-        L.check(lib.rn_pack_weights(kind, ndim, L.ivec(self.kdims), self.cin, self.cout,
-                                    L.ptr(w_tf), L.ptr(self.data), L.stream_ptr()), "rn_pack_weights")
+        self.w_tf = w_tf                  # the TF-layout master copy (what the optimiser updates)
+        self._dgrad = None
+        self.repack()
+
+    def repack(self):
+        """Re-derive the packed copies from the TF-layout master (after an optimiser step)."""
+        L.check(L.lib().rn_pack_weights(self.kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
+                                        L.ptr(self.w_tf), L.ptr(self.data), L.stream_ptr()), "rn_pack_weights")
+        if self._dgrad is not None:
+            self._dgrad.repack()
+
+    def dgrad_pack(self, unit_stride):
+        """The packing the layer's input-gradient kernel reads (include/rendernet_hip.h, dgrad section):
+        conv, stride 1 -> the same TF tensor packed as a stride-1 transposed-conv filter; strided conv ->
+        the forward pack itself; transposed conv -> the same TF tensor packed as a conv filter."""
+        if self.kind == L.RN_PACK_CONV and not unit_stride:
+            return self
+        if self._dgrad is None:
+            kind = L.RN_PACK_CONVT_S1 if self.kind == L.RN_PACK_CONV else L.RN_PACK_CONV
+            self._dgrad = PackedWeight(self.w_tf, kind, self.ndim)
+        return self._dgrad
 
 
 def pack_conv(w_tf):
@@ -100,47 +124,148 @@ def pose_to_affine(pose, size=64, new_size=128):
 LAUNCH_HOOK = None
 
 
-class _Conv(_ForwardOnly):
+# ---------------------------------------------------------------------------------------------
+# training context
+# ---------------------------------------------------------------------------------------------
+class TrainContext:
+    """Maps parameter tensors (by data_ptr) to the gradient views they accumulate into and is told
+    when a parameter's gradient is complete.  `anchor` is a dummy leaf that requires grad: it rides
+    along every conv call so that autograd schedules the backward of layers whose data input does
+    not require grad (the first conv reads the resampled voxels)."""
+
+    def __init__(self, grad_of, on_ready=None, device="cuda"):
+        self.grad_of = grad_of            # {data_ptr: grad tensor}
+        self.on_ready = on_ready          # callable(data_ptr) or None
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    def grad(self, t):
+        g = self.grad_of.get(t.data_ptr())
+        if g is None:
+            raise L.RenderNetHipError("no gradient buffer registered for a parameter of shape %s" % (tuple(t.shape),))
+        return g
+
+    def ready(self, *ts):
+        if self.on_ready is not None:
+            for t in ts:
+                if t is not None:
+                    self.on_ready(t.data_ptr())
+
+
+TRAIN = None
+
+
+@contextlib.contextmanager
+def training(ctx):
+    """Within this context the conv operators save what their backward needs and are differentiable."""
+    global TRAIN
+    old, TRAIN = TRAIN, ctx
+    try:
+        yield ctx
+    finally:
+        TRAIN = old
+
+
+def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
+    lib, st = L.lib(), L.stream_ptr()
+    a = (L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))
+    if mode == "conv3d":
+        B, H, W, D, Cin = x.shape
+        return lib.rn_conv3d_fwd_train(*a, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
+    if mode == "conv2d":
+        B, H, W, Cin = x.shape
+        return lib.rn_conv2d_fwd_train(*a, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
+    if mode == "conv2d_transpose":
+        B, H, W, Cin = x.shape
+        return lib.rn_conv2d_transpose_fwd_train(*a, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
+    if mode == "conv3d_transpose":
+        B, H, W, D, Cin = x.shape
+        return lib.rn_conv3d_transpose_fwd_train(*a, B, H, W, D, Cin, pw.cout, ksize[0], stride[0], act, st)
+    raise ValueError(mode)
+
+
+def _out_shape(mode, x, pw, stride):
+    sp = x.shape[1:-1]
+    if mode in ("conv3d", "conv2d"):
+        return (x.shape[0],) + tuple(-(-int(n) // int(s)) for n, s in zip(sp, stride)) + (pw.cout,)
+    return (x.shape[0],) + tuple(int(n) * int(stride[0]) for n in sp) + (pw.cout,)
+
+
+class _Conv(torch.autograd.Function):
+    """y = sigmoid?( prelu?( conv(x, w) + bias ) + residual ) for the four conv flavours; one HIP launch
+    forward (plus the saved pre-activation when training), three backward (epilogue, dgrad, wgrad)."""
+
     @staticmethod
-    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode):
+    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor):
         _chk_dev(x, pw.data, bias, alpha, residual)
         ev = LAUNCH_HOOK(mode, tuple(x.shape), pw) if LAUNCH_HOOK is not None else None
         if ev is not None:
             ev[0].record()
-        lib = L.lib()
         act = _act_code(alpha, sigmoid)
-        st = L.stream_ptr()
-        if mode == "conv3d":
-            B, H, W, D, Cin = x.shape
-            o = [-(-H // stride[0]), -(-W // stride[1]), -(-D // stride[2])]
-            y = torch.empty((B, o[0], o[1], o[2], pw.cout), dtype=torch.float32, device=x.device)
-            rc = lib.rn_conv3d_fwd(L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
-                                   B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
-        elif mode == "conv2d":
-            B, H, W, Cin = x.shape
-            y = torch.empty((B, -(-H // stride[0]), -(-W // stride[1]), pw.cout), dtype=torch.float32, device=x.device)
-            rc = lib.rn_conv2d_fwd(L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
-                                   B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
-        elif mode == "conv2d_transpose":
-            B, H, W, Cin = x.shape
-            s = stride[0]
-            y = torch.empty((B, H * s, W * s, pw.cout), dtype=torch.float32, device=x.device)
-            rc = lib.rn_conv2d_transpose_fwd(L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual),
-                                             L.ptr(y), B, H, W, Cin, pw.cout, ksize[0], s, act, st)
-        elif mode == "conv3d_transpose":
-            B, H, W, D, Cin = x.shape
-            s = stride[0]
-            y = torch.empty((B, H * s, W * s, D * s, pw.cout), dtype=torch.float32, device=x.device)
-            rc = lib.rn_conv3d_transpose_fwd(L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual),
-                                             L.ptr(y), B, H, W, D, Cin, pw.cout, ksize[0], s, act, st)
-        else:
-            raise ValueError(mode)
-        L.check(rc, "rn_%s_fwd" % mode)
-        if ev is not None:
-            ev[1].record()
+        train = anchor is not None
+        y = torch.empty(_out_shape(mode, x, pw, stride), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:
             raise L.RenderNetHipError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+        z = torch.empty_like(y) if (train and alpha is not None) else None
+        L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act), "rn_%s_fwd" % mode)
+        if ev is not None:
+            ev[1].record()
+        if train:
+            ctx.save_for_backward(x, z, y if sigmoid else None)
+            ctx.cfg = (pw, bias, alpha, residual is not None, tuple(ksize), tuple(stride), act, mode, TRAIN)
         return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, y = ctx.saved_tensors
+        pw, bias, alpha, has_res, ksize, stride, act, mode, tc = ctx.cfg
+        lib, st = L.lib(), L.stream_ptr()
+        dy = dy.contiguous()
+        C = dy.shape[-1]
+        M = dy.numel() // C
+        # 1. epilogue backward: dz (new buffer only when the values change), dbias, dalpha
+        dz = torch.empty_like(dy) if act else dy
+        if act or bias is not None:
+            L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), L.ptr(y), L.ptr(alpha), L.ptr(dz) if act else None,
+                                        L.ptr(tc.grad(bias)) if bias is not None else None,
+                                        L.ptr(tc.grad(alpha)) if alpha is not None else None,
+                                        M, C, act, st), "rn_epilogue_bwd")
+        d_res = None
+        if has_res and ctx.needs_input_grad[4]:
+            if act & L.RN_ACT_SIGMOID:
+                raise L.RenderNetHipError("backward of sigmoid + residual in one epilogue is not supported")
+            d_res = dy                      # PReLU sits before the residual add: its gradient is dy itself
+        # 2. wgrad, accumulated into the registered gradient view (TF layout)
+        dw = tc.grad(pw.w_tf)
+        unit = all(int(v) == 1 for v in stride)
+        if mode == "conv3d":
+            B, H, W, D, Cin = x.shape
+            rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+        elif mode == "conv2d":
+            B, H, W, Cin = x.shape
+            rc = lib.rn_conv2d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+        elif mode == "conv2d_transpose":
+            B, H, W, Cin = x.shape
+            rc = lib.rn_conv2d_transpose_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, ksize[0], stride[0], st)
+        else:
+            B, H, W, D, Cin = x.shape
+            rc = lib.rn_conv3d_transpose_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, ksize[0], stride[0], st)
+        L.check(rc, "rn_%s_wgrad" % mode)
+        # 3. dgrad
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            dp = pw.dgrad_pack(unit)
+            if mode == "conv3d":
+                rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+            elif mode == "conv2d":
+                rc = lib.rn_conv2d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+            elif mode == "conv2d_transpose":
+                rc = lib.rn_conv2d_transpose_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, Cin, pw.cout, ksize[0], stride[0], st)
+            else:
+                rc = lib.rn_conv3d_transpose_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, ksize[0], stride[0], st)
+            L.check(rc, "rn_%s_dgrad" % mode)
+        tc.ready(pw.w_tf, bias, alpha)
+        return dx, None, None, None, d_res, None, None, None, None, None
 
 
 def _prep(x, pw, mode_cin):
@@ -150,26 +275,31 @@ def _prep(x, pw, mode_cin):
     return x
 
 
+def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode):
+    anchor = TRAIN.anchor if (TRAIN is not None and torch.is_grad_enabled()) else None
+    return _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor)
+
+
 def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False):
     x = _prep(x, pw, 4)
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(pw.kdims), tuple(stride), sigmoid, "conv3d")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d")
 
 
 def conv2d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False):
     x = _prep(x, pw, 3)
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(pw.kdims), tuple(stride), sigmoid, "conv2d")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d")
 
 
 def conv2d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False):
     x = _prep(x, pw, 3)
     if stride[0] != stride[1] or pw.kdims[0] != pw.kdims[1]:
         raise L.RenderNetHipError("conv2d_transpose: square kernels/strides only")
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(pw.kdims), tuple(stride), sigmoid, "conv2d_transpose")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d_transpose")
 
 
 def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False):
     x = _prep(x, pw, 4)
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(pw.kdims), tuple(stride), sigmoid, "conv3d_transpose")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d_transpose")
 
 
 class _Projection(_ForwardOnly):
@@ -188,6 +318,10 @@ def projection(x, pw, bias, alpha):
     x = x.contiguous().float()
     if x.shape[3] * x.shape[4] != pw.cin or pw.cin != pw.cout:
         raise L.RenderNetHipError("projection: D*C=%d but filter is %dx%d" % (x.shape[3] * x.shape[4], pw.cin, pw.cout))
+    if TRAIN is not None and torch.is_grad_enabled():
+        # training: the same GEMM through the differentiable 1x1 conv2d path (the reshape is a view)
+        B, H, W, D, C = x.shape
+        return _conv_apply(x.view(B, H, W, D * C), pw, bias, alpha, None, (1, 1), (1, 1), False, "conv2d")
     return _Projection.apply(x, pw, bias, alpha)
 
 

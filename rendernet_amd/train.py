@@ -1,0 +1,206 @@
+"""The training step of the Phong-shader net on the MI355X path (BASELINE config 4).
+
+Mirrors RenderNet_Shader.py:135-167 + :239-240: resample -> transform -> random crop (one window for
+the whole batch, tools/model_util.py:77-100) -> RenderNet(is_training=True) -> BCE (greyscale) or
+MSE (RGB) reconstruction loss -> `tf.train.AdamOptimizer(lr, beta1=0.5).minimize` with
+`tf.train.exponential_decay(e_eta, global_step, decay_steps, 0.96, staircase=True)`.
+
+MI355X design: forward, dgrad, wgrad, epilogue backward, loss and Adam are HIP kernels behind the C
+ABI; parameters, gradients and both Adam moments live in four flat fp32 buffers (237.3 M floats =
+949 MB each); wgrad kernels accumulate straight into the flat gradient buffer.  Data parallelism is one
+process per GPU with the batch sharded by frame: the loss is a mean over the GLOBAL batch, so ranks
+compute d(sum of their frames)/global_batch and the gradient all-reduce is a plain SUM (RCCL over
+xGMI through torch.distributed, backend "nccl").  The flat gradient buffer is cut into contiguous
+buckets in reverse creation order (= the order the backward finishes them); a bucket's all-reduce is
+launched asynchronously the moment its last parameter gradient is complete, overlapping the remaining
+backward; the optimiser step waits for all buckets.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+from . import variables as V
+from .shader import RenderNet, ShaderSpec, init_shader_weights
+from .tools.resampling_voxel_grid import rotation_resampling_to_image
+
+
+def exponential_decay(lr0, step, decay_steps, rate=0.96, staircase=True):
+    """tf.train.exponential_decay (RenderNet_Shader.py:165)."""
+    e = step / float(decay_steps)
+    return lr0 * rate ** (math.floor(e) if staircase else e)
+
+
+def adam_lr_t(lr, t, beta1, beta2):
+    """TF's AdamOptimizer folds the bias corrections into the step size (t = 1 on the first update)."""
+    return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+
+def plan_buckets(layout, order, bucket_floats):
+    """Cut the flat gradient buffer into contiguous buckets following `order` (the parameter names in
+    the order their gradients complete, i.e. reverse creation order).  Returns [(lo, hi, [names])] with
+    lo/hi float offsets; every parameter belongs to exactly one bucket.  Pure host logic (CPU-testable)."""
+    buckets, cur, lo, hi = [], [], None, None
+    for n in order:
+        o, k = layout[n]
+        e = o + (k + 3) // 4 * 4
+        if cur and (max(hi, e) - min(lo, o)) > bucket_floats:
+            buckets.append((lo, hi, cur))
+            cur, lo, hi = [], None, None
+        cur.append(n)
+        lo = o if lo is None else min(lo, o)
+        hi = e if hi is None else max(hi, e)
+    if cur:
+        buckets.append((lo, hi, cur))
+    return buckets
+
+
+class GradBuckets:
+    """Bucketed, overlapped SUM all-reduce of a flat gradient buffer.  `ready(name)` is called as each
+    parameter's gradient completes; when a bucket is complete its slice is all-reduced asynchronously
+    (on the process group's own stream, ordered after the work already queued on the current stream).
+    Backend-agnostic: RCCL ("nccl") on the GPUs, gloo in the CPU tests."""
+
+    def __init__(self, flat_grad, layout, order, bucket_mb=100.0, group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = plan_buckets(layout, order, int(bucket_mb * 1e6 / 4))
+        self.bucket_of = {n: i for i, (_, _, ns) in enumerate(self.buckets) for n in ns}
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(ns) for _, _, ns in self.buckets]
+        self.seen = set()
+        self.handles = []
+        self.launched = []
+
+    def ready(self, name):
+        if name in self.seen:
+            return
+        self.seen.add(name)
+        i = self.bucket_of[name]
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        self.launched.append(i)
+        if self.world > 1:
+            lo, hi, _ = self.buckets[i]
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch whatever is still pending (parameters that received no gradient) and wait for all."""
+        for i, p in enumerate(self.pending):
+            if p > 0:
+                self.pending[i] = 0
+                self._launch(i)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+class Trainer:
+    """Holds parameters / gradients / Adam moments of the Phong-shader net on one GPU and runs training
+    steps.  With torch.distributed initialised every rank holds a full replica and a shard of the batch."""
+
+    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, e_eta=1e-5, decay_steps=100000,
+                 beta1=0.5, beta2=0.999, epsilon=1e-8, keep_prob=1.0, bucket_mb=100.0, group=None):
+        self.spec = (spec or ShaderSpec()).check()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("rendernet_amd.Trainer needs a HIP device; there is no CPU training path")
+        self.store = V.VariableStore(self.device, seed)
+        self.store.load_state_dict(weights if weights is not None else init_shader_weights(self.spec, seed))
+        self.names = list(self.store.vars.keys())
+        self.param, self.layout = self.store.flatten(self.names)
+        self.grad = torch.zeros_like(self.param)
+        self.m = torch.zeros_like(self.param)
+        self.v = torch.zeros_like(self.param)
+        self.grad_views = {n: self.grad[o:o + k].view(self.store.vars[n].shape) for n, (o, k) in self.layout.items()}
+        self._ptr_name = {self.store.vars[n].data_ptr(): n for n in self.names}
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = GradBuckets(self.grad, self.layout, list(reversed(self.names)), bucket_mb, group)
+        self.ctx = ops.TrainContext({self.store.vars[n].data_ptr(): g for n, g in self.grad_views.items()},
+                                    on_ready=lambda p: self.buckets.ready(self._ptr_name[p]), device=self.device)
+        self.e_eta, self.decay_steps = float(e_eta), int(decay_steps)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self.keep_prob = float(keep_prob)
+        self.global_step = 0
+        self.loss_buf = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.mse = self.spec.out_ch != 1                      # RenderNet_Shader.py:159-163
+
+    # -- pieces (also used one by one by the parity tests) ----------------------------------
+    def forward(self, voxels, poses, patch_size=None, start_point=None, taps=None, net_in=None):
+        """Training-mode forward: returns (prediction [b,4p,4p,ch], window).  `net_in` [b,p,p,N,C], when
+        given, is an already resampled + cropped grid (voxels/poses are then ignored)."""
+        s = self.spec
+        p = int(patch_size) if patch_size is not None else s.new_size
+        if net_in is not None:
+            net_in = torch.as_tensor(net_in, dtype=torch.float32).to(self.device).contiguous()
+            if start_point is None:
+                raise ValueError("net_in needs the start_point it was cropped at")
+        else:
+            vox = torch.as_tensor(voxels, dtype=torch.float32).to(self.device)
+            pose = torch.as_tensor(poses, dtype=torch.float32).to(self.device)
+        if start_point is None:
+            start_point = torch.randint(0, s.new_size - p + 1, (2,)).tolist() if p != s.new_size else (0, 0)
+        window = (int(start_point[0]), int(start_point[1]), p, p)
+        old = V._default
+        V.set_default_store(self.store)
+        try:
+            with ops.training(self.ctx):
+                if net_in is None:
+                    net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
+                if taps is not None:
+                    taps["net_in"] = net_in
+                pred = RenderNet(net_in, True, prob=self.keep_prob, spec=s, taps=taps)
+        finally:
+            V._default = old
+        return pred, window
+
+    def loss_and_backward(self, pred, target_patch, global_batch):
+        """Loss kernel (value accumulated into self.loss_buf, gradient w.r.t. pred) + the HIP backward."""
+        tgt = target_patch.contiguous()
+        dpred = torch.empty_like(pred)
+        n = pred.numel()
+        divisor = float(global_batch) if not self.mse else float(n // pred.shape[0] * global_batch)
+        L.check(L.lib().rn_loss_fwd_bwd(L.ptr(pred), L.ptr(tgt), L.ptr(dpred), self.loss_buf.data_ptr(), n, divisor,
+                                        1 if self.mse else 0, L.stream_ptr()), "rn_loss_fwd_bwd")
+        pred.backward(dpred)
+
+    def apply_gradients(self):
+        self.global_step += 1
+        lr = exponential_decay(self.e_eta, self.global_step - 1, self.decay_steps)
+        lr_t = adam_lr_t(lr, self.global_step, self.beta1, self.beta2)
+        L.check(L.lib().rn_adam_step(L.ptr(self.param), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.param.numel(),
+                                     lr_t, self.beta1, self.beta2, self.epsilon, 1.0, L.stream_ptr()), "rn_adam_step")
+        self.store.repack_all()
+
+    # -- one step -----------------------------------------------------------------------------
+    def step(self, voxels, poses, targets, patch_size=None, start_point=None, global_batch=None, net_in=None):
+        """One optimiser step on this rank's shard (voxels [b,S,S,S,C], poses [b,3], targets [b,512,512,ch]).
+        `start_point` must be the same on every rank (the reference draws one window per batch).
+        Returns the loss as a 0-d float64 device tensor (global mean; identical on all ranks)."""
+        b = int(targets.shape[0])
+        gb = int(global_batch) if global_batch is not None else b * self.world
+        self.grad.zero_()
+        self.loss_buf.zero_()
+        self.buckets.reset()
+        pred, (r, c, p, _) = self.forward(voxels, poses, patch_size, start_point, net_in=net_in)
+        tgt = torch.as_tensor(targets, dtype=torch.float32).to(self.device)
+        tgt = tgt[:, 4 * r:4 * (r + p), 4 * c:4 * (c + p), :]          # tools/model_util.py:99
+        self.loss_and_backward(pred, tgt, gb)
+        self.buckets.finish()
+        if self.world > 1:
+            dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.apply_gradients()
+        return self.loss_buf[0].clone()
+
+    def state_dict(self):
+        return self.store.state_dict()

@@ -101,6 +101,33 @@ class VariableStore:
     def num_parameters(self):
         return int(sum(v.numel() for v in self.vars.values()))
 
+    # -- training: one flat parameter buffer ------------------------------------------------
+    def flatten(self, names=None):
+        """Move the variables (creation order, or `names`) into ONE contiguous float32 buffer, each
+        variable 16-byte aligned, and make self.vars[name] views of it.  Returns
+        (flat_buffer, {name: (offset, numel)}).  The optimiser (rn_adam_step), the gradient zeroing and
+        the gradient all-reduce then work on flat buffers instead of ~230 small tensors.  The packed
+        filter cache is dropped because it refers to the old storage."""
+        names = list(self.vars.keys()) if names is None else list(names)
+        layout, off = {}, 0
+        for n in names:
+            k = self.vars[n].numel()
+            layout[n] = (off, k)
+            off += (k + 3) // 4 * 4
+        flat = torch.zeros(max(off, 4), dtype=torch.float32, device=self.device)
+        for n in names:
+            o, k = layout[n]
+            view = flat[o:o + k].view(self.vars[n].shape)
+            view.copy_(self.vars[n])
+            self.vars[n] = view
+        self._packed.clear()
+        return flat, layout
+
+    def repack_all(self):
+        """Refresh every cached packed filter from its TF-layout master (after an optimiser step)."""
+        for p in self._packed.values():
+            p.repack()
+
 
 _default = None
 

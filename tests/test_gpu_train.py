@@ -1,0 +1,304 @@
+"""Parity of the training step (BASELINE config 4) through the C ABI against the CPU oracle.  -m gpu.
+
+Unit level: every backward kernel (epilogue backward, dgrad, wgrad of each conv flavour, loss, Adam)
+against torch-CPU autograd over oracle/layers.py on the same seeded inputs.  Tolerance for gradients:
+max|got-want| <= 2e-4 * max|want| (exact-fp32 MFMA = fmaf chain accumulated with fp32 atomics in an
+order that differs from oneDNN's).  Net level: loss, every parameter gradient and the parameters after
+Adam steps of the reduced-width net against oracle/train.py.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as OL
+from oracle import train as OT
+from oracle import resample as OR
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-4
+
+
+def _dev(a):
+    return None if a is None else torch.as_tensor(a).cuda()
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def _xavier(rng, shape):
+    rf = int(np.prod(shape[:-2]))
+    lim = np.sqrt(6.0 / ((shape[-2] + shape[-1]) * rf))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+def _close(got, want, what, rtol=RTOL):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    want = want.detach().numpy() if isinstance(want, torch.Tensor) else want
+    assert got.shape == tuple(want.shape), (what, got.shape, want.shape)
+    err = np.abs(got - want).max()
+    ref = np.abs(want).max()
+    assert err <= rtol * ref + 1e-7, "%s: max err %g vs max |ref| %g" % (what, err, ref)
+
+
+class _Ctx:
+    """A TrainContext over ad-hoc parameters: gradients land in fresh zero buffers."""
+
+    def __init__(self, *params):
+        from rendernet_amd import ops
+        self.g = {p.data_ptr(): torch.zeros_like(p) for p in params if p is not None}
+        self.ready = []
+        self.tc = ops.TrainContext(self.g, on_ready=self.ready.append)
+
+    def grad(self, p):
+        return self.g[p.data_ptr()]
+
+
+# (mode, B, spatial, Cin, Cout, k, stride, prelu, residual)
+LAYER_CASES = [
+    ("conv3d", 2, (16, 16, 16), 1, 8, 5, (2, 2, 2), True, False),      # e_conv1: narrow wgrad, no dgrad needed
+    ("conv3d", 2, (8, 8, 8), 8, 16, 3, (1, 1, 2), True, False),        # e_conv2: strided direct dgrad, 32x32 wgrad tile
+    ("conv3d", 2, (8, 8, 4), 16, 32, 3, (1, 1, 1), True, False),       # e_conv3
+    ("conv3d", 2, (8, 8, 4), 32, 32, 3, (1, 1, 1), True, False),       # res1 first conv (PReLU)
+    ("conv3d", 1, (5, 7, 3), 32, 32, 3, (1, 1, 1), False, True),       # res1 second conv (residual), ragged
+    ("conv2d", 2, (16, 16), 256, 256, 3, (1, 1), True, False),         # res2-like: 128x128 wgrad tiles
+    ("conv2d", 1, (9, 11), 128, 64, 3, (1, 1), False, True),           # ragged, 128x128 tile with channel tail
+    ("conv2d", 2, (8, 8), 256, 128, 4, (1, 1), True, False),           # e_conv5-like 4x4 (pad 1,2)
+    ("conv2d", 2, (6, 6), 64, 64, 1, (1, 1), True, False),             # projection-like 1x1
+    ("conv2d", 1, (8, 8), 32, 128, 3, (1, 1), False, False),           # 32x128 wgrad tile
+    ("conv2d", 1, (8, 8), 128, 32, 3, (1, 1), False, False),           # 128x32 wgrad tile
+    ("conv2d_transpose", 2, (8, 8), 256, 128, 4, (2, 2), True, False),  # e_conv7
+    ("conv2d_transpose", 2, (8, 8), 128, 128, 4, (1, 1), True, False),  # e_conv7_1
+    ("conv2d_transpose", 1, (12, 12), 64, 32, 4, (2, 2), True, False),  # e_conv9
+    ("conv2d_transpose", 1, (16, 16), 32, 16, 4, (1, 1), True, False),  # e_conv10
+    ("conv2d_transpose", 2, (16, 16), 16, 1, 4, (1, 1), False, False),  # e_conv11 (direct kernels, narrow wgrad)
+    ("conv2d_transpose", 1, (16, 16), 16, 3, 4, (1, 1), False, False),  # RGB head
+    ("conv3d_transpose", 1, (4, 4, 4), 8, 4, 4, (2, 2, 2), True, False),  # texture decoder
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: "%s-%d-%d-k%d-s%d" % (c[0], c[3], c[4], c[5], c[6][-1]))
+def test_layer_backward(case):
+    """dx, dw, dbias, dalpha, d(residual) of one fused layer vs torch-CPU autograd over the oracle op."""
+    from rendernet_amd import ops
+    mode, B, sp, Cin, Cout, k, stride, prelu, residual = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    nd = len(sp)
+    transposed = mode.endswith("transpose")
+    x = _rand(rng, B, *sp, Cin)
+    w = _xavier(rng, (k,) * nd + ((Cout, Cin) if transposed else (Cin, Cout)))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0.05, 0.3, Cout).astype(np.float32) if prelu else None
+    ofn = {"conv3d": OL.conv3d, "conv2d": OL.conv2d, "conv2d_transpose": OL.conv2d_transpose,
+           "conv3d_transpose": OL.conv3d_transpose}[mode]
+    # oracle
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    at = torch.from_numpy(alpha).requires_grad_(True) if prelu else None
+    y = ofn(xt, wt, bt, stride)
+    if prelu:
+        y = OL.prelu(y, at)
+    rt = None
+    if residual:
+        rt = torch.from_numpy(_rand(rng, *y.shape)).requires_grad_(True)
+        y = y + rt
+    dy = _rand(rng, *y.shape)
+    y.backward(torch.from_numpy(dy))
+    # HIP path
+    xd = _dev(x).requires_grad_(True)
+    wd, bd, ad = _dev(w), _dev(b), _dev(alpha)
+    rd = _dev(rt.detach().numpy()).requires_grad_(True) if residual else None
+    c = _Ctx(wd, bd, ad)
+    pw = ops.pack_conv_transpose(wd, stride[0]) if transposed else ops.pack_conv(wd)
+    with ops.training(c.tc):
+        yd = getattr(ops, mode)(xd, pw, bd, ad, rd, stride)
+    _close(yd, y, "forward")
+    yd.backward(_dev(dy))
+    _close(xd.grad, xt.grad, "dx")
+    _close(c.grad(wd), wt.grad, "dw")
+    _close(c.grad(bd), bt.grad, "dbias")
+    if prelu:
+        _close(c.grad(ad), at.grad, "dalpha")
+    if residual:
+        _close(rd.grad, rt.grad, "dresidual")
+    assert set(c.ready) == {t.data_ptr() for t in (wd, bd, ad) if t is not None}
+
+
+def test_wgrad_accumulates_and_large_reduction():
+    """dw is accumulated (two calls = twice the gradient) and the split reduction handles a long, ragged M."""
+    from rendernet_amd import _lib as L
+    rng = np.random.default_rng(5)
+    B, H, W, Cin, Cout = 3, 37, 29, 32, 32
+    x, dz = _rand(rng, B, H, W, Cin), _rand(rng, B, H, W, Cout)
+    xt = torch.from_numpy(x)
+    wt = torch.zeros(3, 3, Cin, Cout, requires_grad=True)
+    OL.conv2d(xt, wt).backward(torch.from_numpy(dz))
+    dw = torch.zeros(3, 3, Cin, Cout, device="cuda")
+    xd, dzd = _dev(x), _dev(dz)            # keep the device tensors alive across the asynchronous launches
+    for _ in range(2):
+        L.check(L.lib().rn_conv2d_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(dw), B, H, W, Cin, Cout,
+                                        L.ivec([3, 3]), L.ivec([1, 1]), L.stream_ptr()), "rn_conv2d_wgrad")
+    _close(dw, 2 * wt.grad, "accumulated dw")
+
+
+@pytest.mark.parametrize("C,act", [(1024, 1), (32, 1), (8, 1), (1, 2), (3, 2), (16, 0), (2048, 1), (20, 1)])
+def test_epilogue_bwd(C, act):
+    from rendernet_amd import _lib as L
+    rng = np.random.default_rng(C * 7 + act)
+    M = 1000 if C < 1024 else 300
+    dy, z = _rand(rng, M, C), _rand(rng, M, C)
+    alpha = rng.uniform(0.05, 0.3, C).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    at = torch.from_numpy(alpha).requires_grad_(True)
+    bt = torch.zeros(C, requires_grad=True)
+    yt = zt + bt
+    if act & 1:
+        yt = OL.prelu(yt, at)
+    if act & 2:
+        yt = torch.sigmoid(yt)
+    yt.backward(torch.from_numpy(dy))
+    dz = torch.empty(M, C, device="cuda")
+    db, da = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dyd, zd, yd, ald = _dev(dy), _dev(z), _dev(yt.detach().numpy()), _dev(alpha)
+    L.check(L.lib().rn_epilogue_bwd(L.ptr(dyd), L.ptr(zd), L.ptr(yd), L.ptr(ald),
+                                    L.ptr(dz) if act else None, L.ptr(db), L.ptr(da), M, C, act, L.stream_ptr()), "epi")
+    if act:
+        _close(dz, zt.grad, "dz")
+    _close(db, bt.grad, "dbias")
+    if act & 1:
+        _close(da, at.grad, "dalpha")
+
+
+@pytest.mark.parametrize("mode,ch", [(0, 1), (1, 3)])
+def test_loss(mode, ch):
+    from rendernet_amd import _lib as L
+    rng = np.random.default_rng(mode)
+    B = 3
+    p = rng.uniform(0.001, 0.999, (B, 40, 40, ch)).astype(np.float32)
+    p[0, 0, 0, 0], p[0, 0, 1, 0] = 0.0, 1.0                     # the 1e-6 guard of RenderNet_Shader.py:160
+    t = rng.uniform(0, 1, p.shape).astype(np.float32)
+    pt = torch.from_numpy(p).requires_grad_(True)
+    loss = OL.bce_loss(pt, t) if mode == 0 else OT.mse_loss(pt, torch.from_numpy(t))
+    loss.backward()
+    dp = torch.empty(p.shape, device="cuda")
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    div = float(B) if mode == 0 else float(p.size)
+    pd, td = _dev(p), _dev(t)
+    L.check(L.lib().rn_loss_fwd_bwd(L.ptr(pd), L.ptr(td), L.ptr(dp), acc.data_ptr(), p.size, div, mode,
+                                    L.stream_ptr()), "loss")
+    assert abs(float(acc.item()) - float(loss.item())) <= 2e-6 * abs(float(loss.item()))
+    _close(dp, pt.grad, "dpred", 1e-5)
+
+
+def test_adam_matches_tf_formulation():
+    from rendernet_amd import _lib as L
+    rng = np.random.default_rng(3)
+    n = 100003                                             # not a multiple of 4: exercises the tail
+    p0 = _rand(rng, n)
+    opt = OT.Adam(e_eta=1e-3, decay_steps=2)
+    w = {"p": p0.copy()}
+    pd, md, vd = _dev(p0.copy()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    from rendernet_amd.train import exponential_decay, adam_lr_t
+    for step in range(1, 5):
+        g = (_rand(rng, n) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
+        w = opt.apply(w, {"p": g})
+        lr_t = adam_lr_t(exponential_decay(1e-3, step - 1, 2), step, 0.5, 0.999)
+        gd = _dev(g)
+        L.check(L.lib().rn_adam_step(L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, lr_t, 0.5, 0.999, 1e-8, 1.0,
+                                     L.stream_ptr()), "adam")
+        _close(pd, w["p"], "param after step %d" % step, 2e-6)
+    _close(md, opt.m["p"], "m", 1e-5)
+    _close(vd, opt.v["p"], "v", 1e-5)
+
+
+def _tiny_problem(out_ch=1, B=2, patch=16, start=(7, 3)):
+    from rendernet_amd.shader import tiny_spec, init_shader_weights
+    spec = tiny_spec(out_ch)
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    rng = np.random.default_rng(11)
+    vox = (rng.random((B, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    poses = np.array([[250 * np.pi / 180, 30 * np.pi / 180, 1.0], [1.0, 0.7, 0.9], [2.0, 0.4, 1.1]][:B], np.float32)
+    target = rng.uniform(0, 1, (B, 128, 128, out_ch)).astype(np.float32)
+    net_in_full = OR.net_input(vox, poses, 16, 32)
+    net_in, tgt = OT.crop_voxel_image(net_in_full, target, start, patch)
+    return spec, w, vox, poses, target, net_in, tgt, start, patch
+
+
+@pytest.mark.parametrize("out_ch", [1, 3])
+def test_net_gradients_match_oracle(out_ch):
+    """Loss and every parameter gradient of the reduced-width net (all layer kinds, crop window,
+    BCE / MSE) against torch-CPU autograd over the oracle graph."""
+    from rendernet_amd.train import Trainer
+    spec, w, vox, poses, target, net_in, tgt, start, patch = _tiny_problem(out_ch)
+    tr = Trainer(spec, w, device="cuda:0")
+    taps = {}
+    p, (r, c, ps, _) = tr.forward(vox, poses, patch, start, taps=taps)
+    # the resampler has its own parity suite (tests/test_gpu_resample.py; its pose path may flip isolated
+    # border samples by design): feed the oracle the very grid the net saw so that this test isolates the
+    # backward kernels
+    got_in = taps["net_in"].cpu().numpy()
+    assert np.abs(got_in - net_in).max() <= 1e-3 and (np.abs(got_in - net_in) > 2e-4).mean() <= 1e-4
+    loss, grads, pred = OT.loss_and_grads(got_in, tgt, w, spec.n_res1, spec.n_res2, spec.n_res3, greyscale=out_ch == 1)
+    assert np.abs(p.detach().cpu().numpy() - pred).max() <= 1e-3
+    tr.loss_and_backward(p, _dev(tgt), vox.shape[0])
+    got_loss = float(tr.loss_buf.item())
+    assert abs(got_loss - loss) <= 1e-4 * abs(loss), (got_loss, loss)
+    worst = 0.0
+    for name, g in grads.items():
+        got = tr.grad_views[name].cpu().numpy()
+        ref = np.abs(g).max()
+        err = np.abs(got - g).max()
+        worst = max(worst, err / (ref + 1e-12))
+        print("%-48s rel err %.2e" % (name, err / (ref + 1e-12)))
+        assert err <= 1e-3 * ref + 1e-7, "%s: grad err %g vs max|ref| %g" % (name, err, ref)
+    assert len(tr.buckets.seen) == len(grads)             # every parameter reported complete
+    print("worst relative gradient error %.3g over %d tensors" % (worst, len(grads)))
+
+
+def test_training_steps_follow_oracle():
+    """Three optimiser steps (Adam beta1=0.5, exponential decay) track the oracle's losses and parameters.
+    Both sides train on the same resampled grid (GPU resampler output) so that only the training kernels
+    are compared.  Adam normalises every update to ~lr whatever the gradient's size, so parameters are
+    compared where the gradient is clear of the fp32 noise floor (|g| > 1e-3 max|g| at every step)."""
+    from rendernet_amd.train import Trainer
+    from rendernet_amd.tools.resampling_voxel_grid import rotation_resampling_to_image
+    spec, w, vox, poses, target, _, _, _, patch = _tiny_problem(1)
+    lr = 1e-3
+    tr = Trainer(spec, w, device="cuda:0", e_eta=lr, decay_steps=2)
+    opt = OT.Adam(e_eta=lr, decay_steps=2)
+    wo = {k: v.copy() for k, v in w.items()}
+    net_in_full = rotation_resampling_to_image(_dev(vox), _dev(poses), 16, 32).cpu().numpy()
+    mask = {k: np.ones(v.shape, bool) for k, v in w.items()}
+    for step, start in enumerate([(7, 3), (0, 16), (16, 0)]):
+        net_in, tgt = OT.crop_voxel_image(net_in_full, target, start, patch)
+        lo, grads, _ = OT.loss_and_grads(net_in, tgt, wo, spec.n_res1, spec.n_res2, spec.n_res3)
+        for k, g in grads.items():
+            mask[k] &= np.abs(g) > 1e-3 * np.abs(g).max()
+        wo = opt.apply(wo, grads)
+        lg = float(tr.step(None, None, target, patch_size=patch, start_point=start, net_in=np.ascontiguousarray(net_in)).item())
+        assert abs(lg - lo) <= 1e-3 * abs(lo), (step, lg, lo)
+    assert tr.global_step == 3
+    sd = tr.state_dict()
+    covered = sum(int(m.sum()) for m in mask.values()) / float(sum(m.size for m in mask.values()))
+    assert covered > 0.5, covered
+    # A PReLU input within rounding of zero may take the other branch on the two sides (the derivative is
+    # discontinuous there) and shifts the few gradient entries fed by that one position: allow 0.1 % outliers.
+    bad = total = 0
+    for k, v in wo.items():
+        d = np.abs(sd[k] - v)[mask[k]]
+        bad += int((d > 0.02 * 3 * lr).sum())                              # 2 % of the total movement
+        total += d.size
+    assert bad <= 1e-3 * total, (bad, total)
+    assert max(np.abs(sd[k] - w[k]).max() for k in w) > lr                # the steps really moved the weights
+
+
+def test_inference_render_unchanged_by_training_mode():
+    """Forward values are identical with and without the training context (preact saving is passive)."""
+    from rendernet_amd.shader import Renderer
+    from rendernet_amd.train import Trainer
+    spec, w, vox, poses, *_ = _tiny_problem(1)
+    a = Renderer(spec, w, device="cuda:0").render(vox, poses)
+    tr = Trainer(spec, w, device="cuda:0")
+    b, _ = tr.forward(vox, poses)
+    assert torch.equal(a, b.detach())
