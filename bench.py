@@ -73,6 +73,63 @@ def cpu_baseline(weights, frames=2):
                       "(resampler + full 237M-parameter net), %.1f s" % (frames, dt)}
 
 
+def train_main(args, world, rank, local_rank):
+    """BASELINE configs[3]: Phong-shader training step, batch 24 per GPU (global batch 24*N), crop `--patch`,
+    BCE loss, Adam; gradients summed across ranks with bucketed RCCL all-reduces overlapped with backward."""
+    import torch
+    import torch.distributed as dist
+    from rendernet_amd.shader import ShaderSpec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    spec = ShaderSpec().check()
+    weights = init_shader_weights(spec, seed=1234, perturb=True)
+    tr = Trainer(spec, weights, device="cuda:%d" % local_rank)
+    B, p = args.batch, args.patch
+    vox_np, poses_np = synthetic_batch(B)
+    poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)
+    vox, poses = torch.as_tensor(vox_np).cuda(), torch.as_tensor(poses_np).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(11 + rank)
+    targets = torch.rand((B, 512, 512, spec.out_ch), device="cuda", generator=gen)
+    starts = np.random.default_rng(3).integers(0, spec.new_size - p + 1, size=(args.warmup + args.steps, 2))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = tr.step(vox, poses, targets, patch_size=p, start_point=starts[i])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step(vox, poses, targets, patch_size=p, start_point=starts[args.warmup + i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    lossv = float(loss.item())
+    assert np.isfinite(lossv)
+    if rank == 0:
+        # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward (SURVEY.md §8d)
+        fwd_tflop = 2e-3 * GMAC_PER_FRAME * (p / float(spec.new_size)) ** 2
+        sps = B * world * args.steps / elapsed
+        print(json.dumps({
+            "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
+            "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Phong shader training step (resampler+crop, forward, BCE, dgrad+wgrad, bucketed "
+                                   "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
+                       "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
+            "approx_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
+            "final_loss": lossv}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +137,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=24, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["render", "train"], default="render",
+                    help="render = the headline metric (BASELINE configs[1]); train = the training step of "
+                         "configs[3] (forward + backward + gradient all-reduce + Adam), reported in samples/s")
+    ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")
     args = ap.parse_args()
 
     import torch
@@ -100,6 +161,8 @@ def main():
     from rendernet_amd import ops
     from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
 
+    if args.mode == "train":
+        return train_main(args, world, rank, local_rank)
     spec = ShaderSpec().check()
     weights = init_shader_weights(spec, seed=1234, perturb=True)
     renderer = Renderer(spec, weights, device="cuda:%d" % local_rank)

@@ -30,12 +30,14 @@ def mse_loss(pred, target):
     return torch.mean((pred - target) ** 2)
 
 
-def loss_and_grads(net_in, target, weights, n_res1=10, n_res2=10, n_res3=5, greyscale=True, taps=None):
+def loss_and_grads(net_in, target, weights, n_res1=10, n_res2=10, n_res3=5, greyscale=True, taps=None,
+                   dtype=np.float32):
     """net_in [B,p,p,N,1] (already resampled + cropped), target [B,4p,4p,ch], weights {tf_name: ndarray}.
-    Returns (loss float, {tf_name: gradient ndarray}, prediction ndarray)."""
-    wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).requires_grad_(True) for k, v in weights.items()}
-    x = torch.from_numpy(np.ascontiguousarray(net_in, dtype=np.float32))
-    t = torch.from_numpy(np.ascontiguousarray(target, dtype=np.float32))
+    Returns (loss float, {tf_name: gradient ndarray}, prediction ndarray).  dtype=float64 is used by the
+    finite-difference check that pins this function (tests/test_oracle_train.py)."""
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=dtype)).requires_grad_(True) for k, v in weights.items()}
+    x = torch.from_numpy(np.ascontiguousarray(net_in, dtype=dtype))
+    t = torch.from_numpy(np.ascontiguousarray(target, dtype=dtype))
     pred = ON.rendernet_forward_torch(x, wt, taps, n_res1, n_res2, n_res3)
     loss = L.bce_loss(pred, t) if greyscale else mse_loss(pred, t)
     loss.backward()

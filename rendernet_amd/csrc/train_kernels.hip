@@ -33,29 +33,47 @@ void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
     float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.act & RN_ACT_PRELU) al = reinterpret_cast<const float4*>(a.alpha)[g];
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, sa[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long r = r0 + rsub; r < r1; r += rstep) {
-        const size_t e = (size_t)r * G + g;
-        float4 d = reinterpret_cast<const float4*>(a.dy)[e];
-        float dv[4] = {d.x, d.y, d.z, d.w};
-        if (a.act & RN_ACT_SIGMOID) {
-            const float4 yv = reinterpret_cast<const float4*>(a.y)[e];
-            const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+    const bool has_s = (a.act & RN_ACT_SIGMOID) != 0, has_p = (a.act & RN_ACT_PRELU) != 0;
+    const float aa[4] = {al.x, al.y, al.z, al.w};
+    // UNR rows in flight per thread: the loop is pure streaming (12-16 B in, 16 B out per lane), so the
+    // loads of all UNR rows are issued before the first use
+    constexpr int UNR = 4;
+    for (long long rb = r0 + rsub; rb < r1; rb += (long long)rstep * UNR) {
+        float4 d[UNR], zv[UNR], yv[UNR];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dv[q] *= yy[q] * (1.f - yy[q]);
-        }
-        if (a.act & RN_ACT_PRELU) {
-            const float4 zv = reinterpret_cast<const float4*>(a.z)[e];
-            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
-            const float aa[4] = {al.x, al.y, al.z, al.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                sa[q] += dv[q] * fminf(zz[q], 0.f);
-                dv[q] = zz[q] > 0.f ? dv[q] : dv[q] * aa[q];
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = rb + (long long)u * rstep;
+            if (r < r1) {
+                const size_t e = (size_t)r * G + g;
+                d[u] = reinterpret_cast<const float4*>(a.dy)[e];
+                if (has_p) zv[u] = reinterpret_cast<const float4*>(a.z)[e];
+                if (has_s) yv[u] = reinterpret_cast<const float4*>(a.y)[e];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sb[q] += dv[q];
-        if (a.dz) reinterpret_cast<float4*>(a.dz)[e] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        for (int u = 0; u < UNR; ++u) {
+            const long long r = rb + (long long)u * rstep;
+            if (r < r1) {
+                const size_t e = (size_t)r * G + g;
+                float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+                if (has_s) {
+                    const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dv[q] *= yy[q] * (1.f - yy[q]);
+                }
+                if (has_p) {
+                    const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sa[q] += dv[q] * fminf(zz[q], 0.f);
+                        dv[q] = zz[q] > 0.f ? dv[q] : dv[q] * aa[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sb[q] += dv[q];
+                if (a.dz) reinterpret_cast<float4*>(a.dz)[e] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            }
+        }
     }
     // reduce the rstep row-lanes of each channel group through LDS, then one atomic per channel
 #pragma unroll
@@ -125,8 +143,8 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
     if (C % 4 == 0 && ((G <= 256 && 256 % G == 0) || G % 256 == 0)) {
         const int gy = G <= 256 ? 1 : G / 256;
         const int rstep = G < 256 ? 256 / G : 1;
-        long long rpb = ((long long)M + 2047) / 2048;                 // ~2048 row blocks
-        rpb = (rpb + rstep - 1) / rstep * rstep;
+        long long rpb = ((long long)M + 4095) / 4096;                 // ~4096 row blocks
+        rpb = (rpb + 4 * rstep - 1) / (4 * rstep) * (4 * rstep);       // whole 4-row unrolls
         if (rpb < 4 * rstep) rpb = 4 * rstep;
         a.rows_per_block = (int)rpb;
         const long long nb = ((long long)M + rpb - 1) / rpb;
