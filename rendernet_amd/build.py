@@ -76,6 +76,10 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        # an undefined symbol (e.g. a kernel whose host stub the compiler dropped) must fail the BUILD, not
+        # the first call on the GPU box
+        import ctypes
+        ctypes.CDLL(so)
     return so
 
 

@@ -24,6 +24,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int WG_MAX_CHUNK = 3072;      // positions per workgroup (row table = 12 KiB of LDS)
+
 struct WgradArgs {
     const float* a; const float* g; float* dw;
     unsigned a_bytes, g_bytes;
@@ -50,6 +52,7 @@ void conv_wgrad_kernel(const WgradArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);      // [2][BK][BM]
     float* Gs = As + 2 * ASZ;                        // [2][BK][BN]
+    unsigned* rowtab = reinterpret_cast<unsigned*>(Gs + 2 * GSZ);   // [WG_MAX_CHUNK] A-row byte offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,63 +70,76 @@ void conv_wgrad_kernel(const WgradArgs a)
     if (kbeg >= kend) return;
     const int nstage = (kend - kbeg + BK - 1) / BK;
 
-    // mixed-radix digits of BK over (b, o0, o1, o2): the per-stage position advance
-    int d2 = BK % a.O2, rr = BK / a.O2;
-    int d1 = rr % a.O1; rr /= a.O1;
-    int d0 = rr % a.O0; const int db = rr / a.O0;
-
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t arsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a), 0, a.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t grsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.g_bytes, 0x00020000);
 
-    // A rows owned by this lane: instruction q of this wave covers rows (wave*IAW+q)*RA + lane/CA
-    int pb[IAW], p0[IAW], p1[IAW], p2[IAW], ppos[IAW];
-    const int achunk = lane % CA;
-    const bool a_ch_ok = ca0 + achunk * 4 < a.Ca;
-#pragma unroll
-    for (int q = 0; q < IAW; ++q) {
-        int pos = kbeg + (wave * IAW + q) * RA + lane / CA;
-        ppos[q] = pos;
-        p2[q] = pos % a.O2; pos /= a.O2;
-        p1[q] = pos % a.O1; pos /= a.O1;
-        p0[q] = pos % a.O0; pb[q] = pos / a.O0;
+    // Row table: the byte offset of the A row of every position of this workgroup's reduction chunk for
+    // ITS tap (or OOB where SAME padding / the end of the chunk applies), computed once -- an odometer
+    // per thread, stepping 256 positions at a time -- and kept in LDS.  The per-stage DMA bookkeeping is
+    // then one ds_read_b32 + select + add per instruction instead of a position -> (b,o0,o1,o2)
+    // decomposition with bounds checks (measured: that block, vector or scalar, sat in front of every
+    // stage's MFMAs -- see DESIGN.md).
+    {
+        const int nrows = nstage * BK;
+        int pos = kbeg + tid;
+        int r = pos;
+        int o2 = r % a.O2; r /= a.O2;
+        int o1 = r % a.O1; r /= a.O1;
+        int o0 = r % a.O0; int b = r / a.O0;
+        const int e2 = 256 % a.O2; r = 256 / a.O2;
+        const int e1 = r % a.O1; r /= a.O1;
+        const int e0 = r % a.O0; const int eb = r / a.O0;
+        for (int i = tid; i < nrows; i += 256) {
+            const int i0 = o0 * a.S0 - a.P0 + t0, i1 = o1 * a.S1 - a.P1 + t1, i2 = o2 * a.S2 - a.P2 + t2;
+            const bool ok = pos < kend && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 &&
+                            (unsigned)i2 < (unsigned)a.I2;
+            const unsigned e = (unsigned)(((b * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * (unsigned)a.Ca;
+            rowtab[i] = ok ? e * 4u : OOB;
+            pos += 256;
+            int c;
+            o2 += e2; c = o2 >= a.O2; o2 -= c ? a.O2 : 0;
+            o1 += e1 + c; c = o1 >= a.O1; o1 -= c ? a.O1 : 0;
+            o0 += e0 + c; c = o0 >= a.O0; o0 -= c ? a.O0 : 0;
+            b += eb + c;
+        }
     }
-    int gpos[IGW];
-    const int gchunk = lane % CG;
+    __syncthreads();
+
+    const int achunk = lane % CA, arow = lane / CA;
+    const bool a_ch_ok = ca0 + achunk * 4 < a.Ca;
+    const unsigned a_cbytes = (unsigned)(ca0 + achunk * 4) * 4u;
+    const int gchunk = lane % CG, grow = lane / CG;
     const bool g_ch_ok = cg0 + gchunk * 4 < a.Cg;
-#pragma unroll
-    for (int q = 0; q < IGW; ++q) gpos[q] = kbeg + (wave * IGW + q) * RG + lane / CG;
+    const unsigned g_cbytes = (unsigned)(cg0 + gchunk * 4) * 4u;
+    const unsigned g_rbytes = (unsigned)a.Cg * 4u;
 
     typedef __attribute__((address_space(3))) void lds_void;
-#define RN_WG_DMA(stage)                                                                                  \
-    {                                                                                                     \
-        _Pragma("unroll") for (int q = 0; q < IAW; ++q) {                                                 \
-            const int i0 = p0[q] * a.S0 - a.P0 + t0, i1 = p1[q] * a.S1 - a.P1 + t1,                        \
-                      i2 = p2[q] * a.S2 - a.P2 + t2;                                                      \
-            const bool ok = a_ch_ok && ppos[q] < kend && (unsigned)i0 < (unsigned)a.I0 &&                 \
-                            (unsigned)i1 < (unsigned)a.I1 && (unsigned)i2 < (unsigned)a.I2;               \
-            const unsigned e = (unsigned)(((pb[q] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * (unsigned)a.Ca \
-                               + (unsigned)(ca0 + achunk * 4);                                            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc,                                               \
-                (lds_void*)(As + (stage) * ASZ + (wave * IAW + q) * RA * BM), 16, ok ? e * 4u : OOB, 0, 0, 0); \
-            /* advance this row by BK positions */                                                        \
-            ppos[q] += BK;                                                                                \
-            int c;                                                                                        \
-            p2[q] += d2; c = p2[q] >= a.O2; p2[q] -= c ? a.O2 : 0;                                        \
-            p1[q] += d1 + c; c = p1[q] >= a.O1; p1[q] -= c ? a.O1 : 0;                                    \
-            p0[q] += d0 + c; c = p0[q] >= a.O0; p0[q] -= c ? a.O0 : 0;                                    \
-            pb[q] += db + c;                                                                              \
-        }                                                                                                 \
-        _Pragma("unroll") for (int q = 0; q < IGW; ++q) {                                                 \
-            const bool ok = g_ch_ok && gpos[q] < kend;                                                    \
-            const unsigned e = (unsigned)gpos[q] * (unsigned)a.Cg + (unsigned)(cg0 + gchunk * 4);         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc,                                               \
-                (lds_void*)(Gs + (stage) * GSZ + (wave * IGW + q) * RG * BN), 16, ok ? e * 4u : OOB, 0, 0, 0); \
-            gpos[q] += BK;                                                                                \
-        }                                                                                                 \
-    }
+    // stage `st` of the chunk -> LDS stage buffer `buf`.  The A-row offsets of a stage are fetched from the
+    // row table one stage ahead (noff[]), so a stage opens with its 8 DMA issues back to back: a table read
+    // cannot be hoisted above an LDS-DMA by the compiler (both touch LDS), which serialised read -> wait ->
+    // DMA four times at the head of every stage.
+    static_assert(IAW <= 8, "noff");
+    unsigned noff[8];   // fixed extent: with the dependent extent [IAW] clang 22 silently drops the HOST stub of this kernel
+    auto load_tab = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < IAW; ++q) noff[q] = rowtab[st * BK + (wave * IAW + q) * RA + arow];
+    };
+    auto issue_dma = [&](int st, int buf) {
+#pragma unroll
+        for (int q = 0; q < IAW; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(As + buf * ASZ + (wave * IAW + q) * RA * BM), 16,
+                                                     a_ch_ok ? noff[q] + a_cbytes : OOB, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < IGW; ++q) {
+            const int gp = kbeg + st * BK + (wave * IGW + q) * RG + grow;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void*)(Gs + buf * GSZ + (wave * IGW + q) * RG * BN), 16,
+                                                     (g_ch_ok && gp < kend) ? (unsigned)gp * g_rbytes + g_cbytes : OOB,
+                                                     0, 0, 0);
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -133,34 +149,50 @@ void conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    RN_WG_DMA(0);
+    load_tab(0);
+    issue_dma(0, 0);
+    if (nstage > 1) load_tab(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int cur = 0;
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) RN_WG_DMA(cur ^ 1);
+        if (s + 1 < nstage) {
+            issue_dma(s + 1, cur ^ 1);
+            if (s + 2 < nstage) load_tab(s + 2);
+        }
         const float* Ab = As + cur * ASZ + lh * BM + wm * WTM + li;
         const float* Gb = Gs + cur * GSZ + lh * BN + wn * WTN + li;
-#pragma unroll 8
-        for (int kk = 0; kk < BK / 2 / WK; ++kk) {
-            const int ks = kk * WK + wk;
-            float af[TM], bf[TN];
+        // Fragment reads run ONE k-step ahead of the MFMAs that consume them (two register sets, fully
+        // unrolled): issued behind the MFMAs of the same step, each read's LDS latency (~100+ cycles) would
+        // open a bubble in the matrix pipe after every 4 MFMAs (256 cycles) -- measured 122 -> see DESIGN.md.
+        constexpr int KS = BK / 2 / WK;
+        float af[2][TM], bf[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * BM + i * 32];
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[wk * 2 * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Gb[ks * 2 * BN + j * 32];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Gb[wk * 2 * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) {
+                const int ks = (kk + 1) * WK + wk;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = Ab[ks * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = Gb[ks * 2 * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the reads above the MFMAs (the scheduler sinks them back)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
-#undef RN_WG_DMA
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* dwt = a.dw + (size_t)tap * a.Ca * a.Cg;
@@ -231,18 +263,20 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st)
     const long long tiles = (long long)taps * a.mtiles * a.ntiles;
     // enough workgroups to fill 256 CUs x 2 several times over, in multiples of 8 (one split residue
     // class per XCD), but never fewer than 4 stages of reduction per workgroup
-    long long ns = (3072 + tiles - 1) / tiles;
+    static const int target_wgs = getenv("RN_WGRAD_WGS") ? atoi(getenv("RN_WGRAD_WGS")) : 3072;
+    long long ns = (target_wgs + tiles - 1) / tiles;
     ns = (ns + 7) / 8 * 8;
     const long long max_ns = (a.M + 4LL * BK - 1) / (4LL * BK);
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
     long long kc = (a.M + ns - 1) / ns;
+    if (kc > WG_MAX_CHUNK) kc = WG_MAX_CHUNK;
     kc = (kc + BK - 1) / BK * BK;
     ns = (a.M + kc - 1) / kc;
     a.nsplit = (int)ns; a.kchunk = (int)kc;
     const long long nb = tiles * ns;
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: bad grid %lld", nb);
-    const size_t lds = (size_t)2 * BK * (BM + BN) * 4;
+    const size_t lds = (size_t)2 * BK * (BM + BN) * 4 + (size_t)WG_MAX_CHUNK * 4;
     auto kern = conv_wgrad_kernel<BM, BN, BK, WM, WN, WK>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -143,7 +143,10 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
     if (C % 4 == 0 && ((G <= 256 && 256 % G == 0) || G % 256 == 0)) {
         const int gy = G <= 256 ? 1 : G / 256;
         const int rstep = G < 256 ? 256 / G : 1;
-        long long rpb = ((long long)M + 4095) / 4096;                 // ~4096 row blocks
+        // ~512 row blocks: every block ends with 2*C same-address atomics, which the L2 serialises per
+        // cache line (~40 ns each) -- thousands of blocks made THAT the critical path (0.31 ms for a
+        // 300 MB stream); 2 blocks per CU with 4 rows in flight per thread still cover the HBM latency
+        long long rpb = ((long long)M + 511) / 512;
         rpb = (rpb + 4 * rstep - 1) / (4 * rstep) * (4 * rstep);       // whole 4-row unrolls
         if (rpb < 4 * rstep) rpb = 4 * rstep;
         a.rows_per_block = (int)rpb;
