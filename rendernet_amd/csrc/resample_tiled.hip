@@ -3,20 +3,27 @@
 // Same arithmetic, bit for bit, as resample.hip (clamp-then-weight trilinear sampling of
 // tools/resampling_voxel_grid.py:381-486, one rounding per op, add_n order), but organised around
 // what bounds this op on MI355X: it WRITES N^3 floats per item (201 MB at B=24) and that stream should
-// run at HBM speed, while >90 % of the output is exactly zero -- 7/8 of the 128^3 target grid lies
-// outside the 64^3 source (s=1), and most of the inside is empty space.  The naive kernel spends its
-// time on 8 divergent L1 gathers per output (~50 cycles per 64-lane gather instruction in the texture
-// addresser).  Here:
-//   pass 0 (resample_prepare_kernel, 25 MB read): per item the inverted 3x4 matrix and an occupancy
-//           bitmap of 4^3-voxel cells (one bit per cell, one 32-bit word per (cz,cy) row);
-//   pass 1 (resample_tiled_kernel): workgroup = an 8x8 (i,j) patch over the whole depth = N/8 tiles of 8x8x8.
-//     phase 1, per wave, no barrier: bounding box of each tile's pre-image (its 8 corners through the
-//       same coordinate arithmetic, +-1 voxel margin, clamped like the sampler clamps) -> occupancy
-//       rows tested with one LDS read + mask per lane -> if every cell is empty, every tap of every
-//       sample of the tile reads 0 and the outputs are exactly 0;
-//     then the workgroup zero-fills all empty wave tiles with 16-B stores, 128 B contiguous per 8 lanes;
-//     phase 2, only for non-empty wave tiles: the bounding box is staged into LDS with 16-B row loads
-//       and the 512 samples are evaluated with LDS gathers (2-cycle ds_read_b32) instead of L1 gathers.
+// run at HBM speed, while ~98 % of the output is exactly zero -- 7/8 of the 128^3 target grid lies
+// outside the 64^3 source (s=1), and most of the inside is empty space.  Two levels of culling keep the
+// trilinear arithmetic to the ~2 % of samples that can be non-zero, and the rest of the grid is a pure
+// 16-B-store stream.  Three launches:
+//   1 resample_prepare_kernel (25 MB read): per item the inverted 3x4 matrix, a voxel bitmap (one bit
+//     per voxel, 64-bit words along x) and a cell bitmap (one bit per 4^3-voxel cell, one 32-bit word per
+//     (cz,cy) row);
+//   2 resample_classify_kernel: one wave per 8x8 (i,j) column, eight of its 8^3 tiles per pass (8 lanes
+//     per tile: the corners of the tile go through the same coordinate arithmetic, +-1 voxel margin, clamped
+//     like the sampler clamps; the cell rows of that box are tested against the cell bitmap).  If every
+//     cell is empty, every tap of every sample reads 0 and the outputs are exactly 0.  Emits one bit mask
+//     per column and appends the candidate tiles (with their boxes) to a per-item work list;
+//   3 resample_main_kernel, a persistent grid in which every workgroup interleaves two streams of work,
+//     both strided over the grid:
+//       candidate tiles: the voxel-bitmap rows of the tile's box are staged in LDS (2 KiB) and every
+//         sample tests its own eight taps against them (exact: a sample whose taps are all zero IS zero);
+//         only if some sample of the tile can be non-zero is the float box staged (16-B row loads) and only
+//         those samples run the trilinear arithmetic, with LDS gathers;
+//       filling: while a tile's loads are in flight, a chunk of a (b,i) output row is zero-filled with 16-B
+//         stores (skipping the 32-B segments that belong to candidate tiles) -- stores need no waiting.
+// Measured history (B=24, five fixtures): one kernel per column 150 us -> this form, see DESIGN.md.
 #include "rn_common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -25,15 +32,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct TiledArgs {
-    const float* vox;      // [B,S,S,S,C]
-    const float* ws_mat;   // [B,12]
-    const unsigned* ws_occ;  // [B,NC,NC]
-    float* out;
-    int B, S, N, NC;
-    int h0, w0, ph, pw, image_layout;
-    int debug;             // development ablations: 1 = treat every tile as empty, 2 = skip the zero fill
-};
+constexpr int BRICK_FLOATS = 6144;     // 24 KiB: the pre-image box of an 8^3 tile at scale >= ~0.75
+constexpr int VROWS_MAX = 400;         // rows (z,y) of the voxel-bitmap box kept in LDS (20 x 20)
+constexpr int MAX_KT = 32;             // tiles per axis (N <= 256)
+constexpr int MAX_ITEMS = 512;         // batch items addressable by the per-item work lists
+constexpr int MAIN_WGS_PER_CU = 5;     // LDS-bound (24 KiB brick + 5 KiB of tables per workgroup)
+constexpr int FILL_CHUNK = 512;        // 16-B units zero-filled at each of a tile's two load latencies
+constexpr int CNT_STRIDE = 32;         // per-item counters live 128 B apart (no same-line atomic serialisation)
 
 __device__ __forceinline__ void pose_to_affine_t(const float* pose, int S, int N, float* m)
 {
@@ -52,38 +57,57 @@ __device__ __forceinline__ void pose_to_affine_t(const float* pose, int S, int N
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1. prepare.  One thread per (z,y) source row; 16 consecutive lanes = the 4x4 rows of one cell row
+//    (cz,cy), so the cell bitmap word is an OR over xor-shuffles.  grid = (S*S/256, B).
+//    ws_vbit [B][S][S][VW] u32 (VW = max(1, S/32)): bit x of row (z,y) = voxel (z,y,x) has a non-zero channel
+//    ws_occ  [B][NC][NC]   u32: bit cx of row (cz,cy) = cell has a non-zero voxel
+// ------------------------------------------------------------------------------------------------
 template <int CT, bool FROM_POSE>
 __global__ __launch_bounds__(256)
 void resample_prepare_kernel(const float* __restrict__ vox, const float* __restrict__ mat_or_pose,
-                             float* __restrict__ ws_mat, unsigned* __restrict__ ws_occ, int S, int N, int NC)
+                             float* __restrict__ ws_mat, unsigned* __restrict__ ws_occ, unsigned* __restrict__ ws_vbit,
+                             unsigned* __restrict__ ws_count, int S, int N, int NC)
 {
     const int b = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    const int ncell = NC * NC * NC;
-    bool any = false;
-    int cx = 0, cy = 0, cz = 0;
-    if (e < ncell) {
-        cx = e % NC; cy = (e / NC) % NC; cz = e / (NC * NC);
-        const float* base = vox + ((size_t)b * S * S * S + ((size_t)(cz * 4) * S + cy * 4) * S + cx * 4) * CT;
-#pragma unroll
-        for (int z = 0; z < 4; ++z)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                const float4* p = reinterpret_cast<const float4*>(base + ((size_t)z * S + y) * S * CT);
-#pragma unroll
-                for (int q = 0; q < CT; ++q) {
-                    const float4 v = p[q];
-                    any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    const int VW = S >= 32 ? S >> 5 : 1;
+    // e -> (cz, cy, zl, yl): the low 4 bits pick the row inside the cell row
+    const int yl = e & 3, zl = (e >> 2) & 3, cy = (e >> 4) % NC, cz = (e >> 4) / NC;
+    const bool live = cz < NC;
+    const int z = cz * 4 + zl, y = cy * 4 + yl;
+    unsigned cellbits = 0;
+    if (live) {
+        const float4* p = reinterpret_cast<const float4*>(vox + (((size_t)b * S + z) * S + y) * S * CT);
+        unsigned* vrow = ws_vbit + (((size_t)b * S + z) * S + y) * VW;
+        for (int w = 0; w < VW; ++w) {
+            unsigned bits = 0;
+            const int nx = S < 32 ? S : 32;
+            if (CT == 1) {
+                for (int q = 0; q < nx / 4; ++q) {
+                    const float4 v = p[w * 8 + q];
+                    bits |= ((v.x != 0.f) ? 1u : 0u) << (4 * q) | ((v.y != 0.f) ? 2u : 0u) << (4 * q) |
+                            ((v.z != 0.f) ? 4u : 0u) << (4 * q) | ((v.w != 0.f) ? 8u : 0u) << (4 * q);
+                }
+            } else {
+                for (int q = 0; q < nx; ++q) {
+                    const float4 v = p[w * 32 + q];
+                    bits |= (((v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f)) ? 1u : 0u) << q;
                 }
             }
+            vrow[w] = bits;
+            // nibble-any: bit cx (of this 32-voxel word: cx = 8*w + n)
+            for (int n = 0; n < nx / 4; ++n)
+                cellbits |= (((bits >> (4 * n)) & 15u) ? 1u : 0u) << (8 * w + n);
+        }
     }
-    const unsigned long long bal = __ballot(any);
-    const int lane = threadIdx.x & 63;
-    if (e < ncell && (lane % NC) == 0) {
-        const unsigned mask = NC == 32 ? 0xffffffffu : ((1u << NC) - 1u);
-        ws_occ[((size_t)b * NC + cz) * NC + cy] = (unsigned)(bal >> lane) & mask;
-    }
+    cellbits |= __shfl_xor(cellbits, 1);
+    cellbits |= __shfl_xor(cellbits, 2);
+    cellbits |= __shfl_xor(cellbits, 4);
+    cellbits |= __shfl_xor(cellbits, 8);
+    if (live && (threadIdx.x & 15) == 0) ws_occ[((size_t)b * NC + cz) * NC + cy] = cellbits;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ws_count[(size_t)b * CNT_STRIDE] = 0u;                   // this item's tile list starts empty
         if (FROM_POSE) pose_to_affine_t(mat_or_pose + 3 * b, S, N, ws_mat + 12 * b);
         else for (int q = 0; q < 12; ++q) ws_mat[12 * b + q] = mat_or_pose[12 * b + q];
     }
@@ -94,19 +118,27 @@ __device__ __forceinline__ float coord_t(float m0, float m1, float m2, float m3,
     return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m0, x), __fmul_rn(m1, y)), __fmul_rn(m2, z)), m3);
 }
 
-// One sample; LD(zi, yi, xi, c) fetches a source value (global or LDS brick).
-template <int CT, class LD>
-__device__ __forceinline__ void sample_ld(int S, float x, float y, float z, const LD& ld, float* __restrict__ o)
+// clamped tap indices of one sample (tools/resampling_voxel_grid.py:410-422)
+struct Taps { int x0, x1, y0, y1, z0, z1; };
+__device__ __forceinline__ Taps sample_taps(int S, float x, float y, float z)
 {
     const int mx = S - 1;
-    int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
-    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
-    x0 = min(max(x0, 0), mx); x1 = min(max(x1, 0), mx);
-    y0 = min(max(y0, 0), mx); y1 = min(max(y1, 0), mx);
-    z0 = min(max(z0, 0), mx); z1 = min(max(z1, 0), mx);
-    const float ax = __fsub_rn((float)x1, x), bx = __fsub_rn(x, (float)x0);
-    const float ay = __fsub_rn((float)y1, y), by = __fsub_rn(y, (float)y0);
-    const float az = __fsub_rn((float)z1, z), bz = __fsub_rn(z, (float)z0);
+    Taps t;
+    t.x0 = (int)floorf(x); t.y0 = (int)floorf(y); t.z0 = (int)floorf(z);
+    t.x1 = t.x0 + 1; t.y1 = t.y0 + 1; t.z1 = t.z0 + 1;
+    t.x0 = min(max(t.x0, 0), mx); t.x1 = min(max(t.x1, 0), mx);
+    t.y0 = min(max(t.y0, 0), mx); t.y1 = min(max(t.y1, 0), mx);
+    t.z0 = min(max(t.z0, 0), mx); t.z1 = min(max(t.z1, 0), mx);
+    return t;
+}
+
+// weights from the clamped indices and the add_n of the eight products (:465-485); LD(zi, yi, xi, c)
+template <int CT, class LD>
+__device__ __forceinline__ void sample_eval(const Taps& t, float x, float y, float z, const LD& ld, float* __restrict__ o)
+{
+    const float ax = __fsub_rn((float)t.x1, x), bx = __fsub_rn(x, (float)t.x0);
+    const float ay = __fsub_rn((float)t.y1, y), by = __fsub_rn(y, (float)t.y0);
+    const float az = __fsub_rn((float)t.z1, z), bz = __fsub_rn(z, (float)t.z0);
     const float wa = __fmul_rn(__fmul_rn(ax, ay), az);
     const float wb = __fmul_rn(__fmul_rn(ax, by), az);
     const float wc = __fmul_rn(__fmul_rn(bx, ay), az);
@@ -117,59 +149,71 @@ __device__ __forceinline__ void sample_ld(int S, float x, float y, float z, cons
     const float wh = __fmul_rn(__fmul_rn(bx, by), bz);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        float v = __fmul_rn(wa, ld(z0, y0, x0, c));
-        v = __fadd_rn(v, __fmul_rn(wb, ld(z0, y1, x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wc, ld(z0, y0, x1, c)));
-        v = __fadd_rn(v, __fmul_rn(wd, ld(z0, y1, x1, c)));
-        v = __fadd_rn(v, __fmul_rn(we, ld(z1, y0, x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wf, ld(z1, y1, x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wg, ld(z1, y0, x1, c)));
-        v = __fadd_rn(v, __fmul_rn(wh, ld(z1, y1, x1, c)));
+        float v = __fmul_rn(wa, ld(t.z0, t.y0, t.x0, c));
+        v = __fadd_rn(v, __fmul_rn(wb, ld(t.z0, t.y1, t.x0, c)));
+        v = __fadd_rn(v, __fmul_rn(wc, ld(t.z0, t.y0, t.x1, c)));
+        v = __fadd_rn(v, __fmul_rn(wd, ld(t.z0, t.y1, t.x1, c)));
+        v = __fadd_rn(v, __fmul_rn(we, ld(t.z1, t.y0, t.x0, c)));
+        v = __fadd_rn(v, __fmul_rn(wf, ld(t.z1, t.y1, t.x0, c)));
+        v = __fadd_rn(v, __fmul_rn(wg, ld(t.z1, t.y0, t.x1, c)));
+        v = __fadd_rn(v, __fmul_rn(wh, ld(t.z1, t.y1, t.x1, c)));
         o[c] = v;
     }
 }
 
-constexpr int BRICK_FLOATS = 6144;     // 24 KiB: the pre-image box of an 8^3 tile at scale >= ~0.75
-constexpr int MAX_KT = 32;             // wave tiles along the depth axis (N <= 256)
+struct TiledArgs {
+    const float* vox;        // [B,S,S,S,C]
+    const float* ws_mat;     // [B,12]
+    const unsigned* ws_occ;  // [B,NC,NC]
+    const unsigned* ws_vbit; // [B,S,S,VW]
+    unsigned* ws_count;      // [B*CNT_STRIDE]  per-item count of candidate tiles
+    unsigned* ws_colmask;    // [B, ph/8, pw/8]  bit kt = tile (column, kt) is a candidate
+    uint4* ws_list;          // [B][ph/8 * pw/8 * N/8] {packed (ti,tj,kt), bx0|bx1<<8|by0<<16|by1<<24, bz0|bz1<<8, -}
+    float* out;
+    int B, S, N, NC;
+    int h0, w0, ph, pw, image_layout;
+    int debug;               // development ablations: 1 = treat every tile as empty, 2 = skip the zero fill,
+                             // 3 = no per-sample test (every sample of a candidate tile is evaluated)
+    int nwg;                 // workgroups of the main launch
+    int list_stride;         // records per item
+};
 
-// Workgroup = one (i,j) 8x8 patch over the FULL depth N: N/8 wave tiles of 8x8x8 samples.
-template <int CT>
+// ------------------------------------------------------------------------------------------------
+// 2. classify.  One wave per (b, ti, tj) column; lane = (g = tile of the pass, c = corner / cell row).
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void resample_tiled_kernel(const TiledArgs a)
+void resample_classify_kernel(const TiledArgs a)
 {
-    __shared__ float msh[12];
-    __shared__ unsigned occ[1024];
-    __shared__ int tinfo[MAX_KT][8];     // per wave tile: {nonzero, bx0, bx1, by0, by1, bz0, bz1, -}
-    __shared__ __attribute__((aligned(16))) float brick[BRICK_FLOATS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = a.N, S = a.S, NC = a.NC;
-    const int nkt = N >> 3;
-    int t = blockIdx.x;
-    const int ntj = a.pw >> 3, nti = a.ph >> 3;
-    const int tj = t % ntj; t /= ntj;
-    const int ti = t % nti; const int b = t / nti;
-
-    for (int i = tid; i < NC * NC; i += 256) occ[i] = a.ws_occ[(size_t)b * NC * NC + i];
-    if (tid < 12) msh[tid] = a.ws_mat[12 * b + tid];
-    __syncthreads();
-    const float m00 = msh[0], m01 = msh[1], m02 = msh[2], m03 = msh[3];
-    const float m10 = msh[4], m11 = msh[5], m12 = msh[6], m13 = msh[7];
-    const float m20 = msh[8], m21 = msh[9], m22 = msh[10], m23 = msh[11];
-
-    const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8;      // grid coordinates of the patch origin
-    // ---------------- phase 1: each wave classifies its share of the 8x8x8 tiles ----------------
-    for (int kt = wave; kt < nkt; kt += 4) {
-        const int k0 = kt * 8;
-        const int ci = lane & 1, cj = (lane >> 1) & 1, ck = (lane >> 2) & 1;
-        const int i = i0 + 7 * ci, j = j0 + 7 * cj, k = k0 + 7 * ck;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nti = a.ph >> 3, ntj = a.pw >> 3, nkt = a.N >> 3;
+    const long long col = (long long)blockIdx.x * 4 + wave;
+    if (col >= (long long)a.B * nti * ntj) return;
+    const int tj = (int)(col % ntj), ti = (int)((col / ntj) % nti), b = (int)(col / ((long long)ntj * nti));
+    float m[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[12 * b + q];
+    const unsigned* occ = a.ws_occ + (size_t)b * a.NC * a.NC;
+    const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8;
+    const int g = lane >> 3, c = lane & 7;
+    const int N = a.N, S = a.S;
+    unsigned mask = 0;
+    unsigned rec_xy[MAX_KT / 8], rec_z[MAX_KT / 8];      // lanes with c == 0 keep the box of tile pass*8+g
+    const int npass = (nkt + 7) >> 3;
+#pragma unroll
+    for (int pass = 0; pass < MAX_KT / 8; ++pass) {
+        rec_xy[pass] = 0; rec_z[pass] = 0;
+        if (pass >= npass) continue;
+        const int kt = pass * 8 + g;
+        // corner c of tile kt through the sampler's own coordinate arithmetic
+        const int ci = c & 1, cj = (c >> 1) & 1, ck = (c >> 2) & 1;
+        const int i = i0 + 7 * ci, j = j0 + 7 * cj, k = kt * 8 + 7 * ck;
         const float gx = (float)k;
         const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
         const float gz = a.image_layout ? (float)j : (float)i;
         float lo[3], hi[3];
-        lo[0] = hi[0] = coord_t(m00, m01, m02, m03, gx, gy, gz);
-        lo[1] = hi[1] = coord_t(m10, m11, m12, m13, gx, gy, gz);
-        lo[2] = hi[2] = coord_t(m20, m21, m22, m23, gx, gy, gz);
+        lo[0] = hi[0] = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
+        lo[1] = hi[1] = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
+        lo[2] = hi[2] = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -189,59 +233,185 @@ void resample_tiled_kernel(const TiledArgs a)
         const int cx0 = b0[0] >> 2, cx1 = b1[0] >> 2;
         const int cy0 = b0[1] >> 2, ncy = (b1[1] >> 2) - cy0 + 1;
         const int cz0 = b0[2] >> 2, ncz = (b1[2] >> 2) - cz0 + 1;
-        const int cyl = lane & 7, czl = lane >> 3;
+        // lane c owns cell row cy0 + c and walks the cz of the box (independent loads)
         bool hit = false;
-        if (cyl < ncy && czl < ncz) {
-            const unsigned row = occ[(cz0 + czl) * NC + cy0 + cyl];
+        if (kt < nkt && c < ncy) {
             const unsigned mhi = cx1 >= 31 ? 0xffffffffu : ((1u << (cx1 + 1)) - 1u);
             const unsigned mlo = (1u << cx0) - 1u;
-            hit = (row & mhi & ~mlo) != 0u;
+            unsigned acc = 0;
+            for (int zz = 0; zz < ncz; ++zz) acc |= occ[(cz0 + zz) * a.NC + cy0 + c];
+            hit = (acc & mhi & ~mlo) != 0u;
         }
-        bool nz = __ballot(hit) != 0ull;
-        if (ncy > 8 || ncz > 8) nz = true;
-        if (a.debug == 1) nz = false;                 // box wider than the 8x8 row test: be conservative
-        if (lane == 0) {
-            tinfo[kt][0] = nz ? 1 : 0;
-            tinfo[kt][1] = b0[0]; tinfo[kt][2] = b1[0];
-            tinfo[kt][3] = b0[1]; tinfo[kt][4] = b1[1];
-            tinfo[kt][5] = b0[2]; tinfo[kt][6] = b1[2];
-        }
+        if (kt < nkt && ncy > 8) hit = true;             // box wider than 8 cell rows: be conservative
+        const unsigned long long bal = __ballot(hit);
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bits |= (((bal >> (8 * q)) & 0xffull) ? 1u : 0u) << q;
+        if (a.debug == 1) bits = 0;
+        mask |= bits << (pass * 8);
+        rec_xy[pass] = (unsigned)b0[0] | ((unsigned)b1[0] << 8) | ((unsigned)b0[1] << 16) | ((unsigned)b1[1] << 24);
+        rec_z[pass] = (unsigned)b0[2] | ((unsigned)b1[2] << 8);
     }
-    __syncthreads();
-
-    // ---------------- zero fill of the empty tiles: 16 B per lane, whole 128-B lines per 8 lanes --------
-    const size_t patch_base = (((size_t)b * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
-    {
-        const int per_line = (CT == 1) ? (N >> 2) : N;       // 16-B units per (i,j) depth line
-        const int total = 64 * per_line;
-        for (int f = tid; f < total; f += 256) {
-            const int ij = f / per_line, u = f - ij * per_line;
-            const int kt = (CT == 1) ? (u >> 1) : (u >> 3);
-            if (!tinfo[kt][0] && a.debug != 2) {
-                float* op = a.out + (patch_base + ((size_t)(ij >> 3) * a.pw + (ij & 7)) * N) * CT + (size_t)u * 4;
-                *reinterpret_cast<float4*>(op) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = __popc(mask);
+    unsigned base = 0;
+    if (lane == 0) {
+        a.ws_colmask[col] = mask;
+        if (n) base = atomicAdd(a.ws_count + (size_t)b * CNT_STRIDE, (unsigned)n);
+    }
+    base = __shfl(base, 0);
+    if (c == 0) {
+#pragma unroll
+        for (int pass = 0; pass < MAX_KT / 8; ++pass) {
+            const int kt = pass * 8 + g;
+            if (pass < npass && ((mask >> kt) & 1u)) {
+                const int rank = __popc(mask & ((1u << kt) - 1u));
+                const unsigned desc = ((unsigned)ti << 10) | ((unsigned)tj << 5) | (unsigned)kt;
+                a.ws_list[(size_t)b * a.list_stride + base + rank] = make_uint4(desc, rec_xy[pass], rec_z[pass], 0u);
             }
         }
     }
+}
 
-    // ---------------- phase 2: non-empty tiles, source bounding box staged in LDS ----------------
-    const float* vb = a.vox + (size_t)b * S * S * S * CT;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (!tinfo[kt][0]) continue;                        // uniform
-        const int bx0 = tinfo[kt][1], bx1 = tinfo[kt][2], by0 = tinfo[kt][3], by1 = tinfo[kt][4];
-        const int bz0 = tinfo[kt][5], bz1 = tinfo[kt][6];
+// ------------------------------------------------------------------------------------------------
+// 3. main
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256)
+void resample_main_kernel(const TiledArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float brick[BRICK_FLOATS];
+    __shared__ uint2 vrows[VROWS_MAX];
+    __shared__ unsigned rowmask[MAX_KT];
+    __shared__ unsigned prefix[MAX_ITEMS + 1];
+    const int tid = threadIdx.x;
+    const int N = a.N, S = a.S;
+    const int G = a.nwg;
+    const int VW = S >= 32 ? S >> 5 : 1;
+
+    // exclusive prefix of the per-item tile counts (B is small: serial scan by one thread)
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int b = 0; b < a.B; ++b) { prefix[b] = acc; acc += a.ws_count[(size_t)b * CNT_STRIDE]; }
+        prefix[a.B] = acc;
+    }
+    __syncthreads();
+    const unsigned count = prefix[a.B];
+
+    // fill stream state: rows f = blockIdx.x, +G, ...; FILL_CHUNK units at a time
+    const int per_line = (CT == 1) ? (N >> 2) : N;        // 16-B units per (i,j) depth line
+    const int row_units = a.pw * per_line;
+    const long long nrows = (a.debug == 2) ? 0 : (long long)a.B * a.ph;
+    long long frow = blockIdx.x;
+    int fpos = 0;
+    bool fmask_ready = false;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fill_chunk = [&]() {
+        if (frow >= nrows) return;
+        const int il = (int)(frow % a.ph);
+        const long long b = frow / a.ph;
+        if (!fmask_ready) {
+            const int ntj = a.pw >> 3;
+            if (tid < ntj) rowmask[tid] = a.ws_colmask[((size_t)b * (a.ph >> 3) + (il >> 3)) * ntj + tid];
+            __syncthreads();
+            fmask_ready = true;
+        }
+        float4* op = reinterpret_cast<float4*>(a.out + (size_t)frow * a.pw * N * CT);
+        const int uend = min(fpos + FILL_CHUNK, row_units);
+        for (int u = fpos + tid; u < uend; u += 256) {
+            const int j = u / per_line, w = u - j * per_line;
+            const int kt = (CT == 1) ? (w >> 1) : (w >> 3);
+            if (!((rowmask[j >> 3] >> kt) & 1u)) op[u] = z4;
+        }
+        fpos = uend;
+        if (fpos >= row_units) {
+            fpos = 0; frow += G; fmask_ready = false;
+            __syncthreads();                               // rowmask is rewritten for the next row
+        }
+    };
+    // global tile index -> (item, record)
+    auto fetch = [&](unsigned t, int& b) -> uint4 {
+        int lo = 0, hi = a.B;                              // largest b with prefix[b] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
+        b = lo;
+        return a.ws_list[(size_t)lo * a.list_stride + (t - prefix[lo])];
+    };
+
+    unsigned t = blockIdx.x;
+    int b = 0, bn = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (t < count) rec = fetch(t, b);
+    while (t < count) {
+        const unsigned desc = rec.x;
+        const int kt = desc & 31, tj = (desc >> 5) & 31, ti = (desc >> 10) & 31;
+        const int bx0 = rec.y & 255, bx1 = (rec.y >> 8) & 255, by0 = (rec.y >> 16) & 255, by1 = rec.y >> 24;
+        const int bz0 = rec.z & 255, bz1 = (rec.z >> 8) & 255;
+        const int bcur = b;
+        const unsigned tn = t + G;
+        if (tn < count) rec = fetch(tn, bn);                  // next record: in flight during this tile
         const int ny = by1 - by0 + 1, nzz = bz1 - bz0 + 1, rows = ny * nzz;
+
+        // ---- level 2: the voxel-bitmap rows of the box; 64-bit window starting at word xw0 ----
+        const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
+        const bool vtest = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && a.debug != 3;
+        uint2 myv = make_uint2(0u, 0u);
+        const float rny = 1.0f / (float)ny;
+        if (vtest) {
+            for (int r = tid; r < rows; r += 256) {            // at most 2 iterations
+                const int z = (int)(((float)r + 0.5f) * rny), y = r - z * ny;
+                const unsigned* vr = a.ws_vbit + (((size_t)bcur * S + bz0 + z) * S + by0 + y) * VW + xw0;
+                const uint2 w2 = make_uint2(vr[0], (xw0 + 1 < VW) ? vr[1] : 0u);
+                if (r < 256) myv = w2;
+                else vrows[r] = w2;                            // second iteration (rare): straight to LDS
+            }
+        }
+        float m[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[12 * bcur + q];
+        fill_chunk();                                          // stores only: the loads above stay in flight
+        if (vtest && tid < rows) vrows[tid] = myv;
+        __syncthreads();
+
+        const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8, k0 = kt * 8;
+        float xs[2], ys[2], zs[2];
+        Taps tp[2];
+        bool hit[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q;
+            const int kl = p & 7, jl = (p >> 3) & 7, il = p >> 6;
+            const int i = i0 + il, j = j0 + jl, k = k0 + kl;
+            const float gx = (float)k;
+            const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
+            const float gz = a.image_layout ? (float)j : (float)i;
+            xs[q] = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
+            ys[q] = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
+            zs[q] = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
+            tp[q] = sample_taps(S, xs[q], ys[q], zs[q]);
+            hit[q] = true;
+            if (vtest) {
+                // a sample whose eight taps are all zero is exactly zero
+                const int r00 = (tp[q].z0 - bz0) * ny + (tp[q].y0 - by0), r01 = (tp[q].z0 - bz0) * ny + (tp[q].y1 - by0);
+                const int r10 = (tp[q].z1 - bz0) * ny + (tp[q].y0 - by0), r11 = (tp[q].z1 - bz0) * ny + (tp[q].y1 - by0);
+                const uint2 w00 = vrows[r00], w01 = vrows[r01], w10 = vrows[r10], w11 = vrows[r11];
+                const unsigned long long w = ((unsigned long long)(w00.y | w01.y | w10.y | w11.y) << 32) |
+                                             (unsigned long long)(w00.x | w01.x | w10.x | w11.x);
+                const unsigned long long sel = (1ull << (tp[q].x0 - xw0 * 32)) | (1ull << (tp[q].x1 - xw0 * 32));
+                hit[q] = (w & sel) != 0ull;
+            }
+        }
+        const int any = __syncthreads_or((hit[0] || hit[1]) ? 1 : 0);
+
+        const float* vb = a.vox + (size_t)bcur * S * S * S * CT;
         const int xo = (CT == 1) ? (bx0 & ~3) : bx0;                       // x origin of the brick (voxels)
         const int U = (CT == 1) ? ((bx1 - xo) >> 2) + 1 : bx1 - bx0 + 1;   // 16-B units per row
         const int rstride = U * 4;                                         // floats per brick row
         const bool staged = rows * rstride <= BRICK_FLOATS;
-        if (staged) {
-            // all of a thread's 16-B units are requested before the first one is written to LDS (one
-            // L2 round trip per tile, not one per row); unit -> (row, u) and row -> (z, y) by exact
-            // float reciprocals (indices < 2^20)
+        if (any && staged) {
+            // all of a thread's 16-B units are requested before the first one is used (one L2 round trip per
+            // tile); unit -> (row, u) and row -> (z, y) by exact float reciprocals (indices < 2^20)
             constexpr int UPT = (BRICK_FLOATS / 4 + 255) / 256;
             const int units = rows * U;
-            const float rU = 1.0f / (float)U, rny = 1.0f / (float)ny;
+            const float rU = 1.0f / (float)U;
             f32x4 v[UPT];
 #pragma unroll
             for (int q = 0; q < UPT; ++q) {
@@ -254,43 +424,43 @@ void resample_tiled_kernel(const TiledArgs a)
                     v[q] = *reinterpret_cast<const f32x4*>(vb + (((size_t)(bz0 + z) * S + by0 + y) * S + xo) * CT + u * 4);
                 }
             }
+            fill_chunk();
 #pragma unroll
             for (int q = 0; q < UPT; ++q) {
                 const int idx = tid + 256 * q;
                 if (idx < units) *reinterpret_cast<f32x4*>(brick + idx * 4) = v[q];
             }
+            __syncthreads();
         }
-        __syncthreads();
-        const int k0 = kt * 8;
+        const size_t patch_base = (((size_t)bcur * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
             const int kl = p & 7, jl = (p >> 3) & 7, il = p >> 6;
-            const int i = i0 + il, j = j0 + jl, k = k0 + kl;
-            const float gx = (float)k;
-            const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
-            const float gz = a.image_layout ? (float)j : (float)i;
-            const float xs = coord_t(m00, m01, m02, m03, gx, gy, gz);
-            const float ys = coord_t(m10, m11, m12, m13, gx, gy, gz);
-            const float zs = coord_t(m20, m21, m22, m23, gx, gy, gz);
             float r[CT];
-            if (staged) {
-                auto ld = [&](int zi, int yi, int xi, int c) -> float {
-                    return brick[((zi - bz0) * ny + (yi - by0)) * rstride + (xi - xo) * CT + c];
-                };
-                sample_ld<CT>(S, xs, ys, zs, ld, r);
-            } else {
-                auto ld = [&](int zi, int yi, int xi, int c) -> float {
-                    return vb[(((size_t)zi * S + yi) * S + xi) * CT + c];
-                };
-                sample_ld<CT>(S, xs, ys, zs, ld, r);
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) r[cc] = 0.f;
+            if (hit[q]) {
+                if (staged) {
+                    auto ld = [&](int zi, int yi, int xi, int cc) -> float {
+                        return brick[((zi - bz0) * ny + (yi - by0)) * rstride + (xi - xo) * CT + cc];
+                    };
+                    sample_eval<CT>(tp[q], xs[q], ys[q], zs[q], ld, r);
+                } else {
+                    auto ld = [&](int zi, int yi, int xi, int cc) -> float {
+                        return vb[(((size_t)zi * S + yi) * S + xi) * CT + cc];
+                    };
+                    sample_eval<CT>(tp[q], xs[q], ys[q], zs[q], ld, r);
+                }
             }
-            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + k) * CT;
+            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + k0 + kl) * CT;
             if (CT == 1) op[0] = r[0];
             else *reinterpret_cast<float4*>(op) = make_float4(r[0], r[CT > 1 ? 1 : 0], r[CT > 2 ? 2 : 0], r[CT > 3 ? 3 : 0]);
         }
-        __syncthreads();
+        __syncthreads();                                       // brick / vrows are rewritten by the next tile
+        t = tn; b = bn;
     }
+    while (frow < nrows) fill_chunk();                         // whatever is left of the fill stream
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -299,13 +469,31 @@ bool rn_resample_tiled_supported(int B, int S, int N, int C, int ph, int pw)
     if (C != 1 && C != 4) return false;
     if (S != 16 && S != 32 && S != 64 && S != 128) return false;
     if (N % 8 != 0 || N > 8 * MAX_KT || N < 16 || ph % 8 != 0 || pw % 8 != 0) return false;
+    if (B > MAX_ITEMS) return false;
     return true;
+}
+
+// [B,12] matrices | [B,NC,NC] cell bitmap | [B,S,S,VW] voxel bitmap | [B*32] counters | [B,32,32] column masks |
+// [B,32,32,32] tile records (16 B each; sized for the largest supported grid, N = 256: the entry point does not
+// know N)
+static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_cnt, size_t* o_mask, size_t* o_list)
+{
+    const int NC = S / 4, VW = S >= 32 ? S / 32 : 1;
+    size_t off = (size_t)B * 12 * sizeof(float);
+    *o_occ = off;  off += (size_t)B * NC * NC * sizeof(unsigned);
+    *o_vbit = off; off += (size_t)B * S * S * VW * sizeof(unsigned);
+    off = (off + 127) & ~(size_t)127;
+    *o_cnt = off;  off += (size_t)B * CNT_STRIDE * sizeof(unsigned);
+    *o_mask = off; off += (size_t)B * MAX_KT * MAX_KT * sizeof(unsigned);
+    off = (off + 15) & ~(size_t)15;
+    *o_list = off; off += (size_t)B * MAX_KT * MAX_KT * MAX_KT * sizeof(uint4);
+    return off;
 }
 
 size_t rn_resample_tiled_workspace(int B, int S)
 {
-    const int NC = S / 4;
-    return (size_t)B * (12 * sizeof(float) + (size_t)NC * NC * sizeof(unsigned));
+    size_t a, b, c, d, e;
+    return ws_layout(B, S, &a, &b, &c, &d, &e) + 128;       // slack: the caller's buffer may be 16-B aligned only
 }
 
 int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool from_pose, float* out,
@@ -313,23 +501,43 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
                              void* workspace, hipStream_t st)
 {
     const int NC = S / 4;
-    float* ws_mat = reinterpret_cast<float*>(workspace);
-    unsigned* ws_occ = reinterpret_cast<unsigned*>(ws_mat + (size_t)B * 12);
-    dim3 pgrid((NC * NC * NC + 255) / 256, B);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 127) & ~(uintptr_t)127);
+    size_t o_occ, o_vbit, o_cnt, o_mask, o_list;
+    ws_layout(B, S, &o_occ, &o_vbit, &o_cnt, &o_mask, &o_list);
+    float* ws_mat = reinterpret_cast<float*>(ws);
+    unsigned* ws_occ = reinterpret_cast<unsigned*>(ws + o_occ);
+    unsigned* ws_vbit = reinterpret_cast<unsigned*>(ws + o_vbit);
+    unsigned* ws_count = reinterpret_cast<unsigned*>(ws + o_cnt);
+    unsigned* ws_colmask = reinterpret_cast<unsigned*>(ws + o_mask);
+    uint4* ws_list = reinterpret_cast<uint4*>(ws + o_list);
+    dim3 pgrid((NC * NC * 16 + 255) / 256, B);
     if (C == 1) {
-        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, S, N, NC);
-        else hipLaunchKernelGGL((resample_prepare_kernel<1, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, S, N, NC);
+        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
+        else hipLaunchKernelGGL((resample_prepare_kernel<1, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
     } else {
-        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<4, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, S, N, NC);
-        else hipLaunchKernelGGL((resample_prepare_kernel<4, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, S, N, NC);
+        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<4, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
+        else hipLaunchKernelGGL((resample_prepare_kernel<4, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
     }
     int rc = rn_check_launch("resample_prepare");
     if (rc != RN_OK) return rc;
     static const int dbg = getenv("RN_RS_DEBUG") ? atoi(getenv("RN_RS_DEBUG")) : 0;
-    TiledArgs a{vox, ws_mat, ws_occ, out, B, S, N, NC, h0, w0, ph, pw, image_layout, dbg};
-    const long long nb = (long long)B * (ph / 8) * (pw / 8);
-    if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
-    if (C == 1) hipLaunchKernelGGL(resample_tiled_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(resample_tiled_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, a);
-    return rn_check_launch("resample_tiled");
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long long ncol = (long long)B * (ph / 8) * (pw / 8);
+    const long long nfill = (long long)B * ph;
+    long long nwg = (long long)ncu * MAIN_WGS_PER_CU;
+    if (nwg > nfill) nwg = nfill;                           // tiny problems: one workgroup per output row
+    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_count, ws_colmask, ws_list, out, B, S, N, NC, h0, w0, ph, pw,
+                image_layout, dbg, (int)nwg, MAX_KT * MAX_KT * MAX_KT};
+    if (ncol > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
+    hipLaunchKernelGGL(resample_classify_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, st, a);
+    rc = rn_check_launch("resample_classify");
+    if (rc != RN_OK) return rc;
+    if (C == 1) hipLaunchKernelGGL(resample_main_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(resample_main_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, a);
+    return rn_check_launch("resample_main");
 }
