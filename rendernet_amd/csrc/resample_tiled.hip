@@ -5,40 +5,26 @@
 // what bounds this op on MI355X: it WRITES N^3 floats per item (201 MB at B=24) and that stream should
 // run at HBM speed, while ~98 % of the output is exactly zero -- 7/8 of the 128^3 target grid lies
 // outside the 64^3 source (s=1), and most of the inside is empty space.  Two levels of culling keep the
-// trilinear arithmetic to the ~2 % of samples that can be non-zero, and the rest of the grid is a pure
+// trilinear arithmetic to the ~4 % of samples that can be non-zero, and the rest of the grid is a pure
 // 16-B-store stream.  Three launches:
 //   1 resample_prepare_kernel (25 MB read): per item the inverted 3x4 matrix, a voxel bitmap (one bit
-//     per voxel, 64-bit words along x) and a cell bitmap (one bit per 4^3-voxel cell, one 32-bit word per
-//     (cz,cy) row);
-//   2 resample_classify_kernel: one wave per 8x8 (i,j) column, eight of its 8^3 tiles per pass (8 lanes
-//     per tile: the corners of the tile go through the same coordinate arithmetic, +-1 voxel margin, clamped
-//     like the sampler clamps; the cell rows of that box are tested against the cell bitmap).  If every
-//     cell is empty, every tap of every sample reads 0 and the outputs are exactly 0.  Emits one bit mask
-//     per column and appends the candidate tiles (with their boxes) to a per-item work list;
-//   3 resample_main_kernel, a persistent grid in which every workgroup interleaves two streams of work,
-//     both strided over the grid:
-//       candidate tiles: the voxel-bitmap rows of the tile's box are staged in LDS (2 KiB) and every
-//         sample tests its own eight taps against them (exact: a sample whose taps are all zero IS zero);
-//         only if some sample of the tile can be non-zero is the float box staged (16-B row loads) and only
-//         those samples run the trilinear arithmetic, with LDS gathers;
-//       filling: while a tile's loads are in flight, a chunk of a (b,i) output row is zero-filled with 16-B
-//         stores (skipping the 32-B segments that belong to candidate tiles) -- stores need no waiting.
-// Measured history (B=24, five fixtures): one kernel per column 150 us -> this form, see DESIGN.md.
+//     per voxel, 64-bit words along x), a cell bitmap (one bit per 4^3-voxel cell, one 32-bit word per
+//     (cz,cy) row) and a flag telling whether the item is an occupancy grid (values in {0,1});
+//   2 resample_classify_kernel: one bit per 8^3 output tile -- can it hold a non-zero sample?
+//   3 resample_main_kernel: zero-fill workgroups and sampler workgroups interleaved in one launch.
+// Measured history (B=24, five fixtures): see DESIGN.md.
 #include "rn_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BRICK_FLOATS = 6144;     // 24 KiB: the pre-image box of an 8^3 tile at scale >= ~0.75
-constexpr int VROWS_MAX = 400;         // rows (z,y) of the voxel-bitmap box kept in LDS (20 x 20)
+constexpr int VROWS_MAX = 512;         // rows (z,y) of the voxel-bitmap box kept in LDS (two per thread)
 constexpr int MAX_KT = 32;             // tiles per axis (N <= 256)
-constexpr int MAX_ITEMS = 512;         // batch items addressable by the per-item work lists
-constexpr int MAIN_WGS_PER_CU = 5;     // LDS-bound (24 KiB brick + 5 KiB of tables per workgroup)
-constexpr int FILL_CHUNK = 512;        // 16-B units zero-filled at each of a tile's two load latencies
-constexpr int CNT_STRIDE = 32;         // per-item counters live 128 B apart (no same-line atomic serialisation)
+constexpr int MAT_STRIDE = 12;         // per item: the inverse 3x4 (floats)
 
 __device__ __forceinline__ void pose_to_affine_t(const float* pose, int S, int N, float* m)
 {
@@ -67,9 +53,10 @@ template <int CT, bool FROM_POSE>
 __global__ __launch_bounds__(256)
 void resample_prepare_kernel(const float* __restrict__ vox, const float* __restrict__ mat_or_pose,
                              float* __restrict__ ws_mat, unsigned* __restrict__ ws_occ, unsigned* __restrict__ ws_vbit,
-                             unsigned* __restrict__ ws_count, int S, int N, int NC)
+                             unsigned* __restrict__ ws_nb, int S, int N, int NC)
 {
     const int b = blockIdx.y;
+    int nonbin = (CT == 1) ? 0 : 1;            // some non-zero voxel differs from 1.0f (occupancy grids are {0,1})
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int VW = S >= 32 ? S >> 5 : 1;
     // e -> (cz, cy, zl, yl): the low 4 bits pick the row inside the cell row
@@ -86,6 +73,8 @@ void resample_prepare_kernel(const float* __restrict__ vox, const float* __restr
             if (CT == 1) {
                 for (int q = 0; q < nx / 4; ++q) {
                     const float4 v = p[w * 8 + q];
+                    nonbin |= ((v.x != 0.f) & (v.x != 1.f)) | ((v.y != 0.f) & (v.y != 1.f)) |
+                              ((v.z != 0.f) & (v.z != 1.f)) | ((v.w != 0.f) & (v.w != 1.f));
                     bits |= ((v.x != 0.f) ? 1u : 0u) << (4 * q) | ((v.y != 0.f) ? 2u : 0u) << (4 * q) |
                             ((v.z != 0.f) ? 4u : 0u) << (4 * q) | ((v.w != 0.f) ? 8u : 0u) << (4 * q);
                 }
@@ -106,10 +95,13 @@ void resample_prepare_kernel(const float* __restrict__ vox, const float* __restr
     cellbits |= __shfl_xor(cellbits, 4);
     cellbits |= __shfl_xor(cellbits, 8);
     if (live && (threadIdx.x & 15) == 0) ws_occ[((size_t)b * NC + cz) * NC + cy] = cellbits;
+    // every (block, item) slot is rewritten by every call: no zeroing, no atomics
+    nonbin = __syncthreads_or(nonbin);
+    if (threadIdx.x == 0) ws_nb[(size_t)b * gridDim.x + blockIdx.x] = (unsigned)nonbin;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ws_count[(size_t)b * CNT_STRIDE] = 0u;                   // this item's tile list starts empty
-        if (FROM_POSE) pose_to_affine_t(mat_or_pose + 3 * b, S, N, ws_mat + 12 * b);
-        else for (int q = 0; q < 12; ++q) ws_mat[12 * b + q] = mat_or_pose[12 * b + q];
+        float* m = ws_mat + MAT_STRIDE * b;
+        if (FROM_POSE) pose_to_affine_t(mat_or_pose + 3 * b, S, N, m);
+        else for (int q = 0; q < 12; ++q) m[q] = mat_or_pose[12 * b + q];
     }
 }
 
@@ -132,9 +124,11 @@ __device__ __forceinline__ Taps sample_taps(int S, float x, float y, float z)
     return t;
 }
 
-// weights from the clamped indices and the add_n of the eight products (:465-485); LD(zi, yi, xi, c)
-template <int CT, class LD>
-__device__ __forceinline__ void sample_eval(const Taps& t, float x, float y, float z, const LD& ld, float* __restrict__ o)
+// weights from the clamped indices and the add_n of the eight products (:465-485).  tv[n][c]: the eight taps in
+// add_n order a..h = (z0,y0,x0) (z0,y1,x0) (z0,y0,x1) (z0,y1,x1) (z1,y0,x0) (z1,y1,x0) (z1,y0,x1) (z1,y1,x1)
+template <int CT>
+__device__ __forceinline__ void sample_eval(const Taps& t, float x, float y, float z, const float (&tv)[8][CT],
+                                            float* __restrict__ o)
 {
     const float ax = __fsub_rn((float)t.x1, x), bx = __fsub_rn(x, (float)t.x0);
     const float ay = __fsub_rn((float)t.y1, y), by = __fsub_rn(y, (float)t.y0);
@@ -149,37 +143,69 @@ __device__ __forceinline__ void sample_eval(const Taps& t, float x, float y, flo
     const float wh = __fmul_rn(__fmul_rn(bx, by), bz);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        float v = __fmul_rn(wa, ld(t.z0, t.y0, t.x0, c));
-        v = __fadd_rn(v, __fmul_rn(wb, ld(t.z0, t.y1, t.x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wc, ld(t.z0, t.y0, t.x1, c)));
-        v = __fadd_rn(v, __fmul_rn(wd, ld(t.z0, t.y1, t.x1, c)));
-        v = __fadd_rn(v, __fmul_rn(we, ld(t.z1, t.y0, t.x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wf, ld(t.z1, t.y1, t.x0, c)));
-        v = __fadd_rn(v, __fmul_rn(wg, ld(t.z1, t.y0, t.x1, c)));
-        v = __fadd_rn(v, __fmul_rn(wh, ld(t.z1, t.y1, t.x1, c)));
+        float v = __fmul_rn(wa, tv[0][c]);
+        v = __fadd_rn(v, __fmul_rn(wb, tv[1][c]));
+        v = __fadd_rn(v, __fmul_rn(wc, tv[2][c]));
+        v = __fadd_rn(v, __fmul_rn(wd, tv[3][c]));
+        v = __fadd_rn(v, __fmul_rn(we, tv[4][c]));
+        v = __fadd_rn(v, __fmul_rn(wf, tv[5][c]));
+        v = __fadd_rn(v, __fmul_rn(wg, tv[6][c]));
+        v = __fadd_rn(v, __fmul_rn(wh, tv[7][c]));
         o[c] = v;
     }
 }
 
 struct TiledArgs {
     const float* vox;        // [B,S,S,S,C]
-    const float* ws_mat;     // [B,12]
+    const float* ws_mat;     // [B,MAT_STRIDE]
     const unsigned* ws_occ;  // [B,NC,NC]
     const unsigned* ws_vbit; // [B,S,S,VW]
-    unsigned* ws_count;      // [B*CNT_STRIDE]  per-item count of candidate tiles
+    const unsigned* ws_nb;   // [B, nprep]  per prepare-block flag: a non-zero voxel other than 1.0f was seen
+    int nprep;
     unsigned* ws_colmask;    // [B, ph/8, pw/8]  bit kt = tile (column, kt) is a candidate
-    uint4* ws_list;          // [B][ph/8 * pw/8 * N/8] {packed (ti,tj,kt), bx0|bx1<<8|by0<<16|by1<<24, bz0|bz1<<8, -}
     float* out;
     int B, S, N, NC;
     int h0, w0, ph, pw, image_layout;
     int debug;               // development ablations: 1 = treat every tile as empty, 2 = skip the zero fill,
-                             // 3 = no per-sample test (every sample of a candidate tile is evaluated)
-    int nwg;                 // workgroups of the main launch
-    int list_stride;         // records per item
+                             // 3 = no per-sample bit test, 5 = no occupancy-grid fast path
+    int nfill, nsub;         // fill rows (B*ph) and sampler sub-columns (B * ph/8 * pw/8 * ceil(N/32)) of the main launch
 };
 
+// bounding box (source voxel indices, inclusive) of the pre-image of the 8^3 tile at (i0, j0, k0): the 8 corners go
+// through the sampler's own coordinate arithmetic on lanes (lane & 7), min/max over xor-shuffles of 1,2,4, so every
+// lane of each group of 8 returns the same box
+__device__ __forceinline__ void tile_bbox(const float* m, int S, int N, int image_layout, int i0, int j0, int k0,
+                                          int lane, int* b0, int* b1)
+{
+    const int ci = lane & 1, cj = (lane >> 1) & 1, ck = (lane >> 2) & 1;
+    const int i = i0 + 7 * ci, j = j0 + 7 * cj, k = k0 + 7 * ck;
+    const float gx = (float)k;
+    const float gy = image_layout ? (float)(N - 1 - i) : (float)j;
+    const float gz = image_layout ? (float)j : (float)i;
+    float lo[3], hi[3];
+    lo[0] = hi[0] = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
+    lo[1] = hi[1] = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
+    lo[2] = hi[2] = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 1; s < 8; s <<= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], s));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], s));
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        // every tap index of every sample of the tile is clamp(floor(c)) or clamp(floor(c)+1) with
+        // c within rounding of [lo,hi]: one voxel of margin on each side covers the rounding
+        const float l = fminf(fmaxf(floorf(lo[d]) - 1.f, 0.f), (float)(S - 1));
+        const float h = fminf(fmaxf(floorf(hi[d]) + 2.f, 0.f), (float)(S - 1));
+        b0[d] = (int)l; b1[d] = (int)h;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// 2. classify.  One wave per (b, ti, tj) column; lane = (g = tile of the pass, c = corner / cell row).
+// 2. classify.  One wave per (b, ti, tj) column; lane = (g = tile of the pass, c = corner / cell row), eight
+// tiles per pass.  A tile whose box holds no occupied cell is exactly zero everywhere.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void resample_classify_kernel(const TiledArgs a)
@@ -191,45 +217,16 @@ void resample_classify_kernel(const TiledArgs a)
     const int tj = (int)(col % ntj), ti = (int)((col / ntj) % nti), b = (int)(col / ((long long)ntj * nti));
     float m[12];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[12 * b + q];
+    for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[MAT_STRIDE * b + q];
     const unsigned* occ = a.ws_occ + (size_t)b * a.NC * a.NC;
     const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8;
     const int g = lane >> 3, c = lane & 7;
-    const int N = a.N, S = a.S;
     unsigned mask = 0;
-    unsigned rec_xy[MAX_KT / 8], rec_z[MAX_KT / 8];      // lanes with c == 0 keep the box of tile pass*8+g
     const int npass = (nkt + 7) >> 3;
-#pragma unroll
-    for (int pass = 0; pass < MAX_KT / 8; ++pass) {
-        rec_xy[pass] = 0; rec_z[pass] = 0;
-        if (pass >= npass) continue;
+    for (int pass = 0; pass < npass; ++pass) {
         const int kt = pass * 8 + g;
-        // corner c of tile kt through the sampler's own coordinate arithmetic
-        const int ci = c & 1, cj = (c >> 1) & 1, ck = (c >> 2) & 1;
-        const int i = i0 + 7 * ci, j = j0 + 7 * cj, k = kt * 8 + 7 * ck;
-        const float gx = (float)k;
-        const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
-        const float gz = a.image_layout ? (float)j : (float)i;
-        float lo[3], hi[3];
-        lo[0] = hi[0] = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
-        lo[1] = hi[1] = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
-        lo[2] = hi[2] = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int s = 1; s < 8; s <<= 1) {
-                lo[d] = fminf(lo[d], __shfl_xor(lo[d], s));
-                hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], s));
-            }
         int b0[3], b1[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            // every tap index of every sample of the tile is clamp(floor(c)) or clamp(floor(c)+1) with
-            // c within rounding of [lo,hi]: one voxel of margin on each side covers the rounding
-            const float l = fminf(fmaxf(floorf(lo[d]) - 1.f, 0.f), (float)(S - 1));
-            const float h = fminf(fmaxf(floorf(hi[d]) + 2.f, 0.f), (float)(S - 1));
-            b0[d] = (int)l; b1[d] = (int)h;
-        }
+        tile_bbox(m, a.S, a.N, a.image_layout, i0, j0, kt * 8, lane, b0, b1);
         const int cx0 = b0[0] >> 2, cx1 = b1[0] >> 2;
         const int cy0 = b0[1] >> 2, ncy = (b1[1] >> 2) - cy0 + 1;
         const int cz0 = b0[2] >> 2, ncz = (b1[2] >> 2) - cz0 + 1;
@@ -247,134 +244,145 @@ void resample_classify_kernel(const TiledArgs a)
         unsigned bits = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) bits |= (((bal >> (8 * q)) & 0xffull) ? 1u : 0u) << q;
-        if (a.debug == 1) bits = 0;
         mask |= bits << (pass * 8);
-        rec_xy[pass] = (unsigned)b0[0] | ((unsigned)b1[0] << 8) | ((unsigned)b0[1] << 16) | ((unsigned)b1[1] << 24);
-        rec_z[pass] = (unsigned)b0[2] | ((unsigned)b1[2] << 8);
     }
-    const int n = __popc(mask);
-    unsigned base = 0;
-    if (lane == 0) {
-        a.ws_colmask[col] = mask;
-        if (n) base = atomicAdd(a.ws_count + (size_t)b * CNT_STRIDE, (unsigned)n);
-    }
-    base = __shfl(base, 0);
-    if (c == 0) {
-#pragma unroll
-        for (int pass = 0; pass < MAX_KT / 8; ++pass) {
-            const int kt = pass * 8 + g;
-            if (pass < npass && ((mask >> kt) & 1u)) {
-                const int rank = __popc(mask & ((1u << kt) - 1u));
-                const unsigned desc = ((unsigned)ti << 10) | ((unsigned)tj << 5) | (unsigned)kt;
-                a.ws_list[(size_t)b * a.list_stride + base + rank] = make_uint4(desc, rec_xy[pass], rec_z[pass], 0u);
-            }
-        }
-    }
+    if (a.debug == 1) mask = 0;
+    if (lane == 0) a.ws_colmask[col] = mask;
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. main
+// 3. main.  Two kinds of workgroups interleaved in one launch (block id % 9 == 0: fill, else sampler):
+//   fill: one (b,i) row of the output (pw*N floats, 64 KiB) zero-filled with 16-B stores, skipping the 32-B
+//     segments of candidate tiles.  One tiny load, then stores only.
+//   sampler: one (b, ti, tj, kq) sub-column = four 8^3 tiles; exits at once if none is a candidate.  Strictly
+//     LOADS -> COMPUTE -> STORES: vector memory operations complete in issue order (one vmcnt for loads and
+//     stores), so a load issued behind stores into an HBM-saturated write stream waits for them -- every earlier
+//     form of this kernel that reloaded after storing (persistent loops over tiles, fill chunks between tiles)
+//     spent its time exactly there, not in arithmetic or gathers.
+//       a. wave w: box of tile w (as the classifier computed it);
+//       b. the voxel-bitmap rows of the candidate tiles' boxes -> LDS (<= 4 KiB each);
+//       c. every sample tests its own eight taps against those rows (a sample whose taps are all zero IS zero);
+//          the ~20 % that pass run the trilinear arithmetic -- on occupancy grids ({0,1} values, flagged by
+//          the prepare pass) with taps read from the bitmap itself, otherwise gathered from L1/L2;
+//       d. 16-B stores (results of four depth-adjacent lanes are combined first).
 // ------------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256)
 void resample_main_kernel(const TiledArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float brick[BRICK_FLOATS];
-    __shared__ uint2 vrows[VROWS_MAX];
+    __shared__ uint2 vrows[4][VROWS_MAX];
+    __shared__ int tinfo[4][8];           // per tile: {-, bx0, bx1, by0, by1, bz0, bz1, -}
     __shared__ unsigned rowmask[MAX_KT];
-    __shared__ unsigned prefix[MAX_ITEMS + 1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, S = a.S;
-    const int G = a.nwg;
     const int VW = S >= 32 ? S >> 5 : 1;
+    const int nti = a.ph >> 3, ntj = a.pw >> 3, nkt = N >> 3, nkq = (nkt + 3) >> 2;
+    const int grp = blockIdx.x / 9, rem = blockIdx.x % 9;
 
-    // exclusive prefix of the per-item tile counts (B is small: serial scan by one thread)
-    if (tid == 0) {
-        unsigned acc = 0;
-        for (int b = 0; b < a.B; ++b) { prefix[b] = acc; acc += a.ws_count[(size_t)b * CNT_STRIDE]; }
-        prefix[a.B] = acc;
-    }
-    __syncthreads();
-    const unsigned count = prefix[a.B];
-
-    // fill stream state: rows f = blockIdx.x, +G, ...; FILL_CHUNK units at a time
-    const int per_line = (CT == 1) ? (N >> 2) : N;        // 16-B units per (i,j) depth line
-    const int row_units = a.pw * per_line;
-    const long long nrows = (a.debug == 2) ? 0 : (long long)a.B * a.ph;
-    long long frow = blockIdx.x;
-    int fpos = 0;
-    bool fmask_ready = false;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fill_chunk = [&]() {
-        if (frow >= nrows) return;
-        const int il = (int)(frow % a.ph);
-        const long long b = frow / a.ph;
-        if (!fmask_ready) {
-            const int ntj = a.pw >> 3;
-            if (tid < ntj) rowmask[tid] = a.ws_colmask[((size_t)b * (a.ph >> 3) + (il >> 3)) * ntj + tid];
-            __syncthreads();
-            fmask_ready = true;
-        }
-        float4* op = reinterpret_cast<float4*>(a.out + (size_t)frow * a.pw * N * CT);
-        const int uend = min(fpos + FILL_CHUNK, row_units);
-        for (int u = fpos + tid; u < uend; u += 256) {
+    if (rem == 0) {
+        // ---------------- fill ----------------
+        if (grp >= a.nfill || a.debug == 2) return;
+        const int il = grp % a.ph, b = grp / a.ph;
+        if (tid < ntj) rowmask[tid] = a.ws_colmask[((size_t)b * nti + (il >> 3)) * ntj + tid];
+        __syncthreads();
+        float4* op = reinterpret_cast<float4*>(a.out + ((size_t)b * a.ph + il) * a.pw * N * CT);
+        const int per_line = (CT == 1) ? (N >> 2) : N;        // 16-B units per (i,j) depth line
+        const int total = a.pw * per_line;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = tid; u < total; u += 256) {
             const int j = u / per_line, w = u - j * per_line;
             const int kt = (CT == 1) ? (w >> 1) : (w >> 3);
             if (!((rowmask[j >> 3] >> kt) & 1u)) op[u] = z4;
         }
-        fpos = uend;
-        if (fpos >= row_units) {
-            fpos = 0; frow += G; fmask_ready = false;
-            __syncthreads();                               // rowmask is rewritten for the next row
+        return;
+    }
+
+    // ---------------- sampler ----------------
+    int id = grp * 8 + rem - 1;
+    if (id >= a.nsub) return;
+    const int kq = id % nkq; id /= nkq;
+    const int tj = id % ntj; id /= ntj;
+    const int ti = id % nti; const int b = id / nti;
+    const unsigned cmask = (a.ws_colmask[((size_t)b * nti + ti) * ntj + tj] >> (4 * kq)) & 15u;   // uniform
+    if (cmask == 0u) return;
+    const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8;
+
+    const float* mp = a.ws_mat + (size_t)MAT_STRIDE * b;      // uniform address -> scalar loads
+    float m[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) m[q] = mp[q];
+    unsigned nonbin = 0;
+    for (int q = 0; q < a.nprep; ++q) nonbin |= a.ws_nb[(size_t)b * a.nprep + q];
+    const bool binary = CT == 1 && nonbin == 0u && a.debug != 5;
+
+    // ---- a. boxes: wave w <-> tile 4*kq + w ----
+    {
+        int b0[3], b1[3];
+        tile_bbox(m, S, N, a.image_layout, i0, j0, (kq * 4 + wave) * 8, lane, b0, b1);
+        if (lane == 0) {
+            tinfo[wave][1] = b0[0]; tinfo[wave][2] = b1[0];
+            tinfo[wave][3] = b0[1]; tinfo[wave][4] = b1[1];
+            tinfo[wave][5] = b0[2]; tinfo[wave][6] = b1[2];
         }
-    };
-    // global tile index -> (item, record)
-    auto fetch = [&](unsigned t, int& b) -> uint4 {
-        int lo = 0, hi = a.B;                              // largest b with prefix[b] <= t
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
-        b = lo;
-        return a.ws_list[(size_t)lo * a.list_stride + (t - prefix[lo])];
-    };
+    }
+    __syncthreads();
 
-    unsigned t = blockIdx.x;
-    int b = 0, bn = 0;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    if (t < count) rec = fetch(t, b);
-    while (t < count) {
-        const unsigned desc = rec.x;
-        const int kt = desc & 31, tj = (desc >> 5) & 31, ti = (desc >> 10) & 31;
-        const int bx0 = rec.y & 255, bx1 = (rec.y >> 8) & 255, by0 = (rec.y >> 16) & 255, by1 = rec.y >> 24;
-        const int bz0 = rec.z & 255, bz1 = (rec.z >> 8) & 255;
-        const int bcur = b;
-        const unsigned tn = t + G;
-        if (tn < count) rec = fetch(tn, bn);                  // next record: in flight during this tile
-        const int ny = by1 - by0 + 1, nzz = bz1 - bz0 + 1, rows = ny * nzz;
-
-        // ---- level 2: the voxel-bitmap rows of the box; 64-bit window starting at word xw0 ----
-        const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
-        const bool vtest = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && a.debug != 3;
-        uint2 myv = make_uint2(0u, 0u);
-        const float rny = 1.0f / (float)ny;
-        if (vtest) {
-            for (int r = tid; r < rows; r += 256) {            // at most 2 iterations
-                const int z = (int)(((float)r + 0.5f) * rny), y = r - z * ny;
-                const unsigned* vr = a.ws_vbit + (((size_t)bcur * S + bz0 + z) * S + by0 + y) * VW + xw0;
-                const uint2 w2 = make_uint2(vr[0], (xw0 + 1 < VW) ? vr[1] : 0u);
-                if (r < 256) myv = w2;
-                else vrows[r] = w2;                            // second iteration (rare): straight to LDS
+    // ---- b. voxel-bitmap rows of the candidate tiles: all loads first, then LDS ----
+    // (the per-tile steps are generic lambdas instantiated with a compile-time tile index: with runtime-indexed
+    //  loops the compiler kept rv / vt / res in scratch memory -- loads and stores behind our own stores)
+    uint2 rv[4][2];
+    bool vt[4];
+    auto load_rows = [&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        rv[tt][0] = make_uint2(0u, 0u); rv[tt][1] = make_uint2(0u, 0u);
+        vt[tt] = false;
+        if ((cmask >> tt) & 1u) {                                         // uniform
+            const int bx0 = tinfo[tt][1], bx1 = tinfo[tt][2], by0 = tinfo[tt][3], by1 = tinfo[tt][4];
+            const int bz0 = tinfo[tt][5], bz1 = tinfo[tt][6];
+            const int ny = by1 - by0 + 1, rows = ny * (bz1 - bz0 + 1);
+            const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
+            vt[tt] = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && a.debug != 3;
+            if (vt[tt]) {
+                const float rny = 1.0f / (float)ny;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int r = tid + 256 * half;
+                    if (r < rows) {
+                        const int z = (int)(((float)r + 0.5f) * rny), y = r - z * ny;
+                        const unsigned* vr = a.ws_vbit + (((size_t)b * S + bz0 + z) * S + by0 + y) * VW + xw0;
+                        rv[tt][half] = make_uint2(vr[0], (xw0 + 1 < VW) ? vr[1] : 0u);
+                    }
+                }
             }
         }
-        float m[12];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[12 * bcur + q];
-        fill_chunk();                                          // stores only: the loads above stay in flight
-        if (vtest && tid < rows) vrows[tid] = myv;
-        __syncthreads();
+    };
+    load_rows(std::integral_constant<int, 0>{}); load_rows(std::integral_constant<int, 1>{});
+    load_rows(std::integral_constant<int, 2>{}); load_rows(std::integral_constant<int, 3>{});
+    auto put_rows = [&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        if (vt[tt]) {
+            vrows[tt][tid] = rv[tt][0];
+            vrows[tt][tid + 256] = rv[tt][1];
+        }
+    };
+    put_rows(std::integral_constant<int, 0>{}); put_rows(std::integral_constant<int, 1>{});
+    put_rows(std::integral_constant<int, 2>{}); put_rows(std::integral_constant<int, 3>{});
+    __syncthreads();
 
-        const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8, k0 = kt * 8;
-        float xs[2], ys[2], zs[2];
-        Taps tp[2];
-        bool hit[2];
+    // ---- c. samples ----
+    const float* vb = a.vox + (size_t)b * S * S * S * CT;
+    float res[4][2][CT];
+    auto sample_tile = [&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) res[tt][q][cc] = 0.f;
+        if (!((cmask >> tt) & 1u)) return;                                 // uniform
+        const int bx0 = tinfo[tt][1], by0 = tinfo[tt][3], by1 = tinfo[tt][4], bz0 = tinfo[tt][5];
+        const int ny = by1 - by0 + 1;
+        const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
+        const int k0 = (kq * 4 + tt) * 8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
@@ -383,84 +391,80 @@ void resample_main_kernel(const TiledArgs a)
             const float gx = (float)k;
             const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
             const float gz = a.image_layout ? (float)j : (float)i;
-            xs[q] = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
-            ys[q] = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
-            zs[q] = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
-            tp[q] = sample_taps(S, xs[q], ys[q], zs[q]);
-            hit[q] = true;
-            if (vtest) {
+            const float xs = coord_t(m[0], m[1], m[2], m[3], gx, gy, gz);
+            const float ys = coord_t(m[4], m[5], m[6], m[7], gx, gy, gz);
+            const float zs = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
+            const Taps u = sample_taps(S, xs, ys, zs);
+            bool hit = true;
+            unsigned long long w00 = 0ull, w01 = 0ull, w10 = 0ull, w11 = 0ull;      // rows (z0,y0) (z0,y1) (z1,y0) (z1,y1)
+            const int sx0 = u.x0 - xw0 * 32, sx1 = u.x1 - xw0 * 32;
+            if (vt[tt]) {
                 // a sample whose eight taps are all zero is exactly zero
-                const int r00 = (tp[q].z0 - bz0) * ny + (tp[q].y0 - by0), r01 = (tp[q].z0 - bz0) * ny + (tp[q].y1 - by0);
-                const int r10 = (tp[q].z1 - bz0) * ny + (tp[q].y0 - by0), r11 = (tp[q].z1 - bz0) * ny + (tp[q].y1 - by0);
-                const uint2 w00 = vrows[r00], w01 = vrows[r01], w10 = vrows[r10], w11 = vrows[r11];
-                const unsigned long long w = ((unsigned long long)(w00.y | w01.y | w10.y | w11.y) << 32) |
-                                             (unsigned long long)(w00.x | w01.x | w10.x | w11.x);
-                const unsigned long long sel = (1ull << (tp[q].x0 - xw0 * 32)) | (1ull << (tp[q].x1 - xw0 * 32));
-                hit[q] = (w & sel) != 0ull;
+                const int rz0 = (u.z0 - bz0) * ny, rz1 = (u.z1 - bz0) * ny, ry0 = u.y0 - by0, ry1 = u.y1 - by0;
+                const uint2 a00 = vrows[tt][rz0 + ry0], a01 = vrows[tt][rz0 + ry1];
+                const uint2 a10 = vrows[tt][rz1 + ry0], a11 = vrows[tt][rz1 + ry1];
+                w00 = ((unsigned long long)a00.y << 32) | a00.x; w01 = ((unsigned long long)a01.y << 32) | a01.x;
+                w10 = ((unsigned long long)a10.y << 32) | a10.x; w11 = ((unsigned long long)a11.y << 32) | a11.x;
+                const unsigned long long sel = (1ull << sx0) | (1ull << sx1);
+                hit = ((w00 | w01 | w10 | w11) & sel) != 0ull;
             }
-        }
-        const int any = __syncthreads_or((hit[0] || hit[1]) ? 1 : 0);
-
-        const float* vb = a.vox + (size_t)bcur * S * S * S * CT;
-        const int xo = (CT == 1) ? (bx0 & ~3) : bx0;                       // x origin of the brick (voxels)
-        const int U = (CT == 1) ? ((bx1 - xo) >> 2) + 1 : bx1 - bx0 + 1;   // 16-B units per row
-        const int rstride = U * 4;                                         // floats per brick row
-        const bool staged = rows * rstride <= BRICK_FLOATS;
-        if (any && staged) {
-            // all of a thread's 16-B units are requested before the first one is used (one L2 round trip per
-            // tile); unit -> (row, u) and row -> (z, y) by exact float reciprocals (indices < 2^20)
-            constexpr int UPT = (BRICK_FLOATS / 4 + 255) / 256;
-            const int units = rows * U;
-            const float rU = 1.0f / (float)U;
-            f32x4 v[UPT];
+            if (hit) {
+                float tv[8][CT];
+                if (binary && vt[tt]) {
+                    // occupancy grid: a tap is exactly 0.0f or 1.0f and the bitmap says which (no gather at all)
+                    tv[0][0] = ((w00 >> sx0) & 1ull) ? 1.f : 0.f; tv[1][0] = ((w01 >> sx0) & 1ull) ? 1.f : 0.f;
+                    tv[2][0] = ((w00 >> sx1) & 1ull) ? 1.f : 0.f; tv[3][0] = ((w01 >> sx1) & 1ull) ? 1.f : 0.f;
+                    tv[4][0] = ((w10 >> sx0) & 1ull) ? 1.f : 0.f; tv[5][0] = ((w11 >> sx0) & 1ull) ? 1.f : 0.f;
+                    tv[6][0] = ((w10 >> sx1) & 1ull) ? 1.f : 0.f; tv[7][0] = ((w11 >> sx1) & 1ull) ? 1.f : 0.f;
 #pragma unroll
-            for (int q = 0; q < UPT; ++q) {
-                const int idx = tid + 256 * q;
-                if (idx < units) {
-                    int r = (int)(((float)idx + 0.5f) * rU);
-                    const int u = idx - r * U;
-                    int z = (int)(((float)r + 0.5f) * rny);
-                    const int y = r - z * ny;
-                    v[q] = *reinterpret_cast<const f32x4*>(vb + (((size_t)(bz0 + z) * S + by0 + y) * S + xo) * CT + u * 4);
+                    for (int n = 0; n < 8; ++n)
+#pragma unroll
+                        for (int cc = 1; cc < CT; ++cc) tv[n][cc] = 0.f;   // (CT > 1 never takes this branch)
+                } else {
+                    const float* r00 = vb + (((size_t)u.z0 * S + u.y0) * S) * CT, * r01 = vb + (((size_t)u.z0 * S + u.y1) * S) * CT;
+                    const float* r10 = vb + (((size_t)u.z1 * S + u.y0) * S) * CT, * r11 = vb + (((size_t)u.z1 * S + u.y1) * S) * CT;
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) {
+                        tv[0][cc] = r00[u.x0 * CT + cc]; tv[1][cc] = r01[u.x0 * CT + cc];
+                        tv[2][cc] = r00[u.x1 * CT + cc]; tv[3][cc] = r01[u.x1 * CT + cc];
+                        tv[4][cc] = r10[u.x0 * CT + cc]; tv[5][cc] = r11[u.x0 * CT + cc];
+                        tv[6][cc] = r10[u.x1 * CT + cc]; tv[7][cc] = r11[u.x1 * CT + cc];
+                    }
                 }
-            }
-            fill_chunk();
+                float r[CT];
+                sample_eval<CT>(u, xs, ys, zs, tv, r);
 #pragma unroll
-            for (int q = 0; q < UPT; ++q) {
-                const int idx = tid + 256 * q;
-                if (idx < units) *reinterpret_cast<f32x4*>(brick + idx * 4) = v[q];
+                for (int cc = 0; cc < CT; ++cc) res[tt][q][cc] = r[cc];
             }
-            __syncthreads();
         }
-        const size_t patch_base = (((size_t)bcur * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
+    };
+    sample_tile(std::integral_constant<int, 0>{}); sample_tile(std::integral_constant<int, 1>{});
+    sample_tile(std::integral_constant<int, 2>{}); sample_tile(std::integral_constant<int, 3>{});
+
+    // ---- d. stores (nothing is loaded after this point) ----
+    const size_t patch_base = (((size_t)b * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
+    auto store_tile = [&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        if (!((cmask >> tt) & 1u)) return;                                 // the fill stream owns empty tiles
+        const int kt = kq * 4 + tt;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
             const int kl = p & 7, jl = (p >> 3) & 7, il = p >> 6;
-            float r[CT];
-#pragma unroll
-            for (int cc = 0; cc < CT; ++cc) r[cc] = 0.f;
-            if (hit[q]) {
-                if (staged) {
-                    auto ld = [&](int zi, int yi, int xi, int cc) -> float {
-                        return brick[((zi - bz0) * ny + (yi - by0)) * rstride + (xi - xo) * CT + cc];
-                    };
-                    sample_eval<CT>(tp[q], xs[q], ys[q], zs[q], ld, r);
-                } else {
-                    auto ld = [&](int zi, int yi, int xi, int cc) -> float {
-                        return vb[(((size_t)zi * S + yi) * S + xi) * CT + cc];
-                    };
-                    sample_eval<CT>(tp[q], xs[q], ys[q], zs[q], ld, r);
-                }
+            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + kt * 8 + kl) * CT;
+            if (CT == 1) {
+                // four consecutive depth samples sit on four consecutive lanes: gather them into the first
+                const float r0_ = res[tt][q][0];
+                const float r1 = __shfl_down(r0_, 1), r2 = __shfl_down(r0_, 2), r3 = __shfl_down(r0_, 3);
+                if ((tid & 3) == 0) *reinterpret_cast<float4*>(op) = make_float4(r0_, r1, r2, r3);
+            } else {
+                *reinterpret_cast<float4*>(op) = make_float4(res[tt][q][0], res[tt][q][CT > 1 ? 1 : 0],
+                                                             res[tt][q][CT > 2 ? 2 : 0], res[tt][q][CT > 3 ? 3 : 0]);
             }
-            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + k0 + kl) * CT;
-            if (CT == 1) op[0] = r[0];
-            else *reinterpret_cast<float4*>(op) = make_float4(r[0], r[CT > 1 ? 1 : 0], r[CT > 2 ? 2 : 0], r[CT > 3 ? 3 : 0]);
         }
-        __syncthreads();                                       // brick / vrows are rewritten by the next tile
-        t = tn; b = bn;
-    }
-    while (frow < nrows) fill_chunk();                         // whatever is left of the fill stream
+    };
+    store_tile(std::integral_constant<int, 0>{}); store_tile(std::integral_constant<int, 1>{});
+    store_tile(std::integral_constant<int, 2>{}); store_tile(std::integral_constant<int, 3>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,31 +473,27 @@ bool rn_resample_tiled_supported(int B, int S, int N, int C, int ph, int pw)
     if (C != 1 && C != 4) return false;
     if (S != 16 && S != 32 && S != 64 && S != 128) return false;
     if (N % 8 != 0 || N > 8 * MAX_KT || N < 16 || ph % 8 != 0 || pw % 8 != 0) return false;
-    if (B > MAX_ITEMS) return false;
+    (void)B;
     return true;
 }
 
-// [B,12] matrices | [B,NC,NC] cell bitmap | [B,S,S,VW] voxel bitmap | [B*32] counters | [B,32,32] column masks |
-// [B,32,32,32] tile records (16 B each; sized for the largest supported grid, N = 256: the entry point does not
-// know N)
-static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_cnt, size_t* o_mask, size_t* o_list)
+// [B,12] matrices | [B,NC,NC] cell bitmap | [B,S,S,VW] voxel bitmap | [B,nprep] non-binary flags | [B,32,32] column masks
+// (sized for the largest supported grid, N = 256: the entry point does not know N)
+static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_nb, size_t* o_mask)
 {
     const int NC = S / 4, VW = S >= 32 ? S / 32 : 1;
-    size_t off = (size_t)B * 12 * sizeof(float);
+    size_t off = (size_t)B * MAT_STRIDE * sizeof(float);
     *o_occ = off;  off += (size_t)B * NC * NC * sizeof(unsigned);
     *o_vbit = off; off += (size_t)B * S * S * VW * sizeof(unsigned);
-    off = (off + 127) & ~(size_t)127;
-    *o_cnt = off;  off += (size_t)B * CNT_STRIDE * sizeof(unsigned);
+    *o_nb = off;   off += (size_t)B * (S * S / 256 + 1) * sizeof(unsigned);
     *o_mask = off; off += (size_t)B * MAX_KT * MAX_KT * sizeof(unsigned);
-    off = (off + 15) & ~(size_t)15;
-    *o_list = off; off += (size_t)B * MAX_KT * MAX_KT * MAX_KT * sizeof(uint4);
     return off;
 }
 
 size_t rn_resample_tiled_workspace(int B, int S)
 {
-    size_t a, b, c, d, e;
-    return ws_layout(B, S, &a, &b, &c, &d, &e) + 128;       // slack: the caller's buffer may be 16-B aligned only
+    size_t a, b, c, d;
+    return ws_layout(B, S, &a, &b, &c, &d) + 128;           // slack: the caller's buffer may be 16-B aligned only
 }
 
 int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool from_pose, float* out,
@@ -502,42 +502,35 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
 {
     const int NC = S / 4;
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 127) & ~(uintptr_t)127);
-    size_t o_occ, o_vbit, o_cnt, o_mask, o_list;
-    ws_layout(B, S, &o_occ, &o_vbit, &o_cnt, &o_mask, &o_list);
+    size_t o_occ, o_vbit, o_nb, o_mask;
+    ws_layout(B, S, &o_occ, &o_vbit, &o_nb, &o_mask);
     float* ws_mat = reinterpret_cast<float*>(ws);
     unsigned* ws_occ = reinterpret_cast<unsigned*>(ws + o_occ);
     unsigned* ws_vbit = reinterpret_cast<unsigned*>(ws + o_vbit);
-    unsigned* ws_count = reinterpret_cast<unsigned*>(ws + o_cnt);
+    unsigned* ws_nb = reinterpret_cast<unsigned*>(ws + o_nb);
     unsigned* ws_colmask = reinterpret_cast<unsigned*>(ws + o_mask);
-    uint4* ws_list = reinterpret_cast<uint4*>(ws + o_list);
     dim3 pgrid((NC * NC * 16 + 255) / 256, B);
     if (C == 1) {
-        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
-        else hipLaunchKernelGGL((resample_prepare_kernel<1, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
+        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
+        else hipLaunchKernelGGL((resample_prepare_kernel<1, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
     } else {
-        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<4, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
-        else hipLaunchKernelGGL((resample_prepare_kernel<4, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_count, S, N, NC);
+        if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<4, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
+        else hipLaunchKernelGGL((resample_prepare_kernel<4, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
     }
     int rc = rn_check_launch("resample_prepare");
     if (rc != RN_OK) return rc;
     static const int dbg = getenv("RN_RS_DEBUG") ? atoi(getenv("RN_RS_DEBUG")) : 0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
     const long long ncol = (long long)B * (ph / 8) * (pw / 8);
-    const long long nfill = (long long)B * ph;
-    long long nwg = (long long)ncu * MAIN_WGS_PER_CU;
-    if (nwg > nfill) nwg = nfill;                           // tiny problems: one workgroup per output row
-    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_count, ws_colmask, ws_list, out, B, S, N, NC, h0, w0, ph, pw,
-                image_layout, dbg, (int)nwg, MAX_KT * MAX_KT * MAX_KT};
-    if (ncol > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
+    const int nkq = (N / 8 + 3) / 4;
+    const long long nfill = (long long)B * ph, nsub = ncol * nkq;
+    const long long groups = nfill > (nsub + 7) / 8 ? nfill : (nsub + 7) / 8;
+    if (groups * 9 > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
+    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, (int)pgrid.x, ws_colmask, out, B, S, N, NC, h0, w0, ph, pw,
+                image_layout, dbg, (int)nfill, (int)nsub};
     hipLaunchKernelGGL(resample_classify_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, st, a);
     rc = rn_check_launch("resample_classify");
     if (rc != RN_OK) return rc;
-    if (C == 1) hipLaunchKernelGGL(resample_main_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(resample_main_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, a);
+    if (C == 1) hipLaunchKernelGGL(resample_main_kernel<1>, dim3((unsigned)(groups * 9)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(resample_main_kernel<4>, dim3((unsigned)(groups * 9)), dim3(256), 0, st, a);
     return rn_check_launch("resample_main");
 }
