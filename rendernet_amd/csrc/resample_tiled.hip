@@ -163,11 +163,13 @@ struct TiledArgs {
     const unsigned* ws_nb;   // [B, nprep]  per prepare-block flag: a non-zero voxel other than 1.0f was seen
     int nprep;
     unsigned* ws_colmask;    // [B, ph/8, pw/8]  bit kt = tile (column, kt) is a candidate
+    uint2* ws_box;           // [B, ph/8, pw/8, 32]  box of tile kt: {bx0|bx1<<8|by0<<16|by1<<24, bz0|bz1<<8}
     float* out;
     int B, S, N, NC;
     int h0, w0, ph, pw, image_layout;
     int debug;               // development ablations: 1 = treat every tile as empty, 2 = skip the zero fill,
                              // 3 = no per-sample bit test, 5 = no occupancy-grid fast path
+    int order;               // dispatch order of the two kinds of workgroups in the main launch (0 = interleaved 1:8)
     int nfill, nsub;         // fill rows (B*ph) and sampler sub-columns (B * ph/8 * pw/8 * ceil(N/32)) of the main launch
 };
 
@@ -245,6 +247,10 @@ void resample_classify_kernel(const TiledArgs a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) bits |= (((bal >> (8 * q)) & 0xffull) ? 1u : 0u) << q;
         mask |= bits << (pass * 8);
+        if (c == 0 && kt < nkt)
+            a.ws_box[(size_t)col * MAX_KT + kt] =
+                make_uint2((unsigned)b0[0] | ((unsigned)b1[0] << 8) | ((unsigned)b0[1] << 16) | ((unsigned)b1[1] << 24),
+                           (unsigned)b0[2] | ((unsigned)b1[2] << 8));
     }
     if (a.debug == 1) mask = 0;
     if (lane == 0) a.ws_colmask[col] = mask;
@@ -252,8 +258,8 @@ void resample_classify_kernel(const TiledArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // 3. main.  Two kinds of workgroups interleaved in one launch (block id % 9 == 0: fill, else sampler):
-//   fill: one (b,i) row of the output (pw*N floats, 64 KiB) zero-filled with 16-B stores, skipping the 32-B
-//     segments of candidate tiles.  One tiny load, then stores only.
+//   fill: one (b,i) row of the output (pw*N floats, 64 KiB) zero-filled with 16-B stores, skipping the 128-B
+//     line segments of sub-columns that hold a candidate tile.  One tiny load, then stores only.
 //   sampler: one (b, ti, tj, kq) sub-column = four 8^3 tiles; exits at once if none is a candidate.  Strictly
 //     LOADS -> COMPUTE -> STORES: vector memory operations complete in issue order (one vmcnt for loads and
 //     stores), so a load issued behind stores into an HBM-saturated write stream waits for them -- every earlier
@@ -270,14 +276,20 @@ template <int CT>
 __global__ __launch_bounds__(256)
 void resample_main_kernel(const TiledArgs a)
 {
-    __shared__ uint2 vrows[4][VROWS_MAX];
-    __shared__ int tinfo[4][8];           // per tile: {-, bx0, bx1, by0, by1, bz0, bz1, -}
+    __shared__ unsigned vrows[4][VROWS_MAX];   // bit x of row r = voxel bx0 + x of the box row (32-bit window)
     __shared__ unsigned rowmask[MAX_KT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int N = a.N, S = a.S;
     const int VW = S >= 32 ? S >> 5 : 1;
     const int nti = a.ph >> 3, ntj = a.pw >> 3, nkt = N >> 3, nkq = (nkt + 3) >> 2;
-    const int grp = blockIdx.x / 9, rem = blockIdx.x % 9;
+    int grp = blockIdx.x / 9, rem = blockIdx.x % 9;
+    if (a.order == 1) {            // samplers first, then fill
+        if ((int)blockIdx.x < a.nsub) { grp = blockIdx.x / 8; rem = blockIdx.x % 8 + 1; }
+        else { grp = blockIdx.x - a.nsub; rem = 0; }
+    } else if (a.order == 2) {     // fill first, then samplers
+        if ((int)blockIdx.x < a.nfill) { grp = blockIdx.x; rem = 0; }
+        else { const int q = blockIdx.x - a.nfill; grp = q / 8; rem = q % 8 + 1; }
+    }
 
     if (rem == 0) {
         // ---------------- fill ----------------
@@ -292,7 +304,9 @@ void resample_main_kernel(const TiledArgs a)
         for (int u = tid; u < total; u += 256) {
             const int j = u / per_line, w = u - j * per_line;
             const int kt = (CT == 1) ? (w >> 1) : (w >> 3);
-            if (!((rowmask[j >> 3] >> kt) & 1u)) op[u] = z4;
+            // a sub-column (4 tiles = one 128-B line per (i,j) at C=1) with ANY candidate belongs to its sampler
+            // workgroup entirely, so that every line is written once, in full, by one workgroup
+            if (!((rowmask[j >> 3] >> (kt & ~3)) & 15u)) op[u] = z4;
         }
         return;
     }
@@ -315,33 +329,33 @@ void resample_main_kernel(const TiledArgs a)
     for (int q = 0; q < a.nprep; ++q) nonbin |= a.ws_nb[(size_t)b * a.nprep + q];
     const bool binary = CT == 1 && nonbin == 0u && a.debug != 5;
 
-    // ---- a. boxes: wave w <-> tile 4*kq + w ----
+    // ---- a. the boxes the classifier recorded (uniform addresses -> scalar loads, no barrier) ----
+    int tinfo[4][8];
     {
-        int b0[3], b1[3];
-        tile_bbox(m, S, N, a.image_layout, i0, j0, (kq * 4 + wave) * 8, lane, b0, b1);
-        if (lane == 0) {
-            tinfo[wave][1] = b0[0]; tinfo[wave][2] = b1[0];
-            tinfo[wave][3] = b0[1]; tinfo[wave][4] = b1[1];
-            tinfo[wave][5] = b0[2]; tinfo[wave][6] = b1[2];
+        const uint2* bp = a.ws_box + (((size_t)b * nti + ti) * ntj + tj) * MAX_KT + kq * 4;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const uint2 bx = bp[tt];
+            tinfo[tt][1] = bx.x & 255; tinfo[tt][2] = (bx.x >> 8) & 255; tinfo[tt][3] = (bx.x >> 16) & 255; tinfo[tt][4] = bx.x >> 24;
+            tinfo[tt][5] = bx.y & 255; tinfo[tt][6] = (bx.y >> 8) & 255;
         }
     }
-    __syncthreads();
 
     // ---- b. voxel-bitmap rows of the candidate tiles: all loads first, then LDS ----
     // (the per-tile steps are generic lambdas instantiated with a compile-time tile index: with runtime-indexed
     //  loops the compiler kept rv / vt / res in scratch memory -- loads and stores behind our own stores)
-    uint2 rv[4][2];
+    unsigned rv[4][2];
     bool vt[4];
     auto load_rows = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
-        rv[tt][0] = make_uint2(0u, 0u); rv[tt][1] = make_uint2(0u, 0u);
+        rv[tt][0] = 0u; rv[tt][1] = 0u;
         vt[tt] = false;
         if ((cmask >> tt) & 1u) {                                         // uniform
             const int bx0 = tinfo[tt][1], bx1 = tinfo[tt][2], by0 = tinfo[tt][3], by1 = tinfo[tt][4];
             const int bz0 = tinfo[tt][5], bz1 = tinfo[tt][6];
             const int ny = by1 - by0 + 1, rows = ny * (bz1 - bz0 + 1);
             const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
-            vt[tt] = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && a.debug != 3;
+            vt[tt] = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && (bx1 - bx0) < 32 && a.debug != 3;
             if (vt[tt]) {
                 const float rny = 1.0f / (float)ny;
 #pragma unroll
@@ -350,7 +364,9 @@ void resample_main_kernel(const TiledArgs a)
                     if (r < rows) {
                         const int z = (int)(((float)r + 0.5f) * rny), y = r - z * ny;
                         const unsigned* vr = a.ws_vbit + (((size_t)b * S + bz0 + z) * S + by0 + y) * VW + xw0;
-                        rv[tt][half] = make_uint2(vr[0], (xw0 + 1 < VW) ? vr[1] : 0u);
+                        // the 32 bits starting at voxel bx0: the only 64-bit shift of this row (none per sample)
+                        const unsigned long long w64 = ((unsigned long long)((xw0 + 1 < VW) ? vr[1] : 0u) << 32) | vr[0];
+                        rv[tt][half] = (unsigned)(w64 >> (bx0 - xw0 * 32));
                     }
                 }
             }
@@ -381,7 +397,6 @@ void resample_main_kernel(const TiledArgs a)
         if (!((cmask >> tt) & 1u)) return;                                 // uniform
         const int bx0 = tinfo[tt][1], by0 = tinfo[tt][3], by1 = tinfo[tt][4], bz0 = tinfo[tt][5];
         const int ny = by1 - by0 + 1;
-        const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
         const int k0 = (kq * 4 + tt) * 8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -396,26 +411,23 @@ void resample_main_kernel(const TiledArgs a)
             const float zs = coord_t(m[8], m[9], m[10], m[11], gx, gy, gz);
             const Taps u = sample_taps(S, xs, ys, zs);
             bool hit = true;
-            unsigned long long w00 = 0ull, w01 = 0ull, w10 = 0ull, w11 = 0ull;      // rows (z0,y0) (z0,y1) (z1,y0) (z1,y1)
-            const int sx0 = u.x0 - xw0 * 32, sx1 = u.x1 - xw0 * 32;
+            unsigned w00 = 0u, w01 = 0u, w10 = 0u, w11 = 0u;                        // rows (z0,y0) (z0,y1) (z1,y0) (z1,y1)
+            const int sx0 = u.x0 - bx0, sx1 = u.x1 - bx0;
             if (vt[tt]) {
                 // a sample whose eight taps are all zero is exactly zero
                 const int rz0 = (u.z0 - bz0) * ny, rz1 = (u.z1 - bz0) * ny, ry0 = u.y0 - by0, ry1 = u.y1 - by0;
-                const uint2 a00 = vrows[tt][rz0 + ry0], a01 = vrows[tt][rz0 + ry1];
-                const uint2 a10 = vrows[tt][rz1 + ry0], a11 = vrows[tt][rz1 + ry1];
-                w00 = ((unsigned long long)a00.y << 32) | a00.x; w01 = ((unsigned long long)a01.y << 32) | a01.x;
-                w10 = ((unsigned long long)a10.y << 32) | a10.x; w11 = ((unsigned long long)a11.y << 32) | a11.x;
-                const unsigned long long sel = (1ull << sx0) | (1ull << sx1);
-                hit = ((w00 | w01 | w10 | w11) & sel) != 0ull;
+                w00 = vrows[tt][rz0 + ry0]; w01 = vrows[tt][rz0 + ry1];
+                w10 = vrows[tt][rz1 + ry0]; w11 = vrows[tt][rz1 + ry1];
+                hit = ((w00 | w01 | w10 | w11) & ((1u << sx0) | (1u << sx1))) != 0u;
             }
             if (hit) {
                 float tv[8][CT];
                 if (binary && vt[tt]) {
                     // occupancy grid: a tap is exactly 0.0f or 1.0f and the bitmap says which (no gather at all)
-                    tv[0][0] = ((w00 >> sx0) & 1ull) ? 1.f : 0.f; tv[1][0] = ((w01 >> sx0) & 1ull) ? 1.f : 0.f;
-                    tv[2][0] = ((w00 >> sx1) & 1ull) ? 1.f : 0.f; tv[3][0] = ((w01 >> sx1) & 1ull) ? 1.f : 0.f;
-                    tv[4][0] = ((w10 >> sx0) & 1ull) ? 1.f : 0.f; tv[5][0] = ((w11 >> sx0) & 1ull) ? 1.f : 0.f;
-                    tv[6][0] = ((w10 >> sx1) & 1ull) ? 1.f : 0.f; tv[7][0] = ((w11 >> sx1) & 1ull) ? 1.f : 0.f;
+                    tv[0][0] = (float)((w00 >> sx0) & 1u); tv[1][0] = (float)((w01 >> sx0) & 1u);
+                    tv[2][0] = (float)((w00 >> sx1) & 1u); tv[3][0] = (float)((w01 >> sx1) & 1u);
+                    tv[4][0] = (float)((w10 >> sx0) & 1u); tv[5][0] = (float)((w11 >> sx0) & 1u);
+                    tv[6][0] = (float)((w10 >> sx1) & 1u); tv[7][0] = (float)((w11 >> sx1) & 1u);
 #pragma unroll
                     for (int n = 0; n < 8; ++n)
 #pragma unroll
@@ -445,8 +457,8 @@ void resample_main_kernel(const TiledArgs a)
     const size_t patch_base = (((size_t)b * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
     auto store_tile = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
-        if (!((cmask >> tt) & 1u)) return;                                 // the fill stream owns empty tiles
-        const int kt = kq * 4 + tt;
+        const int kt = kq * 4 + tt;                                        // all four tiles, zeros where not a candidate
+        if (kt >= nkt) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
@@ -477,9 +489,9 @@ bool rn_resample_tiled_supported(int B, int S, int N, int C, int ph, int pw)
     return true;
 }
 
-// [B,12] matrices | [B,NC,NC] cell bitmap | [B,S,S,VW] voxel bitmap | [B,nprep] non-binary flags | [B,32,32] column masks
+// [B,12] matrices | [B,NC,NC] cell bitmap | [B,S,S,VW] voxel bitmap | [B,nprep] non-binary flags | [B,32,32] column masks | [B,32,32,32] tile boxes
 // (sized for the largest supported grid, N = 256: the entry point does not know N)
-static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_nb, size_t* o_mask)
+static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_nb, size_t* o_mask, size_t* o_box)
 {
     const int NC = S / 4, VW = S >= 32 ? S / 32 : 1;
     size_t off = (size_t)B * MAT_STRIDE * sizeof(float);
@@ -487,13 +499,15 @@ static size_t ws_layout(int B, int S, size_t* o_occ, size_t* o_vbit, size_t* o_n
     *o_vbit = off; off += (size_t)B * S * S * VW * sizeof(unsigned);
     *o_nb = off;   off += (size_t)B * (S * S / 256 + 1) * sizeof(unsigned);
     *o_mask = off; off += (size_t)B * MAX_KT * MAX_KT * sizeof(unsigned);
+    off = (off + 15) & ~(size_t)15;
+    *o_box = off;  off += (size_t)B * MAX_KT * MAX_KT * MAX_KT * sizeof(uint2);
     return off;
 }
 
 size_t rn_resample_tiled_workspace(int B, int S)
 {
-    size_t a, b, c, d;
-    return ws_layout(B, S, &a, &b, &c, &d) + 128;           // slack: the caller's buffer may be 16-B aligned only
+    size_t a, b, c, d, e;
+    return ws_layout(B, S, &a, &b, &c, &d, &e) + 128;           // slack: the caller's buffer may be 16-B aligned only
 }
 
 int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool from_pose, float* out,
@@ -502,13 +516,14 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
 {
     const int NC = S / 4;
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 127) & ~(uintptr_t)127);
-    size_t o_occ, o_vbit, o_nb, o_mask;
-    ws_layout(B, S, &o_occ, &o_vbit, &o_nb, &o_mask);
+    size_t o_occ, o_vbit, o_nb, o_mask, o_box;
+    ws_layout(B, S, &o_occ, &o_vbit, &o_nb, &o_mask, &o_box);
     float* ws_mat = reinterpret_cast<float*>(ws);
     unsigned* ws_occ = reinterpret_cast<unsigned*>(ws + o_occ);
     unsigned* ws_vbit = reinterpret_cast<unsigned*>(ws + o_vbit);
     unsigned* ws_nb = reinterpret_cast<unsigned*>(ws + o_nb);
     unsigned* ws_colmask = reinterpret_cast<unsigned*>(ws + o_mask);
+    uint2* ws_box = reinterpret_cast<uint2*>(ws + o_box);
     dim3 pgrid((NC * NC * 16 + 255) / 256, B);
     if (C == 1) {
         if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
@@ -523,10 +538,11 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
     const long long ncol = (long long)B * (ph / 8) * (pw / 8);
     const int nkq = (N / 8 + 3) / 4;
     const long long nfill = (long long)B * ph, nsub = ncol * nkq;
-    const long long groups = nfill > (nsub + 7) / 8 ? nfill : (nsub + 7) / 8;
+    static const int order = getenv("RN_RS_ORDER") ? atoi(getenv("RN_RS_ORDER")) : 0;
+    const long long groups = order ? (nfill + nsub + 8) / 9 : (nfill > (nsub + 7) / 8 ? nfill : (nsub + 7) / 8);
     if (groups * 9 > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
-    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, (int)pgrid.x, ws_colmask, out, B, S, N, NC, h0, w0, ph, pw,
-                image_layout, dbg, (int)nfill, (int)nsub};
+    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, (int)pgrid.x, ws_colmask, ws_box, out, B, S, N, NC, h0, w0, ph, pw,
+                image_layout, dbg, order, (int)nfill, (int)nsub};
     hipLaunchKernelGGL(resample_classify_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, st, a);
     rc = rn_check_launch("resample_classify");
     if (rc != RN_OK) return rc;
