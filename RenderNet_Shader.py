@@ -3,11 +3,16 @@
 (RenderNet_Shader.py) on the MI355X path, same JSON keys (config_RenderNet.json:1-17,
 README.md:41-70).
 
-Round-1 scope: the forward render path.  The script builds the graph of RenderNet_Shader.py:135-156
-(resample -> transform -> crop -> RenderNet), loads weights from `<sample_save>/<trained_model_name>.npz`
-when present (else the seeded reference initialisers), renders every binvox under `model_path` at the
-poses of the demo sweep and writes PNGs to `sample_save`.  The training loop (:193-306: Adam step,
-BCE loss, tar data loader) needs the backward kernels and is not built yet: it raises.
+Without `--train` the script builds the graph of RenderNet_Shader.py:135-156 (resample -> transform -> crop ->
+RenderNet), loads weights from `<sample_save>/<trained_model_name>.npz` when present (else the seeded reference
+initialisers), renders every binvox under `model_path` at the demo pose and writes PNGs to `sample_save`.
+
+`--train` runs the reference's training loop (:193-306): epochs over the image tar (`image_path`, poses parsed from
+the member names) + binvox folder (`model_path`), crop 32 for the first five epochs then 64 (:204-207), BCE (greyscale)
+or MSE loss, Adam(beta1=0.5) with staircase-decayed learning rate, a sample PNG every 600 steps, weights saved as
+`<sample_save>/<trained_model_name>.npz` after every epoch, then the validation pass over `image_path_valid`
+(:257-301).  Under `torch.distributed.run` every rank trains on its shard of each batch and the gradients are
+summed with bucketed RCCL all-reduces (rendernet_amd/train.py).
 """
 import glob
 import json
@@ -26,14 +31,104 @@ def load_config(path):
     return cfg
 
 
+def _save_png(path, arr01):
+    from PIL import Image
+    Image.fromarray(np.squeeze(np.clip(255 * arr01, 0, 255).astype(np.uint8))).save(path)
+
+
+def train(cfg, argv):
+    """RenderNet_Shader.py:193-306 on the MI355X training step."""
+    import random
+    import torch
+    import torch.distributed as dist
+    from rendernet_amd.shader import ShaderSpec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    from rendernet_amd.parallel import shard_range
+    from rendernet_amd.tools.data_util import data_loader
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(cfg.get('gpu', 0)) if world == 1 else "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    grey = cfg['is_greyscale'].lower() == "true"
+    spec = ShaderSpec(out_ch=1 if grey else 3).check()
+    sample_save = cfg['sample_save']
+    os.makedirs(sample_save, exist_ok=True)
+    wpath = os.path.join(sample_save, cfg['trained_model_name'] + ".npz")
+    weights = dict(np.load(wpath)) if os.path.exists(wpath) else init_shader_weights(spec, seed=1234)
+    tr = Trainer(spec, weights, device="cuda:%d" % local_rank, e_eta=cfg.get('e_eta', 1e-5),
+                 decay_steps=cfg.get('decay_steps', 100000), keep_prob=cfg.get('keep_prob', 1.0))
+    bs = int(cfg['batch_size'])
+    new_res = spec.new_size
+    max_steps = int(argv[argv.index("--max-steps") + 1]) if "--max-steps" in argv else None
+    l1_all = []
+    for epoch in range(int(cfg['max_epochs'])):
+        patch = new_res // 4 if epoch < 5 else new_res // 2                           # :204-207
+        for images, models, params, names in data_loader(cfg, img_path=cfg['image_path'], model_path=cfg['model_path'],
+                                                         flatten=grey, validation_mode=False, img_res=4 * new_res):
+            images = images / 255.0                                                     # :224
+            for idx in range(len(images) // bs):
+                sl = slice(idx * bs, (idx + 1) * bs)
+                lo, hi = shard_range(bs, rank, world)                                   # this rank's frames of the batch
+                # one crop window per batch, the same on every rank (tools/model_util.py:92)
+                start = torch.randint(0, new_res - patch + 1, (2,), device="cuda")
+                if world > 1:
+                    dist.broadcast(start, src=0)
+                loss = tr.step(models[sl][lo:hi], params[sl][lo:hi], images[sl][lo:hi], patch_size=patch,
+                               start_point=start.tolist(), global_batch=bs)
+                step = tr.global_step
+                if rank == 0:
+                    print("Step {0} Loss {1}".format(step, float(loss.item())))
+                if step % 600 == 0 and rank == 0 and hi > lo:                           # :242-253
+                    pred, (r, c, p, _) = tr.forward(models[sl][lo:hi], params[sl][lo:hi], patch, start.tolist())
+                    i = random.randint(0, hi - lo - 1)
+                    tgt = images[sl][lo:hi][i, 4 * r:4 * (r + p), 4 * c:4 * (c + p)]
+                    _save_png(os.path.join(sample_save, "{0}_train_target_{1}_patch.png".format(names[sl][lo + i], step)), tgt)
+                    _save_png(os.path.join(sample_save, "{0}_train_{1}_patch.png".format(names[sl][lo + i], step)),
+                              pred[i].detach().cpu().numpy())
+                if max_steps is not None and step >= max_steps:
+                    break
+            if max_steps is not None and tr.global_step >= max_steps:
+                break
+        if rank == 0:
+            np.savez(wpath, **tr.state_dict())                                          # :257 sess_saver.save
+        # validation (:258-301): full-resolution render, mean absolute error
+        if rank == 0 and cfg.get('image_path_valid') and os.path.exists(cfg['image_path_valid']):
+            l1, cnt = 0.0, 0
+            with torch.no_grad():
+                for images, models, params, names in data_loader(cfg, img_path=cfg['image_path_valid'],
+                                                                 model_path=cfg['model_path'], flatten=grey,
+                                                                 validation_mode=True, img_res=4 * new_res):
+                    images = images / 255.0
+                    pred, _ = tr.forward(models, params)
+                    pred = pred.cpu().numpy()
+                    if cnt % 600 == 0:
+                        _save_png(os.path.join(sample_save, "VALID_{0}_target_{1}.png".format(names[0], epoch)), images[0])
+                        _save_png(os.path.join(sample_save, "VALID_{0}_pred_{1}.png".format(names[0], epoch)), pred[0])
+                    acc = float(np.mean(np.absolute(images - pred)))
+                    print("Validation accuracy {0}".format(acc))
+                    l1 += acc
+                    cnt += 1
+            if cnt:
+                l1_all.append(l1 / cnt)
+                np.savez(os.path.join(sample_save, "L1 All.txt"), l1_all)
+        if max_steps is not None and tr.global_step >= max_steps:
+            break
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     if not argv:
-        raise SystemExit("usage: python RenderNet_Shader.py <config.json> [--train]")
+        raise SystemExit("usage: python RenderNet_Shader.py <config.json> [--train [--max-steps N]]")
     cfg = load_config(argv[0])
     if "--train" in argv:
-        raise NotImplementedError("the training step (RenderNet_Shader.py:193-306) needs the backward kernels, "
-                                  "which are not built yet; this script runs the forward/validation render only")
+        return train(cfg, argv)
     os.environ.setdefault("HIP_VISIBLE_DEVICES", "{0}".format(cfg.get('gpu', 0)))
     from PIL import Image
     from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights

@@ -184,9 +184,13 @@ def main():
             out = renderer.render(vox, poses)
         # dominant kernel = the res2 3x3 1024->1024 conv (21 launches/step, 73 % + 3.7 % of FLOPs):
         # bracket each of its launches with HIP events on the launch stream during the timed region
-        events = []
+        events, rs_events = [], []
 
         def hook(mode, xshape, pw):
+            if mode == "resample":
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                rs_events.append(ev)
+                return ev
             if mode == "conv2d" and pw.cin == spec.w_res2 and pw.cout == spec.w_res2 and pw.kdims[0] == 3:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 events.append(ev)
@@ -239,6 +243,16 @@ def main():
                          "launches_timed": len(events), "flop_per_launch": flop_per_launch,
                          "traffic": traffic},
         }
+        if rs_events:
+            # second roofline of the path: the resampler is HBM-bound (9 437 184 algorithmic bytes per
+            # frame = 1 MiB source read + 8 MiB grid written); its three launches are bracketed together
+            rs_ms = float(np.mean([a.elapsed_time(b) for a, b in rs_events]))
+            rs_bytes = B * 9437184.0
+            res["roofline_resampler"] = {
+                "kernel": "resample_prepare + resample_classify + resample_main (csrc/resample_tiled.hip)",
+                "bound": "hbm", "achieved": round(rs_bytes / (rs_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 8000.0, 4), "avg_ms": round(rs_ms, 4),
+                "launches_timed": len(rs_events), "bytes_per_call": rs_bytes, "traffic": None}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(res), flush=True)

@@ -17,6 +17,12 @@ import torch
 from . import _lib as L
 
 
+# Optional measurement hook (bench.py): called as LAUNCH_HOOK(mode, x_shape, packed_weight) and must
+# return None or a (start_event, end_event) pair that is recorded around the launch on the
+# current stream.
+LAUNCH_HOOK = None
+
+
 def _chk_dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -94,9 +100,14 @@ class _Resample(_ForwardOnly):
         nws = int(lib.rn_resample_workspace_bytes(B, S, C))
         ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=vox.device) if nws else None
         fn = lib.rn_resample_affine_fwd if affine else lib.rn_resample_fwd
+        ev = LAUNCH_HOOK("resample", tuple(vox.shape), None) if LAUNCH_HOOK is not None else None
+        if ev is not None:
+            ev[0].record()
         L.check(fn(L.ptr(vox), L.ptr(pose), L.ptr(out), B, S, N, C, h0, w0, ph, pw, 1 if image_layout else 0,
                    ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, nws, L.stream_ptr()),
                 "rn_resample_fwd")
+        if ev is not None:
+            ev[1].record()
         return out
 
 
@@ -117,11 +128,6 @@ def pose_to_affine(pose, size=64, new_size=128):
             "rn_pose_to_affine")
     return m
 
-
-# Optional measurement hook (bench.py): called as LAUNCH_HOOK(mode, x_shape, packed_weight) and must
-# return None or a (start_event, end_event) pair that is recorded around the launch on the
-# current stream.
-LAUNCH_HOOK = None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -153,3 +153,49 @@ def test_phong_light_and_oracle_composite():
     img = np.random.default_rng(0).uniform(0, 1, (1, 4, 4, 3))
     out = OP.np_phong_composite(img, OP.generate_light_pos(60, 250), np.array([[1., 1., 1.]]), 0.1, 0.9)
     assert out.shape == img.shape and out.min() >= 0 and out.max() <= 1
+
+
+def test_data_loader_tar_and_pose_parsing(tmp_path):
+    """Mirror of tools/data_util.py / tools/utils.py: image tar whose member names carry the pose + binvox folder."""
+    import io
+    import shutil
+    from PIL import Image
+    from rendernet_amd.tools import utils, data_util
+    p = data_util.extract_param_from_names("model_chair_abc_p250_t30_r3.3")
+    assert p.shape == (1, 3)
+    assert np.allclose(p[0], [250 * np.pi / 180, (90 - 30) * np.pi / 180, 1.0])
+    assert np.allclose(data_util.extract_param_from_names("x_p10_t100_r2.5.png")[0], [10 * np.pi / 180, -10 * np.pi / 180, 3.3 / 2.5])
+    with pytest.raises(ValueError):
+        data_util.extract_param_from_names("no_pose_here.png")
+    shutil.copy(os.path.join(ROOT, "binvox", "chair.binvox"), tmp_path / "model_chair_abc_clean.binvox")
+    shutil.copy(os.path.join(ROOT, "binvox", "table.binvox"), tmp_path / "model_normalized_xyz_clean.binvox")
+    tarp = str(tmp_path / "imgs.tar")
+    w = utils.NpyTarWriter(tarp)
+    rng = np.random.default_rng(0)
+    imgs = []
+    for name in ("model_chair_abc_p250_t30_r3.3", "model_chair_xyz_p10_t100_r2.5", "model_chair_abc_p90_t60_r3.3"):
+        img = (rng.random((32, 32, 3)) * 255).astype(np.uint8)
+        imgs.append(img)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="PNG")
+        w.add_bytes(buf.getvalue(), name + ".png")
+    w.add(np.arange(6, dtype=np.float32).reshape(2, 3), "arr")
+    w.close()
+    # raw reader: images come back as float32 with their member stem, arrays from .npy.z members
+    items = list(utils.NpyTarReader(tarp))
+    assert items[0][1] == "model_chair_abc_p250_t30_r3.3" and np.array_equal(items[0][0], imgs[0].astype(np.float32))
+    assert np.array_equal(items[3], np.arange(6, dtype=np.float32).reshape(2, 3))
+    # batches of 2, greyscale: tail of 1 is repeated up to a batch (tools/data_util.py:144-157)
+    cfg = {"batch_size": 2, "batches_chunk": 1}
+    chunks = list(data_util.data_loader(cfg, tarp, str(tmp_path), flatten=True, img_res=32))
+    assert len(chunks) == 2
+    ims, mods, params, names = chunks[0]
+    assert ims.shape == (2, 32, 32, 1) and mods.shape == (2, 64, 64, 64, 1) and params.shape == (2, 3)
+    assert np.allclose(ims[0, :, :, 0], imgs[0].astype(np.float32).mean(axis=2))
+    assert mods[0].sum() != mods[1].sum()                       # chair vs the model_normalized_ fallback (table)
+    assert np.allclose(params[1], [10 * np.pi / 180, -10 * np.pi / 180, 3.3 / 2.5])
+    ims2, mods2, params2, names2 = chunks[1]
+    assert ims2.shape[0] == 2 and np.array_equal(ims2[0], ims2[1]) and list(names2) == [names2[0]] * 2
+    # colour images keep 3 channels
+    ims3 = next(data_util.data_loader(cfg, tarp, str(tmp_path), flatten=False, img_res=32))[0]
+    assert ims3.shape == (2, 32, 32, 3) and np.array_equal(ims3[0], imgs[0].astype(np.float32))
