@@ -1,0 +1,46 @@
+"""End-to-end run of the reference's training script surface (`python RenderNet_Shader.py <config.json> --train`)
+on a tiny synthetic data set: image tar with poses in the member names + binvox folder, two optimiser steps of the
+full-size net, checkpoint written with the TF variable names.  -m gpu."""
+import io
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shader_script_trains_and_checkpoints(tmp_path, capsys):
+    from PIL import Image
+    import RenderNet_Shader
+    from rendernet_amd.tools import utils
+    models = tmp_path / "models"
+    models.mkdir()
+    shutil.copy(os.path.join(ROOT, "binvox", "chair.binvox"), models / "model_chair_abc_clean.binvox")
+    shutil.copy(os.path.join(ROOT, "binvox", "table.binvox"), models / "model_chair_xyz_clean.binvox")
+    tarp = str(tmp_path / "train.tar")
+    w = utils.NpyTarWriter(tarp)
+    rng = np.random.default_rng(0)
+    for name in ("model_chair_abc_p250_t30_r3.3", "model_chair_xyz_p10_t100_r3.3", "model_chair_abc_p90_t60_r3.3",
+                 "model_chair_xyz_p300_t45_r3.3"):
+        buf = io.BytesIO()
+        Image.fromarray((rng.random((512, 512)) * 255).astype(np.uint8)).save(buf, format="PNG")
+        w.add_bytes(buf.getvalue(), name + ".png")
+    w.close()
+    cfg = {"image_path": tarp, "image_path_valid": "", "model_path": str(models), "is_greyscale": "True", "gpu": 0,
+           "batch_size": 2, "max_epochs": 1, "batches_chunk": 1, "threshold": 0.1, "e_eta": 1e-5, "keep_prob": 1.0,
+           "decay_steps": 100000, "trained_model_name": "3d2d_renderer", "sample_save": str(tmp_path / "out"),
+           "checkpoint_secs": 7200}
+    cfgp = str(tmp_path / "config.json")
+    json.dump(cfg, open(cfgp, "w"))
+    RenderNet_Shader.main([cfgp, "--train", "--max-steps", "2"])
+    out = capsys.readouterr().out
+    assert "Step 1 Loss" in out and "Step 2 Loss" in out
+    losses = [float(l.split("Loss")[1]) for l in out.splitlines() if l.startswith("Step")]
+    assert all(np.isfinite(losses)) and losses[0] > 0
+    ck = np.load(os.path.join(cfg["sample_save"], "3d2d_renderer.npz"))
+    assert "encoder/res2_4/con1_3X3/weights" in ck.files and ck["encoder/e_conv7/e_conv7/weights"].shape == (4, 4, 128, 256)
+    assert len(ck.files) == 166                                   # every variable of the Phong-shader graph
