@@ -219,13 +219,15 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
         flop_per_launch = 2.0 * (B * 64 * 64) * (9 * spec.w_res2) * spec.w_res2     # M*K*N*2
         achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms else None
-        traffic = None
+        traffic = rs_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_igemm_res2_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("conv_igemm_res2_hbm_bytes_per_launch")
+                rs_traffic = tj.get("resampler", {}).get("hbm_bytes_per_call")
             except Exception:
-                traffic = None
+                traffic = rs_traffic = None
         res = {
             "metric": "rendered frames/sec, 64^3 voxel->512x512 Phong, batch 24",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -252,7 +254,7 @@ def main():
                 "kernel": "resample_prepare + resample_classify + resample_main (csrc/resample_tiled.hip)",
                 "bound": "hbm", "achieved": round(rs_bytes / (rs_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 8000.0, 4), "avg_ms": round(rs_ms, 4),
-                "launches_timed": len(rs_events), "bytes_per_call": rs_bytes, "traffic": None}
+                "launches_timed": len(rs_events), "bytes_per_call": rs_bytes, "traffic": rs_traffic if B == 24 else None}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(res), flush=True)
