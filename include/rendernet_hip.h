@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 110            /* 0.1.1: training step */
+#define RN_VERSION 120            /* 0.1.2: training step, resampler backward */
 
 /* error codes */
 #define RN_OK              0
@@ -220,6 +220,17 @@ int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B,
                               int Cin, int Cout, int ksize, int stride, void* stream);
 int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
                               int Cin, int Cout, int ksize, int stride, void* stream);
+
+/* Backward of the resampler (what TensorFlow's autodiff derives from tools/resampling_voxel_grid.py:381-486 and
+ * :515-602; used by the reference's inverse rendering, Reconstruct_RenderNet_Face.py:360-364, :402).
+ *   rn_resample_affine_bwd  dout has the shape of the forward output (image_layout / window as in the forward call).
+ *                           dvox [B,S,S,S,C] += scatter of weight*dout (may be NULL); dm [B,3,4] += d(loss)/d(M_inv)
+ *                           (may be NULL; needs vox).  Both are ACCUMULATED with atomics: zero them first.
+ *   rn_pose_to_affine_bwd   dpose [B,3] += J^T dm with J = d(M_inv)/d(azimuth, elevation, scale) of rn_pose_to_affine.
+ * For a pose-driven forward call: m = rn_pose_to_affine(pose); rn_resample_affine_bwd(..., m, ...); rn_pose_to_affine_bwd. */
+int rn_resample_affine_bwd(const float* vox, const float* m_inv, const float* dout, float* dvox, float* dm,
+                           int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout, void* stream);
+int rn_pose_to_affine_bwd(const float* pose, const float* dm, float* dpose, int B, int S, int N, void* stream);
 
 /* Reconstruction loss and d(loss)/d(pred)  (RenderNet_Shader.py:159-163).
  *   mode 0: binary cross-entropy  sum_elems -(t*log(1e-6+p) + (1-t)*log(1e-6+1-p)) / divisor   (divisor = batch)

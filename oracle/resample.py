@@ -174,3 +174,65 @@ def crop_voxel_image(voxels, images, start, patch_size):
 def net_input(voxel_array, view_params, size=64, new_size=128, mode="tf"):
     """RenderNet_Shader.py:150-151: resample then transform to image layout."""
     return transform_voxel_to_match_image(rotation_resampling(voxel_array, view_params, size, new_size, mode))
+
+
+def resampling_affine_bwd(voxel_array, M_inv, dout, new_size=128):
+    """What TensorFlow's autodiff derives from tf_resampling / tf_interpolate (tools/resampling_voxel_grid.py:381-486,
+    :603-610) for a loss L with d L / d out = dout [B,N,N,N,C] (raw [b,z,y,x,c] order): floor / clip carry no
+    gradient; each of the eight tf.gather's scatters weight * dout back (d L / d vox); the weights are linear in
+    the coordinates, which are M_inv @ (gx, gy, gz, 1) (d L / d M_inv).  float64 arithmetic.
+    Returns (dvox [B,S,S,S,C], dM [B,3,4])."""
+    vox = np.asarray(voxel_array, np.float64)
+    B, S, C = vox.shape[0], vox.shape[1], vox.shape[4]
+    N = new_size
+    dvox = np.zeros_like(vox)
+    dM = np.zeros((B, 3, 4), np.float64)
+    gx, gy, gz = (g.astype(np.float64) for g in voxel_meshgrid(N, N, N))
+    G = np.stack([gx, gy, gz, np.ones_like(gx)], 1)                      # [N^3, 4]
+    for b in range(B):
+        xs, ys, zs = source_coords(M_inv[b], N, "ordered")               # the float32 coordinates the forward used
+        x, y, z = xs.astype(np.float64), ys.astype(np.float64), zs.astype(np.float64)
+        x0 = np.floor(x).astype(np.int64); y0 = np.floor(y).astype(np.int64); z0 = np.floor(z).astype(np.int64)
+        x1, y1, z1 = x0 + 1, y0 + 1, z0 + 1
+        x0 = np.clip(x0, 0, S - 1); x1 = np.clip(x1, 0, S - 1)
+        y0 = np.clip(y0, 0, S - 1); y1 = np.clip(y1, 0, S - 1)
+        z0 = np.clip(z0, 0, S - 1); z1 = np.clip(z1, 0, S - 1)
+        ax, bx = x1 - x, x - x0
+        ay, by = y1 - y, y - y0
+        az, bz = z1 - z, z - z0
+        d = np.asarray(dout[b], np.float64).reshape(-1, C)
+        flat = vox[b].reshape(-1, C)
+        dflat = dvox[b].reshape(-1, C)
+        idx = lambda zz, yy, xx: (zz * S + yy) * S + xx
+        taps = [(idx(z0, y0, x0), ax * ay * az), (idx(z0, y1, x0), ax * by * az), (idx(z0, y0, x1), bx * ay * az),
+                (idx(z0, y1, x1), bx * by * az), (idx(z1, y0, x0), ax * ay * bz), (idx(z1, y1, x0), ax * by * bz),
+                (idx(z1, y0, x1), bx * ay * bz), (idx(z1, y1, x1), bx * by * bz)]
+        for ii, w in taps:
+            np.add.at(dflat, ii, w[:, None] * d)
+        va, vb, vc, vd, ve, vf, vg, vh = (flat[ii] for ii, _ in taps)
+        gxs = np.sum(d * ((ay * az)[:, None] * (vc - va) + (by * az)[:, None] * (vd - vb) +
+                          (ay * bz)[:, None] * (vg - ve) + (by * bz)[:, None] * (vh - vf)), 1)
+        gys = np.sum(d * ((ax * az)[:, None] * (vb - va) + (bx * az)[:, None] * (vd - vc) +
+                          (ax * bz)[:, None] * (vf - ve) + (bx * bz)[:, None] * (vh - vg)), 1)
+        gzs = np.sum(d * ((ax * ay)[:, None] * (ve - va) + (ax * by)[:, None] * (vf - vb) +
+                          (bx * ay)[:, None] * (vg - vc) + (bx * by)[:, None] * (vh - vd)), 1)
+        dM[b, 0] = gxs @ G
+        dM[b, 1] = gys @ G
+        dM[b, 2] = gzs @ G
+    return dvox, dM
+
+
+def inverse_affine_f64(view_params, size=64, new_size=128):
+    """float64 twin of inverse_affine (same matrix chain), for finite-difference Jacobians w.r.t. the pose."""
+    vp = np.asarray(view_params, np.float64)
+    out = np.zeros((vp.shape[0], 3, 4))
+    for b, (az, el, s) in enumerate(vp):
+        a = az - math.pi * 0.5
+        ca, sa, ce, se = math.cos(a), math.sin(a), math.cos(el), math.sin(el)
+        rot_y = np.array([[ca, 0, -sa, 0], [0, 1, 0, 0], [sa, 0, ca, 0], [0, 0, 0, 1.0]])
+        rot_z = np.array([[ce, se, 0, 0], [-se, ce, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+        sc = np.diag([s, s, s, 1.0])
+        T = np.eye(4); T[:3, 3] = -size * 0.5
+        Tn = np.eye(4); Tn[:3, 3] = new_size * 0.5
+        out[b] = np.linalg.inv(Tn @ sc @ (rot_z @ rot_y) @ T)[:3]
+    return out

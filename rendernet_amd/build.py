@@ -16,13 +16,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "librendernet_hip.so"
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv3d_drun.hip", "conv_direct.hip", "resample.hip", "resample_tiled.hip", "misc_kernels.hip",
-           "conv_wgrad.hip", "train_kernels.hip"]
+           "conv_wgrad.hip", "train_kernels.hip", "resample_bwd.hip"]
 HEADERS = ["rn_common.h", os.path.join("..", "..", "include", "rendernet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # the resampler must round after every multiply and add (bit parity with the reference's op-by-op
 # TF graph): hipcc's default -ffp-contract=fast would fuse them into FMAs
-EXTRA_FLAGS = {"resample.hip": ["-ffp-contract=off"], "resample_tiled.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"resample.hip": ["-ffp-contract=off"], "resample_tiled.hip": ["-ffp-contract=off"],
+               "resample_bwd.hip": ["-ffp-contract=off"]}
 
 
 def lib_path():

@@ -89,7 +89,10 @@ class _ForwardOnly(torch.autograd.Function):
         raise NotImplementedError("rendernet_amd: backward (training step, SURVEY K13) is not implemented yet")
 
 
-class _Resample(_ForwardOnly):
+class _Resample(torch.autograd.Function):
+    """Forward: rn_resample_fwd / rn_resample_affine_fwd.  Backward: rn_resample_affine_bwd (+ rn_pose_to_affine_bwd
+    for the pose path) -- gradients w.r.t. the voxel grid and the pose / matrix, whichever require grad."""
+
     @staticmethod
     def forward(ctx, vox, pose, N, window, image_layout, affine):
         _chk_dev(vox, pose)
@@ -108,7 +111,33 @@ class _Resample(_ForwardOnly):
                 "rn_resample_fwd")
         if ev is not None:
             ev[1].record()
+        ctx.save_for_backward(vox, pose)
+        ctx.cfg = (N, window, image_layout, affine)
         return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vox, pose = ctx.saved_tensors
+        N, (h0, w0, ph, pw), image_layout, affine = ctx.cfg
+        B, S, C = vox.shape[0], vox.shape[1], vox.shape[4]
+        lib, st = L.lib(), L.stream_ptr()
+        dout = dout.contiguous()
+        m = pose if affine else pose_to_affine(pose, S, N).reshape(B, 12)
+        want_vox, want_pose = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dvox = torch.zeros_like(vox) if want_vox else None
+        dm = torch.zeros((B, 12), dtype=torch.float32, device=vox.device) if want_pose else None
+        if want_vox or want_pose:
+            L.check(lib.rn_resample_affine_bwd(L.ptr(vox), L.ptr(m.contiguous()), L.ptr(dout), L.ptr(dvox), L.ptr(dm),
+                                               B, S, N, C, h0, w0, ph, pw, 1 if image_layout else 0, st),
+                    "rn_resample_affine_bwd")
+        dpose = None
+        if want_pose:
+            if affine:
+                dpose = dm.reshape(pose.shape)
+            else:
+                dpose = torch.zeros_like(pose)
+                L.check(lib.rn_pose_to_affine_bwd(L.ptr(pose), L.ptr(dm), L.ptr(dpose), B, S, N, st), "rn_pose_to_affine_bwd")
+        return dvox, dpose, None, None, None, None
 
 
 def resample(vox, pose, new_size=128, window=None, image_layout=True, affine=False):
