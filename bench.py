@@ -156,7 +156,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rendernet_amd import ops
     from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
@@ -237,7 +238,7 @@ def main():
                                    "cycled, 64^3 -> 128^3 -> 512x512, seeded random weights (237.3M params)",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "batch-sharded x%d, no collective" % world},
             "fraction_of_fp32_conv_roofline": round(fps / world * GMAC_PER_FRAME * 2e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "roofline": {"kernel": "conv_igemm_glds_kernel<0> (128x128x32 tile, LDS-DMA) on res2 3x3 1024->1024 @64x64xB",
+            "roofline": {"kernel": "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA) on res2 3x3 1024->1024 @64x64xB",
                          "bound": "mfma", "achieved": round(achieved, 2) if achieved else None,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,

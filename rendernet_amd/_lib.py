@@ -69,6 +69,7 @@ def lib():
             raise RenderNetHipError(
                 "librendernet_hip.so not found at %s -- build it with `python -m rendernet_amd.build` "
                 "(there is no CPU fallback for the render path)" % LIB_PATH)
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch ships, not a second copy
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing

@@ -78,9 +78,12 @@ def build(force=False, verbose=True):
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         # an undefined symbol (e.g. a kernel whose host stub the compiler dropped) must fail the BUILD, not
-        # the first call on the GPU box
-        import ctypes
-        ctypes.CDLL(so)
+        # the first call on the GPU box.  Checked in a child process: loading the library here would pull the
+        # system libamdhip64 into THIS process before torch loads its own copy (two HIP runtimes, no devices).
+        r = subprocess.run([sys.executable, "-c", "import ctypes,sys; ctypes.CDLL(sys.argv[1])", so],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s does not load:\n%s" % (so, r.stderr))
     return so
 
 

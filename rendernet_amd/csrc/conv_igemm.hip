@@ -33,8 +33,8 @@ struct IgemmArgs {
     int act, ctiles, nk, mtiles, ntiles;
 };
 
-template <int BM, int BN, int BK, int WM, int WN, int VAR = 0>
-__global__ __launch_bounds__(64 * WM * WN, ((VAR == 2 || VAR == 3) ? 3 : 2))
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2)
 void conv_igemm_kernel(const IgemmArgs a)
 {
     constexpr int NT = 64 * WM * WN;
@@ -122,11 +122,9 @@ void conv_igemm_kernel(const IgemmArgs a)
     }
     RN_TAP_SETUP();
 
-    // Two register staging sets: with VAR&4 the loads of K-tile kt+2 are issued while tile kt is
-    // computed and tile kt+1 (loaded one step earlier) is written to LDS, so every load has two
-    // MFMA phases (~8k cycles) to return; without it the prefetch distance is one tile.
-    u32x4 ra0[APASS], ra1[APASS];
-    f32x4 rb0[BPT], rb1[BPT];
+    // register staging set: the loads of K-tile kt+1 are in flight during the MFMAs of tile kt
+    u32x4 ra0[APASS];
+    f32x4 rb0[BPT];
     // global -> registers for K-tile kt (then advance the K-walk)
 #define RN_GLOAD(kt, RA, RB)                                                                             \
     {                                                                                                    \
@@ -157,59 +155,36 @@ void conv_igemm_kernel(const IgemmArgs a)
             if (BF4 % NT == 0 || idx < BF4) *reinterpret_cast<f32x4*>(Bb_ + idx * 4) = RB[i];           \
         }                                                                                                \
     }
-    // MFMAs of the K-tile in LDS stage `cur`; STORE_STMT runs before the last 8-k group (VAR&1) or after it
+    // MFMAs of the K-tile in LDS stage `cur`; STORE_STMT (the next tile's ds_writes) runs before the last 8-k group,
+    // so that the writes issue under the MFMAs
 #define RN_COMPUTE(STORE_STMT)                                                                           \
     {                                                                                                    \
         const float* Ab = As + cur * BM * LDA + (wm * WTM + li) * LDA + lh * 4;                          \
         const float* Bb = Bs + cur * BK * BN + (lh * BN + wn * WTN + li) * 4;                            \
         _Pragma("unroll") for (int kb = 0; kb < BK / 8; ++kb) {                                          \
-            if ((VAR & 1) && kb == BK / 8 - 1) { STORE_STMT; }                                           \
+            if (kb == BK / 8 - 1) { STORE_STMT; }                                                        \
             f32x4 af[TM], bf[TN];                                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
                 af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + kb * 8);                     \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
                 bf[j] = *reinterpret_cast<const f32x4*>(Bb + (kb * 2 * BN + j * 32) * 4);                \
-            if (VAR & 16) __builtin_amdgcn_s_setprio(1);                                                 \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
                     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                       \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0); \
-            if (VAR & 16) __builtin_amdgcn_s_setprio(0);                                                 \
         }                                                                                                \
-        if (!(VAR & 1)) { STORE_STMT; }                                                                  \
     }
 
     int cur = 0;
-    if (VAR & 4) {
-        RN_GLOAD(0, ra0, rb0);
-        RN_LSTORE(0, ra0, rb0);
-        if (a.nk > 1) RN_GLOAD(1, ra1, rb1);
+    RN_GLOAD(0, ra0, rb0);
+    RN_LSTORE(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < a.nk; ++kt) {
+        const bool more = kt + 1 < a.nk;
+        if (more) RN_GLOAD(kt + 1, ra0, rb0);
+        RN_COMPUTE(if (more) RN_LSTORE(cur ^ 1, ra0, rb0));
         __syncthreads();
-        for (int kt = 0; kt < a.nk; kt += 2) {
-            // even step: tile kt in LDS, tile kt+1 in set 1 (in flight), request tile kt+2 into set 0
-            if (kt + 2 < a.nk) RN_GLOAD(kt + 2, ra0, rb0);
-            RN_COMPUTE(if (kt + 1 < a.nk) RN_LSTORE(cur ^ 1, ra1, rb1));
-            __syncthreads();
-            cur ^= 1;
-            if (kt + 1 >= a.nk) break;
-            // odd step: tile kt+1 in LDS, tile kt+2 in set 0, request tile kt+3 into set 1
-            if (kt + 3 < a.nk) RN_GLOAD(kt + 3, ra1, rb1);
-            RN_COMPUTE(if (kt + 2 < a.nk) RN_LSTORE(cur ^ 1, ra0, rb0));
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-        RN_GLOAD(0, ra0, rb0);
-        RN_LSTORE(0, ra0, rb0);
-        __syncthreads();
-        for (int kt = 0; kt < a.nk; ++kt) {
-            const bool more = kt + 1 < a.nk;
-            if (more && VAR != 8 && VAR != 9 && VAR != 11) RN_GLOAD(kt + 1, ra0, rb0);
-            if (VAR == 10) { _Pragma("unroll") for (int p = 0; p < APASS; ++p) asm volatile("" ::"v"(ra0[p])); _Pragma("unroll") for (int i = 0; i < BPT; ++i) asm volatile("" ::"v"(rb0[i])); }
-            RN_COMPUTE(if (more && VAR != 8 && VAR != 9 && VAR != 10) RN_LSTORE(cur ^ 1, ra0, rb0));
-            if (VAR != 9) __syncthreads();
-            if (VAR != 8 && VAR != 9) cur ^= 1;
-        }
+        cur ^= 1;
     }
 #undef RN_COMPUTE
 #undef RN_TAP_SETUP
@@ -251,7 +226,6 @@ void conv_igemm_kernel(const IgemmArgs a)
 // the map makes the 16 rows of every ds_read_b128 lane group hit 16 distinct 16-B slots.  SAME padding
 // still comes from the buffer bounds check (offset >= 2^31 -> zeros are written to LDS).
 // ------------------------------------------------------------------------------------------------
-template <int VAR>
 __global__ __launch_bounds__(256, 2)
 void conv_igemm_glds_kernel(const IgemmArgs a)
 {
@@ -422,7 +396,7 @@ static int launch_glds(IgemmArgs& a, hipStream_t st)
     a.ctiles = a.Cin / BK;
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * BK * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
-    auto kern = conv_igemm_glds_kernel<0>;
+    auto kern = conv_igemm_glds_kernel;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -434,7 +408,7 @@ static int launch_glds(IgemmArgs& a, hipStream_t st)
     return rn_check_launch("conv_igemm_glds");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int VAR = 0>
+template <int BM, int BN, int BK, int WM, int WN>
 static int launch_cfg(IgemmArgs& a, hipStream_t st)
 {
     a.mtiles = (a.M + BM - 1) / BM;
@@ -442,7 +416,7 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st)
     a.ctiles = a.Cin / BK;
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * (BK + 4) * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
-    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, VAR>;
+    auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -503,28 +477,15 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
     a.os_b = p.os_b; a.os0 = p.os[0]; a.os1 = p.os[1]; a.os2 = p.os[2]; a.out_off = p.out_off;
     a.act = p.act;
     const bool k32 = p.Cin % 32 == 0;
-    // VAR bit0: write the next K-tile into LDS before the last MFMA group instead of after it (the
-    // ds_writes then issue under the MFMAs); VAR>=2: BK=16 at >=3 waves/SIMD.  Measured on res2
-    // (B=24): VAR0 129.3, VAR1 133.4, VAR2 134.2, VAR3 133.6, 2-deep register prefetch 133.6, setprio 133.7,
-    // LDS-DMA staging (variant 32, conv_igemm_glds_kernel) 143.7 TFLOP/s -- the default where it applies.
-    // Ablations on the same shape: no global loads 142.5, no LDS stores 137.0, neither 152.8 TFLOP/s.
-    static const int variant = getenv("RN_IGEMM_VARIANT") ? atoi(getenv("RN_IGEMM_VARIANT")) : 32;
+    // Measured on res2 (B=24, 1.855 TFLOP per launch): register-staged tiles 129 TFLOP/s, with the next tile's
+    // ds_writes issued under the last MFMA group 133, LDS-DMA staging (conv_igemm_glds_kernel) 143 -- the default
+    // where it applies (128-wide N, 32-channel K slices).  Ablations of the register-staged form on the same shape:
+    // no global loads 142.5, no LDS stores 137.0, neither 152.8 TFLOP/s.
     if (p.Npad % 128 == 0) {
-        if (variant == 0 && k32) return launch_cfg<128, 128, 32, 2, 2, 0>(a, st);
-        if (variant == 2) return launch_cfg<128, 128, 16, 2, 2, 2>(a, st);
-        if (variant == 3) return launch_cfg<128, 128, 16, 2, 2, 3>(a, st);
-        if (variant == 32 && k32 && a.w_bytes) return launch_glds(a, st);            // LDS-DMA staging
-        if (variant == 10 && k32) return launch_cfg<128, 128, 32, 2, 2, 10>(a, st);  // ablation: loads, no LDS stores (WRONG)
-        if (variant == 11 && k32) return launch_cfg<128, 128, 32, 2, 2, 11>(a, st);  // ablation: LDS stores, no loads (WRONG)
-        if (variant == 17 && k32) return launch_cfg<128, 128, 32, 2, 2, 17>(a, st);  // early store + setprio around MFMAs
-        if (variant == 5 && k32) return launch_cfg<128, 128, 32, 2, 2, 5>(a, st);   // early store + 2-deep prefetch
-        if (variant == 4 && k32) return launch_cfg<128, 128, 32, 2, 2, 4>(a, st);   // late store + 2-deep prefetch
-        if (variant == 8 && k32) return launch_cfg<128, 128, 32, 2, 2, 8>(a, st);   // ablation: no loads/stores (WRONG results)
-        if (variant == 9 && k32) return launch_cfg<128, 128, 32, 2, 2, 9>(a, st);   // ablation: + no barrier (WRONG results)
-        if (variant == 1 && k32) return launch_cfg<128, 128, 32, 2, 2, 1>(a, st);
-        return k32 ? launch_cfg<128, 128, 32, 2, 2, 1>(a, st) : launch_cfg<128, 128, 16, 2, 2, 1>(a, st);
+        if (k32 && a.w_bytes) return launch_glds(a, st);
+        return k32 ? launch_cfg<128, 128, 32, 2, 2>(a, st) : launch_cfg<128, 128, 16, 2, 2>(a, st);
     } else if (p.Npad % 64 == 0) {
-        return k32 ? launch_cfg<128, 64, 32, 2, 2, 1>(a, st) : launch_cfg<128, 64, 16, 2, 2, 1>(a, st);
+        return k32 ? launch_cfg<128, 64, 32, 2, 2>(a, st) : launch_cfg<128, 64, 16, 2, 2>(a, st);
     }
-    return k32 ? launch_cfg<128, 32, 32, 4, 1, 1>(a, st) : launch_cfg<128, 32, 16, 4, 1, 1>(a, st);
+    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, st) : launch_cfg<128, 32, 16, 4, 1>(a, st);
 }

@@ -109,3 +109,23 @@ def test_argument_errors():
         ops.resample(vox, pose, new_size=16, window=(8, 8, 16, 16))   # window outside the grid
     with pytest.raises(RenderNetHipError):
         ops.resample(vox.cpu(), pose.cpu(), new_size=16)  # no CPU path
+
+
+def test_every_path_of_the_tiled_resampler_is_bit_exact(fixtures_vox):
+    """The tiled kernel has data-dependent paths: occupancy-grid fast path (taps read from the bitmap) vs float
+    gathers, per-sample bit test vs the fallback for boxes too large for the LDS window (zoomed-out poses), occupied
+    volume borders (clamped taps with non-cancelling values), a batch that mixes the kinds.  All must equal the
+    oracle bit for bit, and the two exact-result switches of RN_RS_DEBUG must not change a bit either."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    rng = np.random.default_rng(11)
+    S, N = 64, 128
+    sparse_float = (rng.random((1, S, S, S, 1)) < 0.03) * rng.standard_normal((1, S, S, S, 1))        # float values
+    dense_binary = (rng.random((1, S, S, S, 1)) < 0.3).astype(np.float32)                                 # occupied borders
+    half_values = (fixtures_vox[1:2] * 0.5)                                                               # {0, 0.5}: not an occupancy grid
+    vox = np.concatenate([fixtures_vox[0:1], sparse_float, dense_binary, half_values]).astype(np.float32)
+    for scales in ((1.0, 1.0, 1.0, 1.0), (0.45, 2.5, 0.6, 1.8)):
+        poses = np.stack([[1.0 + i, 0.5 + 0.3 * i, s] for i, s in enumerate(scales)]).astype(np.float32)
+        m_inv = OR.inverse_affine(poses, S, N)
+        want = OR.transform_voxel_to_match_image(OR.resampling_affine(vox, m_inv, N, mode="ordered"))
+        got = tf_resampling_affine(_dev(vox), _dev(m_inv), N, image_layout=True).cpu().numpy()
+        assert np.array_equal(got, want), "scales %s: max |diff| = %g" % (scales, np.abs(got - want).max())
