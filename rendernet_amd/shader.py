@@ -287,6 +287,37 @@ class Renderer:
         finally:
             V._default = old
 
+    # -- hipGraph replay for small batches ----------------------------------------------------
+    def capture(self, batch, in_ch=1):
+        """Capture one inference render of `batch` frames into a hipGraph (torch.cuda.CUDAGraph over the HIP stream
+        the kernels are launched on) and return `replay(voxels, poses) -> image tensor`.  At batch 1-2 the 81 launches
+        of a render are host-bound when issued one by one from Python (ctypes + allocator per launch); the graph
+        replays them with one call.  Inputs are copied into static buffers; the returned tensor is the graph's static
+        output buffer (overwritten by the next replay)."""
+        s = self.spec
+        vox_buf = torch.zeros((batch, s.size, s.size, s.size, in_ch), dtype=torch.float32, device=self.device)
+        pose_buf = torch.zeros((batch, 3), dtype=torch.float32, device=self.device)
+        pose_buf[:, 2] = 1.0
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                         # warm-up: packs the filters, sets kernel attributes
+                self.render(vox_buf, pose_buf)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            out_buf = self.render(vox_buf, pose_buf)
+
+        def replay(voxels, poses):
+            vox_buf.copy_(torch.as_tensor(voxels, dtype=torch.float32), non_blocking=True)
+            pose_buf.copy_(torch.as_tensor(np.asarray(poses, np.float32) if not isinstance(poses, torch.Tensor) else poses,
+                                           dtype=torch.float32), non_blocking=True)
+            graph.replay()
+            return out_buf
+
+        replay.graph = graph
+        return replay
+
     # -- the reference's Session contract ---------------------------------------------------
     def run(self, fetches, feed_dict):
         """sess.run("encoder/output:0", {"real_model_in:0": vox, "view_name:0": pose,
