@@ -183,6 +183,14 @@ int rn_conv3d_transpose_fwd_train(const float* x, const float* w_packed, const f
                                   int B, int H, int W, int D, int Cin, int Cout,
                                   int ksize, int stride, int act, void* stream);
 
+/* fully_connected (tools/layer_util.py:311-343; the texture decoder, RenderNet_Texture_Face_Normal.py:34-46) with
+ * the pre-activation saved, and its backward: dw [in,out] += x^T dz (ACCUMULATED; zero it first), dx [B,in] = dz w^T.
+ * dx or dw may be NULL.  Bias / PReLU gradients come from rn_epilogue_bwd on rows [B,out]. */
+int rn_fully_connected_fwd_train(const float* x, const float* w, const float* bias, const float* alpha,
+                                 float* y, float* preact, int B, int in_features, int out_features, int act, void* stream);
+int rn_fully_connected_bwd(const float* x, const float* w, const float* dz, float* dx, float* dw,
+                           int B, int in_features, int out_features, void* stream);
+
 /* Backward of the fused epilogue  y = sigmoid?( prelu?(z) + residual ),  z = conv + bias, rows [M,C]:
  *   dt = dy * y*(1-y) if act has RN_ACT_SIGMOID (needs y);  the residual's gradient is dt;
  *   dz = dt * (z > 0 ? 1 : alpha[c]) and dalpha[c] += sum_rows dt*min(z,0) if RN_ACT_PRELU (needs z);

@@ -9,10 +9,16 @@ from .rendernet import res_block_2d, res_block_3d, _g
 
 
 def decoder_texture(z, w, tex_res=32, c0=4):
-    """:34-46."""
-    t = "texture_encoder/"
+    """:34-46 (NumPy in/out)."""
     with torch.no_grad():
-        zP = L.prelu(L.fully_connected(torch.from_numpy(np.asarray(z, np.float32)),
+        return decoder_texture_torch(torch.from_numpy(np.asarray(z, np.float32)), w, tex_res, c0).numpy()
+
+
+def decoder_texture_torch(z, w, tex_res=32, c0=4):
+    """:34-46 on torch tensors (differentiable when `w` holds tensors that require grad)."""
+    t = "texture_encoder/"
+    if True:
+        zP = L.prelu(L.fully_connected(z,
                                        _g(w, t + "e_tex_fc1/fully_connected/weights"),
                                        _g(w, t + "e_tex_fc1/fully_connected/biases")), _g(w, t + "e_tex_fc1/alpha"))
         x = zP.reshape(zP.shape[0], tex_res, tex_res, tex_res, c0)
@@ -22,7 +28,7 @@ def decoder_texture(z, w, tex_res=32, c0=4):
                                        _g(w, t + "e_tex_conv1/conv3d_transpose/biases"), (2, 2, 2)), _g(w, t + "e_tex_conv1/alpha"))
         x = L.prelu(L.conv3d(x, _g(w, t + "e_tex_conv2/conv3d/weights"), _g(w, t + "e_tex_conv2/conv3d/biases"), (1, 1, 1)),
                     _g(w, t + "e_tex_conv2/alpha"))
-        return x.numpy()
+        return x
 
 
 HEAD_SCOPES = {
@@ -34,15 +40,22 @@ HEAD_SCOPES = {
 
 
 def rendernet_texture_forward(models_in, w, n_res1=10, n_res2=10, n_res3=5, taps=None):
-    """:48-147.  models_in [B,H,W,D,5] -> (image, normal), each [B,4H,4W,3]."""
+    """:48-147.  models_in [B,H,W,D,5] -> (image, normal), each [B,4H,4W,3] (NumPy in/out)."""
+    with torch.no_grad():
+        x = torch.from_numpy(np.ascontiguousarray(models_in, dtype=np.float32))
+        a, b = rendernet_texture_forward_torch(x, w, n_res1, n_res2, n_res3, taps)
+        return a.numpy(), b.numpy()
+
+
+def rendernet_texture_forward_torch(x, w, n_res1=10, n_res2=10, n_res3=5, taps=None):
+    """The two-head graph on torch tensors (differentiable when `w` holds tensors that require grad)."""
     def tap(n, t):
         if taps is not None:
-            taps[n] = t.numpy().copy()
+            taps[n] = t.detach().numpy().copy()
         return t
 
     e = "encoder/"
-    with torch.no_grad():
-        x = torch.from_numpy(np.ascontiguousarray(models_in, dtype=np.float32))
+    if True:
         for name, s in (("e_conv1", (2, 2, 2)), ("e_conv2", (1, 1, 2)), ("e_conv3", (1, 1, 1))):
             p = e + "%s/%s/" % (name, name)
             x = L.prelu(L.conv3d(x, _g(w, p + "weights"), _g(w, p + "biases"), s), _g(w, e + name + "/alpha"))
@@ -75,7 +88,7 @@ def rendernet_texture_forward(models_in, w, n_res1=10, n_res2=10, n_res3=5, taps
             vs, cs = sc[4]
             logits = L.conv2d_transpose(x, _g(w, p + "%s/%s/weights" % (vs, cs)), _g(w, p + "%s/%s/biases" % (vs, cs)), (1, 1))
             tap(head.lower() + "_logits", logits)
-            outs.append(tap(head.lower(), L.sigmoid(logits)).numpy())
+            outs.append(tap(head.lower(), L.sigmoid(logits)))
         return outs[0], outs[1]
 
 

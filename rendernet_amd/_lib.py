@@ -39,6 +39,8 @@ SIGNATURES = {
     "rn_conv2d_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 5 + [_ip, _ip, _c_int, _c_vp]),
     "rn_conv2d_transpose_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 8 + [_c_vp]),
     "rn_conv3d_transpose_fwd_train": (_c_int, [_c_vp] * 7 + [_c_int] * 9 + [_c_vp]),
+    "rn_fully_connected_fwd_train": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp]),
+    "rn_fully_connected_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
     "rn_epilogue_bwd": (_c_int, [_c_vp] * 7 + [ctypes.c_size_t, _c_int, _c_int, _c_vp]),
     "rn_conv3d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
     "rn_conv2d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),

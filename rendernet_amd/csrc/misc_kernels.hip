@@ -105,7 +105,8 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
 template <int BC>
 __global__ __launch_bounds__(256)
 void fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-               const float* __restrict__ alpha, float* __restrict__ y, int B, int in_f, int out_f, int act)
+               const float* __restrict__ alpha, float* __restrict__ y, float* __restrict__ preact,
+               int B, int in_f, int out_f, int act)
 {
     const int col = blockIdx.x * 256 + threadIdx.x;
     const int b0 = blockIdx.y * BC;
@@ -125,6 +126,7 @@ void fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
     for (int i = 0; i < BC; ++i) {
         if (b0 + i < B) {
             float v = acc[i] + bv;
+            if (preact) preact[(size_t)(b0 + i) * out_f + col] = v;
             if (act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
             if (act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
             y[(size_t)(b0 + i) * out_f + col] = v;
@@ -138,9 +140,85 @@ extern "C" int rn_fully_connected_fwd(const float* x, const float* w, const floa
     if (!x || !w || !y || B < 1 || in_features < 1 || out_features < 1)
         return rn_set_error(RN_E_INVALID, "rn_fully_connected_fwd: bad argument");
     dim3 grid((out_features + 255) / 256, (B + 7) / 8);
-    hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, alpha, y, B,
+    hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, alpha, y, (float*)nullptr, B,
                        in_features, out_features, act);
     return rn_check_launch("fully_connected");
+}
+
+extern "C" int rn_fully_connected_fwd_train(const float* x, const float* w, const float* bias, const float* alpha,
+                                            float* y, float* preact, int B, int in_features, int out_features, int act,
+                                            void* stream)
+{
+    if (!x || !w || !y || B < 1 || in_features < 1 || out_features < 1)
+        return rn_set_error(RN_E_INVALID, "rn_fully_connected_fwd_train: bad argument");
+    dim3 grid((out_features + 255) / 256, (B + 7) / 8);
+    hipLaunchKernelGGL(fc_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, alpha, y, preact, B,
+                       in_features, out_features, act);
+    return rn_check_launch("fully_connected_train");
+}
+
+// Backward of y = x @ w (tools/layer_util.py:311-343; bias / PReLU go through rn_epilogue_bwd):
+//   dw[k][col] += sum_b x[b][k] * dz[b][col]   one thread per column, the batch kept in registers BC rows at a time
+//   dx[b][k]    = sum_col dz[b][col] * w[k][col]  one workgroup per (k, 8 batch rows), reduced over the columns
+template <int BC>
+__global__ __launch_bounds__(256)
+void fc_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
+                     int B, int in_f, int out_f)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= out_f) return;
+    for (int b0 = 0; b0 < B; b0 += BC) {
+        float g[BC];
+#pragma unroll
+        for (int i = 0; i < BC; ++i) g[i] = (b0 + i < B) ? dz[(size_t)(b0 + i) * out_f + col] : 0.f;
+        for (int k = 0; k < in_f; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < BC; ++i)
+                if (b0 + i < B) s = fmaf(x[(size_t)(b0 + i) * in_f + k], g[i], s);
+            dw[(size_t)k * out_f + col] += s;             // this thread owns column `col` of dw
+        }
+    }
+}
+
+template <int BC>
+__global__ __launch_bounds__(256)
+void fc_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
+                     int B, int in_f, int out_f)
+{
+    __shared__ float red[4][BC];
+    const int k = blockIdx.x, b0 = blockIdx.y * BC;
+    float acc[BC];
+#pragma unroll
+    for (int i = 0; i < BC; ++i) acc[i] = 0.f;
+    for (int col = threadIdx.x; col < out_f; col += 256) {
+        const float wv = w[(size_t)k * out_f + col];
+#pragma unroll
+        for (int i = 0; i < BC; ++i)
+            if (b0 + i < B) acc[i] = fmaf(dz[(size_t)(b0 + i) * out_f + col], wv, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < BC; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < BC && b0 + threadIdx.x < B)
+        dx[(size_t)(b0 + threadIdx.x) * in_f + k] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+extern "C" int rn_fully_connected_bwd(const float* x, const float* w, const float* dz, float* dx, float* dw,
+                                      int B, int in_features, int out_features, void* stream)
+{
+    if (!dz || B < 1 || in_features < 1 || out_features < 1 || (!dx && !dw))
+        return rn_set_error(RN_E_INVALID, "rn_fully_connected_bwd: bad argument");
+    if ((dw && !x) || (dx && !w)) return rn_set_error(RN_E_INVALID, "rn_fully_connected_bwd: dw needs x, dx needs w");
+    hipStream_t st = (hipStream_t)stream;
+    if (dw) hipLaunchKernelGGL(fc_wgrad_kernel<8>, dim3((out_features + 255) / 256), dim3(256), 0, st, x, dz, dw, B, in_features, out_features);
+    if (dx) hipLaunchKernelGGL(fc_dgrad_kernel<8>, dim3(in_features, (B + 7) / 8), dim3(256), 0, st, dz, w, dx, B, in_features, out_features);
+    return rn_check_launch("fully_connected_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------

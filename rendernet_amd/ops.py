@@ -360,21 +360,49 @@ def projection(x, pw, bias, alpha):
     return _Projection.apply(x, pw, bias, alpha)
 
 
-class _FC(_ForwardOnly):
+class _FC(torch.autograd.Function):
+    """y = prelu?(x @ w + b) (tools/layer_util.py:311-343); backward through rn_epilogue_bwd + rn_fully_connected_bwd."""
+
     @staticmethod
-    def forward(ctx, x, w, bias, alpha):
+    def forward(ctx, x, w, bias, alpha, anchor):
         _chk_dev(x, w, bias, alpha)
         B, fin = x.shape
         fout = w.shape[1]
+        train = anchor is not None
         y = torch.empty((B, fout), dtype=torch.float32, device=x.device)
-        L.check(L.lib().rn_fully_connected_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(alpha), L.ptr(y),
-                                               B, fin, fout, _act_code(alpha, False), L.stream_ptr()),
-                "rn_fully_connected_fwd")
+        z = torch.empty_like(y) if (train and alpha is not None) else None
+        act = _act_code(alpha, False)
+        L.check(L.lib().rn_fully_connected_fwd_train(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(alpha), L.ptr(y), L.ptr(z),
+                                                     B, fin, fout, act, L.stream_ptr()), "rn_fully_connected_fwd")
+        if train:
+            ctx.save_for_backward(x, z)
+            ctx.cfg = (w, bias, alpha, act, TRAIN)
         return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z = ctx.saved_tensors
+        w, bias, alpha, act, tc = ctx.cfg
+        lib, st = L.lib(), L.stream_ptr()
+        dy = dy.contiguous()
+        B, fin = x.shape
+        fout = w.shape[1]
+        dz = torch.empty_like(dy) if act else dy
+        if act or bias is not None:
+            L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), None, L.ptr(alpha), L.ptr(dz) if act else None,
+                                        L.ptr(tc.grad(bias)) if bias is not None else None,
+                                        L.ptr(tc.grad(alpha)) if alpha is not None else None, B, fout, act, st),
+                    "rn_epilogue_bwd")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        L.check(lib.rn_fully_connected_bwd(L.ptr(x), L.ptr(w), L.ptr(dz), L.ptr(dx), L.ptr(tc.grad(w)), B, fin, fout, st),
+                "rn_fully_connected_bwd")
+        tc.ready(w, bias, alpha)
+        return dx, None, None, None, None
 
 
 def fully_connected(x, w, bias=None, alpha=None):
-    return _FC.apply(x.contiguous().float(), w.contiguous().float(), bias, alpha)
+    anchor = TRAIN.anchor if (TRAIN is not None and torch.is_grad_enabled()) else None
+    return _FC.apply(x.contiguous().float(), w.contiguous().float(), bias, alpha, anchor)
 
 
 def prelu(x, alpha):

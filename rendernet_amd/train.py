@@ -104,18 +104,18 @@ class GradBuckets:
         self.handles = []
 
 
-class Trainer:
-    """Holds parameters / gradients / Adam moments of the Phong-shader net on one GPU and runs training
-    steps.  With torch.distributed initialised every rank holds a full replica and a shard of the batch."""
+class _TrainerBase:
+    """Parameters / gradients / Adam moments of one net on one GPU in four flat buffers, the gradient buckets and the
+    optimiser step.  With torch.distributed initialised every rank holds a full replica and a shard of the batch."""
 
-    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, e_eta=1e-5, decay_steps=100000,
+    def __init__(self, spec, weights, device="cuda", seed=1234, e_eta=1e-5, decay_steps=100000,
                  beta1=0.5, beta2=0.999, epsilon=1e-8, keep_prob=1.0, bucket_mb=100.0, group=None):
-        self.spec = (spec or ShaderSpec()).check()
+        self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
-            raise RuntimeError("rendernet_amd.Trainer needs a HIP device; there is no CPU training path")
+            raise RuntimeError("rendernet_amd trainers need a HIP device; there is no CPU training path")
         self.store = V.VariableStore(self.device, seed)
-        self.store.load_state_dict(weights if weights is not None else init_shader_weights(self.spec, seed))
+        self.store.load_state_dict(weights)
         self.names = list(self.store.vars.keys())
         self.param, self.layout = self.store.flatten(self.names)
         self.grad = torch.zeros_like(self.param)
@@ -133,6 +133,47 @@ class Trainer:
         self.keep_prob = float(keep_prob)
         self.global_step = 0
         self.loss_buf = torch.zeros(1, dtype=torch.float64, device=self.device)
+
+    def _loss_grad(self, pred, target, global_batch, mse):
+        """Loss kernel: value accumulated into self.loss_buf, returns d(loss)/d(pred)."""
+        tgt = target.contiguous()
+        dpred = torch.empty_like(pred)
+        n = pred.numel()
+        divisor = float(global_batch) if not mse else float(n // pred.shape[0] * global_batch)
+        L.check(L.lib().rn_loss_fwd_bwd(L.ptr(pred), L.ptr(tgt), L.ptr(dpred), self.loss_buf.data_ptr(), n, divisor,
+                                        1 if mse else 0, L.stream_ptr()), "rn_loss_fwd_bwd")
+        return dpred
+
+    def apply_gradients(self):
+        self.global_step += 1
+        lr = exponential_decay(self.e_eta, self.global_step - 1, self.decay_steps)
+        lr_t = adam_lr_t(lr, self.global_step, self.beta1, self.beta2)
+        L.check(L.lib().rn_adam_step(L.ptr(self.param), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.param.numel(),
+                                     lr_t, self.beta1, self.beta2, self.epsilon, 1.0, L.stream_ptr()), "rn_adam_step")
+        self.store.repack_all()
+
+    def _begin_step(self):
+        self.grad.zero_()
+        self.loss_buf.zero_()
+        self.buckets.reset()
+
+    def _finish_step(self):
+        self.buckets.finish()
+        if self.world > 1:
+            dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.apply_gradients()
+        return self.loss_buf[0].clone()
+
+    def state_dict(self):
+        return self.store.state_dict()
+
+
+class Trainer(_TrainerBase):
+    """The Phong-shader net (RenderNet_Shader.py): crop -> RenderNet -> BCE (greyscale) | MSE (RGB) -> Adam."""
+
+    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, **kw):
+        spec = (spec or ShaderSpec()).check()
+        super().__init__(spec, weights if weights is not None else init_shader_weights(spec, seed), device, seed, **kw)
         self.mse = self.spec.out_ch != 1                      # RenderNet_Shader.py:159-163
 
     # -- pieces (also used one by one by the parity tests) ----------------------------------
@@ -166,21 +207,7 @@ class Trainer:
 
     def loss_and_backward(self, pred, target_patch, global_batch):
         """Loss kernel (value accumulated into self.loss_buf, gradient w.r.t. pred) + the HIP backward."""
-        tgt = target_patch.contiguous()
-        dpred = torch.empty_like(pred)
-        n = pred.numel()
-        divisor = float(global_batch) if not self.mse else float(n // pred.shape[0] * global_batch)
-        L.check(L.lib().rn_loss_fwd_bwd(L.ptr(pred), L.ptr(tgt), L.ptr(dpred), self.loss_buf.data_ptr(), n, divisor,
-                                        1 if self.mse else 0, L.stream_ptr()), "rn_loss_fwd_bwd")
-        pred.backward(dpred)
-
-    def apply_gradients(self):
-        self.global_step += 1
-        lr = exponential_decay(self.e_eta, self.global_step - 1, self.decay_steps)
-        lr_t = adam_lr_t(lr, self.global_step, self.beta1, self.beta2)
-        L.check(L.lib().rn_adam_step(L.ptr(self.param), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.param.numel(),
-                                     lr_t, self.beta1, self.beta2, self.epsilon, 1.0, L.stream_ptr()), "rn_adam_step")
-        self.store.repack_all()
+        pred.backward(self._loss_grad(pred, target_patch, global_batch, self.mse))
 
     # -- one step -----------------------------------------------------------------------------
     def step(self, voxels, poses, targets, patch_size=None, start_point=None, global_batch=None, net_in=None):
@@ -189,18 +216,60 @@ class Trainer:
         Returns the loss as a 0-d float64 device tensor (global mean; identical on all ranks)."""
         b = int(targets.shape[0])
         gb = int(global_batch) if global_batch is not None else b * self.world
-        self.grad.zero_()
-        self.loss_buf.zero_()
-        self.buckets.reset()
+        self._begin_step()
         pred, (r, c, p, _) = self.forward(voxels, poses, patch_size, start_point, net_in=net_in)
         tgt = torch.as_tensor(targets, dtype=torch.float32).to(self.device)
         tgt = tgt[:, 4 * r:4 * (r + p), 4 * c:4 * (c + p), :]          # tools/model_util.py:99
         self.loss_and_backward(pred, tgt, gb)
-        self.buckets.finish()
-        if self.world > 1:
-            dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, group=self.group)
-        self.apply_gradients()
-        return self.loss_buf[0].clone()
+        return self._finish_step()
 
-    def state_dict(self):
-        return self.store.state_dict()
+
+class TextureTrainer(_TrainerBase):
+    """The texture + normal net (RenderNet_Texture_Face_Normal.py:152-186): geometry and the decoded texture
+    volume are resampled, cropped with ONE window (tools/model_util.py:103-152), concatenated and rendered by the
+    two-head net; loss = MSE(image) + MSE(normal) (:182-183); Adam as for the shader.  The texture decoder is
+    trained THROUGH the resampler (rn_resample_affine_bwd scatters the gradient back into the decoded volume)."""
+
+    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, **kw):
+        from .texture import TextureSpec, init_texture_weights
+        spec = (spec or TextureSpec()).check()
+        super().__init__(spec, weights if weights is not None else init_texture_weights(spec, seed), device, seed, **kw)
+
+    def forward(self, voxels, textures, poses, patch_size=None, start_point=None, taps=None):
+        from .texture import decoder_texture, RenderNetTexture
+        s = self.spec
+        vox = torch.as_tensor(voxels, dtype=torch.float32).to(self.device)
+        tex = torch.as_tensor(textures, dtype=torch.float32).to(self.device)
+        pose = torch.as_tensor(poses, dtype=torch.float32).to(self.device)
+        p = int(patch_size) if patch_size is not None else s.new_size
+        if start_point is None:
+            start_point = torch.randint(0, s.new_size - p + 1, (2,)).tolist() if p != s.new_size else (0, 0)
+        window = (int(start_point[0]), int(start_point[1]), p, p)
+        old = V._default
+        V.set_default_store(self.store)
+        try:
+            with ops.training(self.ctx):
+                geo = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
+                tex_vol = decoder_texture(tex, s, taps)
+                tex_rot = rotation_resampling_to_image(tex_vol, pose, size=s.size, new_size=s.new_size, window=window)
+                net_in = torch.cat([geo, tex_rot], dim=4)
+                if taps is not None:
+                    taps["net_in"] = net_in
+                img, nrm = RenderNetTexture(net_in, prob=self.keep_prob, spec=s, taps=taps)
+        finally:
+            V._default = old
+        return img, nrm, window
+
+    def loss_and_backward(self, img, nrm, img_patch, nrm_patch, global_batch):
+        d_img = self._loss_grad(img, img_patch, global_batch, True)
+        d_nrm = self._loss_grad(nrm, nrm_patch, global_batch, True)
+        torch.autograd.backward([img, nrm], [d_img, d_nrm])
+
+    def step(self, voxels, textures, poses, images, normals, patch_size=None, start_point=None, global_batch=None):
+        b = int(images.shape[0])
+        gb = int(global_batch) if global_batch is not None else b * self.world
+        self._begin_step()
+        img, nrm, (r, c, p, _) = self.forward(voxels, textures, poses, patch_size, start_point)
+        crop = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.device)[:, 4 * r:4 * (r + p), 4 * c:4 * (c + p), :]
+        self.loss_and_backward(img, nrm, crop(images), crop(normals), gb)
+        return self._finish_step()

@@ -107,3 +107,24 @@ def test_host_schedule_helpers():
     assert all(hi - lo <= 64 or len(ns) == 1 for lo, hi, ns in b)
     spans = sorted((lo, hi) for lo, hi, _ in b)
     assert spans[0][0] == 0 and spans[-1][1] == off and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+
+
+def test_torch_resampler_equals_numpy_oracle_and_is_differentiable():
+    """oracle/texture_train.py::resample_torch (the differentiable restatement used for the texture net's training
+    oracle) reproduces oracle/resample.py bit for bit, and its gradient is the scatter of oracle/resample.py's backward."""
+    from oracle import resample as OR
+    from oracle import texture_train as TT
+    rng = np.random.default_rng(2)
+    S, N, C = 8, 16, 3
+    vox = rng.standard_normal((2, S, S, S, C)).astype(np.float32)
+    M = OR.inverse_affine(np.array([[1.0, 0.6, 0.9], [2.5, 0.2, 1.2]], np.float32), S, N)
+    for mode in ("tf", "ordered"):
+        got = TT.resample_torch(torch.from_numpy(vox), M, N, mode).numpy()
+        assert np.array_equal(got, OR.resampling_affine(vox, M, N, mode))
+    vt = torch.from_numpy(vox).requires_grad_(True)
+    dout = rng.standard_normal((2, N, N, N, C)).astype(np.float32)
+    TT.resample_torch(vt, M, N, "ordered").backward(torch.from_numpy(dout))
+    dv, _ = OR.resampling_affine_bwd(vox, M, dout, N)
+    assert np.abs(vt.grad.numpy() - dv).max() <= 1e-4 * np.abs(dv).max()
+    img = TT.to_image_layout(torch.from_numpy(vox)).numpy()
+    assert np.array_equal(img, OR.transform_voxel_to_match_image(vox))
