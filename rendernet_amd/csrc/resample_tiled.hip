@@ -17,12 +17,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #pragma clang fp contract(off)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int VROWS_MAX = 512;         // rows (z,y) of the voxel-bitmap box kept in LDS (two per thread)
+constexpr int VROWS_MAX = 544;         // rows (z,y) of the voxel-bitmap box kept in LDS (<= 512 used: two per thread;
+                                       // 8 x 544 words also hold the padded output staging of a sub-column)
 constexpr int MAX_KT = 32;             // tiles per axis (N <= 256)
 constexpr int MAT_STRIDE = 12;         // per item: the inverse 3x4 (floats)
 
@@ -168,6 +170,7 @@ struct TiledArgs {
     int B, S, N, NC;
     int h0, w0, ph, pw, image_layout;
     int debug;               // RN_RS_DEBUG, exact results either way: 3 = no per-sample bit test, 5 = no occupancy-grid fast path
+    int ratio;               // sampler workgroups per fill workgroup in the interleaved launch order
     int nfill, nsub;         // fill rows (B*ph) and sampler sub-columns (B * ph/8 * pw/8 * ceil(N/32)) of the main launch
 };
 
@@ -254,7 +257,7 @@ void resample_classify_kernel(const TiledArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. main.  Two kinds of workgroups interleaved in one launch (block id % 9 == 0: fill, else sampler):
+// 3. main.  Two kinds of workgroups interleaved in one launch (one fill workgroup, then `ratio` samplers, ...):
 //   fill: one (b,i) row of the output (pw*N floats, 64 KiB) zero-filled with 16-B stores, skipping the 128-B
 //     line segments of sub-columns that hold a candidate tile.  One tiny load, then stores only.
 //   sampler: one (b, ti, tj, kq) sub-column = four 8^3 tiles; exits at once if none is a candidate.  Strictly
@@ -269,18 +272,28 @@ void resample_classify_kernel(const TiledArgs a)
 //          the prepare pass) with taps read from the bitmap itself, otherwise gathered from L1/L2;
 //       d. 16-B stores (results of four depth-adjacent lanes are combined first).
 // ------------------------------------------------------------------------------------------------
-template <int CT>
+// f(integral_constant<int,0>{}), ..., f(integral_constant<int,TPW-1>{}): compile-time tile indices keep the per-tile
+// arrays in registers
+template <class F, int... I>
+__device__ __forceinline__ void for_each_tile(F& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// TPW = depth-adjacent tiles per sampler workgroup (8: measured 4 -> 65 us, 8 -> 57-59 us, 16 -> 83 us for the main
+// launch at B=24: fatter workgroups amortise the load -> barrier -> store chain, too fat ones leave too few in flight)
+template <int CT, int TPW>
 __global__ __launch_bounds__(256)
 void resample_main_kernel(const TiledArgs a)
 {
-    __shared__ unsigned vrows[4][VROWS_MAX];   // bit x of row r = voxel bx0 + x of the box row (32-bit window)
+    __shared__ __attribute__((aligned(16))) unsigned vrows[TPW][VROWS_MAX];   // bit x of row r = voxel bx0 + x of the box row (32-bit window)
     __shared__ unsigned rowmask[MAX_KT];
     const int tid = threadIdx.x;
     const int N = a.N, S = a.S;
     const int VW = S >= 32 ? S >> 5 : 1;
-    const int nti = a.ph >> 3, ntj = a.pw >> 3, nkt = N >> 3, nkq = (nkt + 3) >> 2;
-    // interleaved 1:8 -- measured 65 us; all samplers first 81 us, all fill first 84 us
-    const int grp = blockIdx.x / 9, rem = blockIdx.x % 9;
+    const int nti = a.ph >> 3, ntj = a.pw >> 3, nkt = N >> 3, nkq = (nkt + TPW - 1) / TPW;
+    // interleaved 1:ratio (measured at 1:8 with 4-tile sub-columns: 65 us; all samplers first 81 us, all fill first 84 us)
+    const int grp = blockIdx.x / (a.ratio + 1), rem = blockIdx.x % (a.ratio + 1);
 
     if (rem == 0) {
         // ---------------- fill ----------------
@@ -297,18 +310,18 @@ void resample_main_kernel(const TiledArgs a)
             const int kt = (CT == 1) ? (w >> 1) : (w >> 3);
             // a sub-column (4 tiles = one 128-B line per (i,j) at C=1) with ANY candidate belongs to its sampler
             // workgroup entirely, so that every line is written once, in full, by one workgroup
-            if (!((rowmask[j >> 3] >> (kt & ~3)) & 15u)) op[u] = z4;
+            if (!((rowmask[j >> 3] >> (kt / TPW * TPW)) & ((1u << TPW) - 1u))) op[u] = z4;
         }
         return;
     }
 
     // ---------------- sampler ----------------
-    int id = grp * 8 + rem - 1;
+    int id = grp * a.ratio + rem - 1;
     if (id >= a.nsub) return;
     const int kq = id % nkq; id /= nkq;
     const int tj = id % ntj; id /= ntj;
     const int ti = id % nti; const int b = id / nti;
-    const unsigned cmask = (a.ws_colmask[((size_t)b * nti + ti) * ntj + tj] >> (4 * kq)) & 15u;   // uniform
+    const unsigned cmask = (a.ws_colmask[((size_t)b * nti + ti) * ntj + tj] >> (TPW * kq)) & ((1u << TPW) - 1u);   // uniform
     if (cmask == 0u) return;
     const int i0 = a.h0 + ti * 8, j0 = a.w0 + tj * 8;
 
@@ -321,11 +334,11 @@ void resample_main_kernel(const TiledArgs a)
     const bool binary = CT == 1 && nonbin == 0u && a.debug != 5;
 
     // ---- a. the boxes the classifier recorded (uniform addresses -> scalar loads, no barrier) ----
-    int tinfo[4][8];
+    int tinfo[TPW][8];
     {
-        const uint2* bp = a.ws_box + (((size_t)b * nti + ti) * ntj + tj) * MAX_KT + kq * 4;
+        const uint2* bp = a.ws_box + (((size_t)b * nti + ti) * ntj + tj) * MAX_KT + kq * TPW;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < TPW; ++tt) {
             const uint2 bx = bp[tt];
             tinfo[tt][1] = bx.x & 255; tinfo[tt][2] = (bx.x >> 8) & 255; tinfo[tt][3] = (bx.x >> 16) & 255; tinfo[tt][4] = bx.x >> 24;
             tinfo[tt][5] = bx.y & 255; tinfo[tt][6] = (bx.y >> 8) & 255;
@@ -335,8 +348,8 @@ void resample_main_kernel(const TiledArgs a)
     // ---- b. voxel-bitmap rows of the candidate tiles: all loads first, then LDS ----
     // (the per-tile steps are generic lambdas instantiated with a compile-time tile index: with runtime-indexed
     //  loops the compiler kept rv / vt / res in scratch memory -- loads and stores behind our own stores)
-    unsigned rv[4][2];
-    bool vt[4];
+    unsigned rv[TPW][2];
+    bool vt[TPW];
     auto load_rows = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         rv[tt][0] = 0u; rv[tt][1] = 0u;
@@ -346,7 +359,7 @@ void resample_main_kernel(const TiledArgs a)
             const int bz0 = tinfo[tt][5], bz1 = tinfo[tt][6];
             const int ny = by1 - by0 + 1, rows = ny * (bz1 - bz0 + 1);
             const int xw0 = min(bx0 >> 5, max(VW - 2, 0));
-            vt[tt] = rows <= VROWS_MAX && (bx1 - xw0 * 32) < 64 && (bx1 - bx0) < 32 && a.debug != 3;
+            vt[tt] = rows <= 512 && (bx1 - xw0 * 32) < 64 && (bx1 - bx0) < 32 && a.debug != 3;
             if (vt[tt]) {
                 const float rny = 1.0f / (float)ny;
 #pragma unroll
@@ -363,8 +376,7 @@ void resample_main_kernel(const TiledArgs a)
             }
         }
     };
-    load_rows(std::integral_constant<int, 0>{}); load_rows(std::integral_constant<int, 1>{});
-    load_rows(std::integral_constant<int, 2>{}); load_rows(std::integral_constant<int, 3>{});
+    for_each_tile(load_rows, std::make_integer_sequence<int, TPW>{});
     auto put_rows = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         if (vt[tt]) {
@@ -372,13 +384,12 @@ void resample_main_kernel(const TiledArgs a)
             vrows[tt][tid + 256] = rv[tt][1];
         }
     };
-    put_rows(std::integral_constant<int, 0>{}); put_rows(std::integral_constant<int, 1>{});
-    put_rows(std::integral_constant<int, 2>{}); put_rows(std::integral_constant<int, 3>{});
+    for_each_tile(put_rows, std::make_integer_sequence<int, TPW>{});
     __syncthreads();
 
     // ---- c. samples ----
     const float* vb = a.vox + (size_t)b * S * S * S * CT;
-    float res[4][2][CT];
+    float res[TPW][2][CT];
     auto sample_tile = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
 #pragma unroll
@@ -388,7 +399,7 @@ void resample_main_kernel(const TiledArgs a)
         if (!((cmask >> tt) & 1u)) return;                                 // uniform
         const int bx0 = tinfo[tt][1], by0 = tinfo[tt][3], by1 = tinfo[tt][4], bz0 = tinfo[tt][5];
         const int ny = by1 - by0 + 1;
-        const int k0 = (kq * 4 + tt) * 8;
+        const int k0 = (kq * TPW + tt) * 8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
@@ -441,33 +452,42 @@ void resample_main_kernel(const TiledArgs a)
             }
         }
     };
-    sample_tile(std::integral_constant<int, 0>{}); sample_tile(std::integral_constant<int, 1>{});
-    sample_tile(std::integral_constant<int, 2>{}); sample_tile(std::integral_constant<int, 3>{});
+    for_each_tile(sample_tile, std::make_integer_sequence<int, TPW>{});
 
-    // ---- d. stores (nothing is loaded after this point) ----
-    const size_t patch_base = (((size_t)b * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
-    auto store_tile = [&](auto TT) {
+    // ---- d. stores (nothing is loaded after this point).  The sub-column is 64 (i,j) lines of TPW*8 consecutive depth
+    // samples; results go through LDS so that every wave instruction writes whole contiguous lines (16 lanes x 16 B
+    // per line at C=1): written straight from the sampling layout (32-B pieces at a 512-B stride) this kernel's
+    // stores ran at 1.5-2.5 TB/s against 7.4 TB/s for the fill workgroups' 1-KiB-contiguous stores. ----
+    constexpr int LINE = TPW * 8 * CT;                         // floats per (i,j) line of the sub-column
+    constexpr int LSTR = LINE + 4;                             // padded line stride (LDS banks), still 16-B aligned
+    float* obuf = reinterpret_cast<float*>(&vrows[0][0]);      // the bitmap rows are dead: reuse their LDS
+    static_assert(sizeof(vrows) >= 64 * LSTR * sizeof(float) || CT > 1, "output staging fits in the bitmap rows");
+    __shared__ __attribute__((aligned(16))) float obuf4[(CT > 1) ? 64 * LSTR : 4];
+    float* ob = (CT > 1) ? obuf4 : obuf;
+    __syncthreads();                                           // everyone is done reading vrows
+    auto stage_tile = [&](auto TT) {
         constexpr int tt = decltype(TT)::value;
-        const int kt = kq * 4 + tt;                                        // all four tiles, zeros where not a candidate
-        if (kt >= nkt) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q;
-            const int kl = p & 7, jl = (p >> 3) & 7, il = p >> 6;
-            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + kt * 8 + kl) * CT;
-            if (CT == 1) {
-                // four consecutive depth samples sit on four consecutive lanes: gather them into the first
-                const float r0_ = res[tt][q][0];
-                const float r1 = __shfl_down(r0_, 1), r2 = __shfl_down(r0_, 2), r3 = __shfl_down(r0_, 3);
-                if ((tid & 3) == 0) *reinterpret_cast<float4*>(op) = make_float4(r0_, r1, r2, r3);
-            } else {
-                *reinterpret_cast<float4*>(op) = make_float4(res[tt][q][0], res[tt][q][CT > 1 ? 1 : 0],
-                                                             res[tt][q][CT > 2 ? 2 : 0], res[tt][q][CT > 3 ? 3 : 0]);
-            }
+            const int kl = p & 7, line = p >> 3;               // line = il*8 + jl
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) ob[line * LSTR + (tt * 8 + kl) * CT + cc] = res[tt][q][cc];
         }
     };
-    store_tile(std::integral_constant<int, 0>{}); store_tile(std::integral_constant<int, 1>{});
-    store_tile(std::integral_constant<int, 2>{}); store_tile(std::integral_constant<int, 3>{});
+    for_each_tile(stage_tile, std::make_integer_sequence<int, TPW>{});
+    __syncthreads();
+    const size_t patch_base = (((size_t)b * a.ph + ti * 8) * a.pw + tj * 8) * N;   // in voxels
+    const int kvalid = min(TPW, nkt - kq * TPW) * 8 * CT;      // floats of the line that exist (N may end mid sub-column)
+    constexpr int UPL = LINE / 4;                              // 16-B units per line
+    for (int u = tid; u < 64 * UPL; u += 256) {
+        const int line = u / UPL, w = (u - line * UPL) * 4;
+        if (w < kvalid) {
+            const int il = line >> 3, jl = line & 7;
+            float* op = a.out + (patch_base + ((size_t)il * a.pw + jl) * N + (size_t)kq * TPW * 8) * CT + w;
+            *reinterpret_cast<float4*>(op) = *reinterpret_cast<const float4*>(ob + line * LSTR + w);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,16 +547,22 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
     if (rc != RN_OK) return rc;
     static const int dbg = getenv("RN_RS_DEBUG") ? atoi(getenv("RN_RS_DEBUG")) : 0;
     const long long ncol = (long long)B * (ph / 8) * (pw / 8);
-    const int nkq = (N / 8 + 3) / 4;
+    const int TPW = 8;
+    const int nkq = (N / 8 + TPW - 1) / TPW;
     const long long nfill = (long long)B * ph, nsub = ncol * nkq;
-    const long long groups = nfill > (nsub + 7) / 8 ? nfill : (nsub + 7) / 8;
-    if (groups * 9 > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
+    // sampler ids per fill id in the launch order: twice the natural count (the surplus ids exit at once) -- measured
+    // at B=24: 4 -> 63 us, 6 -> 58, 8 -> 59, 12 -> 60, 16 -> 65 (fill workgroups spaced further apart start later,
+    // closer together they crowd the samplers out of the CUs)
+    long long ratio = 2 * ((nsub + nfill - 1) / nfill);
+    if (ratio < 1) ratio = 1;
+    const long long groups = nfill > (nsub + ratio - 1) / ratio ? nfill : (nsub + ratio - 1) / ratio;
+    if (groups * (ratio + 1) > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
     TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, (int)pgrid.x, ws_colmask, ws_box, out, B, S, N, NC, h0, w0, ph, pw,
-                image_layout, dbg, (int)nfill, (int)nsub};
+                image_layout, dbg, (int)ratio, (int)nfill, (int)nsub};
     hipLaunchKernelGGL(resample_classify_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, st, a);
     rc = rn_check_launch("resample_classify");
     if (rc != RN_OK) return rc;
-    if (C == 1) hipLaunchKernelGGL(resample_main_kernel<1>, dim3((unsigned)(groups * 9)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(resample_main_kernel<4>, dim3((unsigned)(groups * 9)), dim3(256), 0, st, a);
+    if (C == 1) hipLaunchKernelGGL((resample_main_kernel<1, 8>), dim3((unsigned)(groups * (ratio + 1))), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resample_main_kernel<4, 8>), dim3((unsigned)(groups * (ratio + 1))), dim3(256), 0, st, a);
     return rn_check_launch("resample_main");
 }
