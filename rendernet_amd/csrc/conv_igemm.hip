@@ -226,11 +226,15 @@ void conv_igemm_kernel(const IgemmArgs a)
 // the map makes the 16 rows of every ds_read_b128 lane group hit 16 distinct 16-B slots.  SAME padding
 // still comes from the buffer bounds check (offset >= 2^31 -> zeros are written to LDS).
 // ------------------------------------------------------------------------------------------------
+// BM = 128: the throughput tile.  BM = 64: same kernel with half-height tiles for small batches -- at M = 4096 (one
+// frame) the 128-row tiling yields 256 workgroups for 512 slots.
+template <int BM>
 __global__ __launch_bounds__(256, 2)
 void conv_igemm_glds_kernel(const IgemmArgs a)
 {
-    constexpr int BM = 128, BN = 128, BK = 32, NT = 256, WN = 2;
-    constexpr int TM = 2, TN = 2, WTM = 64, WTN = 64;
+    constexpr int BN = 128, BK = 32, NT = 256, WN = 2;
+    constexpr int WTM = BM / 2, WTN = 64, TM = WTM / 32, TN = 2;
+    constexpr int APW = BM / 32;                                  // A DMA instructions per wave (8 rows each)
     constexpr int ASZ = BM * BK, BSZ = BK * BN;                 // floats per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                   // [2][128][32]
@@ -269,12 +273,14 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
     }
     __syncthreads();
 
-    // DMA assignment: wave w moves A rows [32w, 32w+32) as 4 instructions of 8 rows; lane -> (row, chunk)
+    // DMA assignment: wave w moves A rows [8*APW*w, +8*APW) as APW instructions of 8 rows; lane -> (row, chunk)
+    // (fixed extents: with the dependent extent [APW] clang 22 silently drops the HOST stub of the kernel)
+    static_assert(APW <= 4, "A DMA instructions per wave");
     int rb[4], r0[4], r1[4], r2[4];
     unsigned lc16[4];                                            // logical chunk byte offset within the row
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int row = wave * 32 + p * 8 + (lane >> 3);
+    for (int p = 0; p < APW; ++p) {
+        const int row = wave * (8 * APW) + p * 8 + (lane >> 3);
         const int4 ri = rowinfo[row];
         rb[p] = ri.x; r0[p] = ri.y; r1[p] = ri.z; r2[p] = ri.w;
         lc16[p] = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
@@ -296,7 +302,7 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
     int t0 = 0, t1 = 0, t2 = 0, ct = 0;
     unsigned aoff[4];
 #define RN_TAP_SETUP_G()                                                                                 \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                      \
+    _Pragma("unroll") for (int p = 0; p < APW; ++p) {                                                      \
         const int i0 = r0[p] + t0, i1 = r1[p] + t1, i2 = r2[p] + t2;                                     \
         const bool ok = rb[p] >= 0 && (unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 &&  \
                         (unsigned)i2 < (unsigned)a.I2;                                                   \
@@ -317,8 +323,8 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
 #define RN_DMA(kt, stage)                                                                                \
     {                                                                                                    \
         const unsigned c0b = (unsigned)ct * (BK * 4);                                                    \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                    \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(As + (stage) * ASZ + (wave * 32 + p * 8) * BK), \
+        _Pragma("unroll") for (int p = 0; p < APW; ++p)                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(As + (stage) * ASZ + (wave * (8 * APW) + p * 8) * BK), \
                                                      16, aoff[p] + c0b, 0, 0, 0);                        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(Bs + (stage) * BSZ + (wave * 4 + j) * 256), \
@@ -388,15 +394,16 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
     }
 }
 
+template <int BM>
 static int launch_glds(IgemmArgs& a, hipStream_t st)
 {
-    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int BN = 128, BK = 32;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.Npad / BN;
     a.ctiles = a.Cin / BK;
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * BK * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
-    auto kern = conv_igemm_glds_kernel;
+    auto kern = conv_igemm_glds_kernel<BM>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -482,7 +489,11 @@ int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st)
     // where it applies (128-wide N, 32-channel K slices).  Ablations of the register-staged form on the same shape:
     // no global loads 142.5, no LDS stores 137.0, neither 152.8 TFLOP/s.
     if (p.Npad % 128 == 0) {
-        if (k32 && a.w_bytes) return launch_glds(a, st);
+        if (k32 && a.w_bytes) {
+            // small batches: half-height tiles once the 128-row tiling cannot fill 256 CUs x 2 workgroups twice over
+            const long long grid128 = (long long)((a.M + 127) / 128) * (p.Npad / 128);
+            return grid128 < 1024 ? launch_glds<64>(a, st) : launch_glds<128>(a, st);
+        }
         return k32 ? launch_cfg<128, 128, 32, 2, 2>(a, st) : launch_cfg<128, 128, 16, 2, 2>(a, st);
     } else if (p.Npad % 64 == 0) {
         return k32 ? launch_cfg<128, 64, 32, 2, 2>(a, st) : launch_cfg<128, 64, 16, 2, 2>(a, st);
