@@ -41,7 +41,7 @@ def synthetic_batch(batch):
     return vox, poses.astype(np.float32)
 
 
-def cpu_baseline(weights, frames=2):
+def cpu_baseline(weights, frames=4):
     """The oracle (CPU restatement of the TF graph; the reference itself needs TensorFlow 1.x, which
     is not installable -- SURVEY.md F4) timed on this box's host cores on a bounded sample."""
     import torch
@@ -69,7 +69,7 @@ def cpu_baseline(weights, frames=2):
     dt = time.time() - t0
     assert out.shape == (frames, 512, 512, 1)
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames (chair, bunny) at the bench poses, one fp32 pass of the NumPy/torch-CPU oracle "
+            "sample": "%d frames (chair, bunny, table, suzanne) at the bench poses, one fp32 pass of the NumPy/torch-CPU oracle "
                       "(resampler + full 237M-parameter net), %.1f s" % (frames, dt)}
 
 
