@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 120            /* 0.1.2: training step, resampler backward */
+#define RN_VERSION 130            /* 0.1.3: + ELU epilogue, differentiable Phong composite */
 
 /* error codes */
 #define RN_OK              0
@@ -34,10 +34,11 @@ extern "C" {
 #define RN_E_LAUNCH       -2      /* HIP launch error */
 #define RN_E_UNSUPPORTED  -3
 
-/* epilogue activation (applied as: v = acc + bias; act PReLU; v += residual; act sigmoid) */
+/* epilogue activation (applied as: v = acc + bias; act PReLU | ELU; v += residual; act sigmoid) */
 #define RN_ACT_NONE     0
 #define RN_ACT_PRELU    1         /* max(0,v) + alpha[c]*min(0,v)  -- tools/layer_util.py:27-45 */
 #define RN_ACT_SIGMOID  2         /* RenderNet_Shader.py:127,130 */
+#define RN_ACT_ELU      4         /* v > 0 ? v : exp(v)-1 -- tf.nn.elu of the shape decoder, Reconstruct_RenderNet_Face.py:49-68 */
 
 /* weight-packing kinds for rn_pack_weights / rn_packed_weight_floats */
 #define RN_PACK_CONV        0     /* TF conv filter  [k0,k1,k2,Cin,Cout]  (2-D: k2 = 1)            */
@@ -155,6 +156,28 @@ int rn_phong_composite_fwd(const float* normals, const float* light_dir, const f
                            float ambient, float k_diffuse, float* out,
                            int B, int H, int W, void* stream);
 
+/* Phong composite, all flavours of tools/Phong_shading.py, and its gradient (the differentiable tf_phong_composite of
+ * the inverse-rendering graph, Reconstruct_RenderNet_Face.py:377-378):
+ *   n = (img-0.5)/|img-0.5|;  D = clip(k_diffuse * max(n . l/|l|, 0) * light_col, 0, 1);  mask = sigmoid(255*s - thr)
+ *   shading = clip(mask*(ambient + D) + (1-mask), 0, 1);  out = shading (* albedo when albedo != NULL)
+ * mask_mode: NP_BLACK s=|img| thr 150 (np_mask :138-148) | NP_WHITE s=|1-img| thr 80 (np_mask_white :150-160) |
+ *            TF_BLACK s=|img| thr 80 (tf_mask :23-32)    | TF_WHITE s=sqrt(3)-|img| thr 80 (tf_mask_white :34-44) |
+ *            NO_MASK  shading = clip(ambient + D)        (with_mask=False, :104-105 / :222-223)
+ * normals, albedo, out, dout, dnormals, dalbedo: [B,H,W,3]; light_dir, light_col: [B,3].
+ * bwd: dnormals / dalbedo are WRITTEN, dlight_dir [B,3] is ACCUMULATED (atomics; zero it first); each may be NULL. */
+#define RN_PHONG_NP_BLACK 0
+#define RN_PHONG_NP_WHITE 1
+#define RN_PHONG_TF_BLACK 2
+#define RN_PHONG_TF_WHITE 3
+#define RN_PHONG_NO_MASK  4
+int rn_phong_composite_ex_fwd(const float* normals, const float* light_dir, const float* light_col,
+                              const float* albedo, float ambient, float k_diffuse, float* out,
+                              int B, int H, int W, int mask_mode, void* stream);
+int rn_phong_composite_bwd(const float* normals, const float* light_dir, const float* light_col,
+                           const float* albedo, float ambient, float k_diffuse, const float* dout,
+                           float* dnormals, float* dlight_dir, float* dalbedo,
+                           int B, int H, int W, int mask_mode, void* stream);
+
 /* ==========================================================================================
  * Training step (BASELINE config 4).  Replaces what TensorFlow's autodiff derives from
  * `tf.train.AdamOptimizer(...).minimize(recon_loss)` (RenderNet_Shader.py:159-167) for the ops of
@@ -194,6 +217,7 @@ int rn_fully_connected_bwd(const float* x, const float* w, const float* dz, floa
 /* Backward of the fused epilogue  y = sigmoid?( prelu?(z) + residual ),  z = conv + bias, rows [M,C]:
  *   dt = dy * y*(1-y) if act has RN_ACT_SIGMOID (needs y);  the residual's gradient is dt;
  *   dz = dt * (z > 0 ? 1 : alpha[c]) and dalpha[c] += sum_rows dt*min(z,0) if RN_ACT_PRELU (needs z);
+ *   dz = dy * (y < 0 ? y+1 : 1) if RN_ACT_ELU (needs y, TF's EluGrad);
  *   dbias[c] += sum_rows dz.
  * dz may alias dy or be NULL; dbias / dalpha are ACCUMULATED (atomics) and may be NULL. */
 int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
@@ -253,6 +277,10 @@ int rn_loss_fwd_bwd(const float* pred, const float* target, float* dpred, double
  * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) is computed by the caller (TF's formulation).  16-byte aligned. */
 int rn_adam_step(float* param, const float* grad, float* m, float* v, size_t n,
                  float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* tf.train.GradientDescentOptimizer update, p -= lr*grad (the latent-variable optimisers of the inverse-rendering
+ * loop, Reconstruct_RenderNet_Face.py:397-413). */
+int rn_sgd_step(float* param, const float* grad, size_t n, float lr, void* stream);
 
 #ifdef __cplusplus
 }

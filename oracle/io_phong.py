@@ -55,8 +55,18 @@ def np_phong_shading(img_batch, light_dir, light_col, k_diffuse):
     return np.clip(d.reshape(img_batch.shape), 0, 1)
 
 
-def np_phong_composite(images_in, light_dir, light_col, ambient_in, k_diffuse):
-    """tools/Phong_shading.py:202-228, black-background branch with mask."""
+def np_mask_white(images_in):
+    """tools/Phong_shading.py:150-160."""
+    m = np.linalg.norm(1. - images_in, axis=3, keepdims=True)
+    return 1. / (1. + np.exp(-(255. * m - 80)))
+
+
+def np_phong_composite(images_in, light_dir, light_col, ambient_in, k_diffuse, background_col="Black", with_mask=True):
+    """tools/Phong_shading.py:202-228."""
     diffuse = np_phong_shading(images_in, light_dir, light_col, k_diffuse)
-    mask = np_mask(images_in)
-    return np.clip(mask * (ambient_in + diffuse) + (1 - mask), 0, 1)
+    if with_mask:
+        mask = np_mask(images_in) if background_col.lower() == "black" else np_mask_white(images_in)
+        compos = mask * (ambient_in + diffuse) + (1 - mask)
+    else:
+        compos = ambient_in + diffuse
+    return np.clip(compos, 0, 1)

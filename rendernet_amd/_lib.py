@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librendernet_hip.so")
 
-RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID = 0, 1, 2
+RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID, RN_ACT_ELU = 0, 1, 2, 4
+RN_PHONG_NP_BLACK, RN_PHONG_NP_WHITE, RN_PHONG_TF_BLACK, RN_PHONG_TF_WHITE, RN_PHONG_NO_MASK = 0, 1, 2, 3, 4
 RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2 = 0, 1, 2
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
@@ -54,6 +55,10 @@ SIGNATURES = {
     "rn_pose_to_affine_bwd": (_c_int, [_c_vp] * 3 + [_c_int] * 3 + [_c_vp]),
     "rn_loss_fwd_bwd": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t, ctypes.c_double, _c_int, _c_vp]),
     "rn_adam_step": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t] + [_c_f] * 5 + [_c_vp]),
+    "rn_sgd_step": (_c_int, [_c_vp, _c_vp, ctypes.c_size_t, _c_f, _c_vp]),
+    # inverse rendering
+    "rn_phong_composite_ex_fwd": (_c_int, [_c_vp] * 4 + [_c_f, _c_f, _c_vp] + [_c_int] * 4 + [_c_vp]),
+    "rn_phong_composite_bwd": (_c_int, [_c_vp] * 4 + [_c_f, _c_f] + [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
 }
 
 _lib = None

@@ -193,6 +193,7 @@ void conv3d_k3_drun_kernel(const DrunArgs a)
                     float v = acc[r] + bv;
                     if (a.z) a.z[oo] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+                    if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
                     if (a.res) v += a.res[oo];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                     a.y[oo] = v;
@@ -367,6 +368,7 @@ void conv3d_k3_drun_dma_kernel(const DrunArgs a)
                     float v = (acc[r] + acc1[r]) + bv;
                     if (a.z) a.z[oo] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+                    if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
                     if (a.res) v += a.res[oo];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                     a.y[oo] = v;

@@ -82,6 +82,7 @@ void conv_direct_kernel(const DirectArgs a)
             float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
             if (a.z) a.z[oo + n] = v;
             if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+            if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
             if (a.res) v += a.res[oo + n];
             if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
             a.y[oo + n] = v;

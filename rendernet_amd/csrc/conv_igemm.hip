@@ -208,6 +208,7 @@ void conv_igemm_kernel(const IgemmArgs a)
                     float v = acc[i][j][r] + bv;
                     if (a.z) a.z[oo + n] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+                    if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
                     if (a.res) v += a.res[oo + n];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                     a.y[oo + n] = v;
@@ -385,6 +386,7 @@ void conv_igemm_glds_kernel(const IgemmArgs a)
                     float v = acc[i][j][r] + bv;
                     if (a.z) a.z[oo + n] = v;
                     if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+                    if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
                     if (a.res) v += a.res[oo + n];
                     if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                     a.y[oo + n] = v;

@@ -128,6 +128,7 @@ void fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const f
             float v = acc[i] + bv;
             if (preact) preact[(size_t)(b0 + i) * out_f + col] = v;
             if (act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
+            if (act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
             if (act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
             y[(size_t)(b0 + i) * out_f + col] = v;
         }
@@ -244,39 +245,177 @@ extern "C" int rn_prelu_fwd(const float* x, const float* alpha, float* y, size_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phong composite (tools/Phong_shading.py:202-228, :162-200, :138-148), black background + mask:
+// Phong composite.  NumPy flavour of the demo (tools/Phong_shading.py:202-228, :162-200, :138-160) and the
+// differentiable TF flavour of the inverse-rendering graph (:46-111, :23-44); they differ only in the mask:
 //   n = (img-0.5)/|img-0.5| ; d = clip(k_d * max(n . l^, 0) * col, 0, 1)
-//   mask = sigmoid(255*|img| - 150) ; out = clip(mask*(ambient + d) + (1-mask), 0, 1)
+//   mask = sigmoid(255*s - thr):  RN_PHONG_NP_BLACK  s = |img|,       thr 150   (np_mask,        :138-148)
+//                                 RN_PHONG_NP_WHITE  s = |1 - img|,   thr 80    (np_mask_white,  :150-160)
+//                                 RN_PHONG_TF_BLACK  s = |img|,       thr 80    (tf_mask,        :23-32)
+//                                 RN_PHONG_TF_WHITE  s = sqrt(3)-|img|, thr 80  (tf_mask_white,  :34-44)
+//                                 RN_PHONG_NO_MASK   out = clip(ambient + d)
+//   shading = clip(mask*(ambient + d) + (1-mask), 0, 1) ;  out = shading * albedo  when albedo is given
+//   (compos_pred = img_pred * shading, Reconstruct_RenderNet_Face.py:377-378).
+// Backward: TF's gradients of the same graph (clip_by_value / maximum pass the gradient inside their range,
+// tf.norm's gradient is v/|v|), d/d img and d/d light_dir (reduced per batch item), d/d albedo.
 // ---------------------------------------------------------------------------------------------
+struct PhongPix {
+    float nx, ny, nz, nn;        // unit normal, |img - 0.5|
+    float lx, ly, lz, ln;        // unit light, |light|
+    float dot, m, s;             // n.l, mask, mask argument s
+    float dc[3], comp[3];        // k_d*d*col before the clip; composite before the clip
+};
+
+__device__ __forceinline__ void phong_eval(float r, float g, float bl, const float* ld, const float* lc,
+                                           float ambient, float k_diffuse, int mode, PhongPix& p, float* sh)
+{
+    p.lx = ld[0]; p.ly = ld[1]; p.lz = ld[2];
+    p.ln = sqrtf(p.lx * p.lx + p.ly * p.ly + p.lz * p.lz);
+    p.lx /= p.ln; p.ly /= p.ln; p.lz /= p.ln;
+    const float vx = r - 0.5f, vy = g - 0.5f, vz = bl - 0.5f;
+    p.nn = sqrtf(vx * vx + vy * vy + vz * vz);
+    p.nx = vx / p.nn; p.ny = vy / p.nn; p.nz = vz / p.nn;
+    p.dot = p.nx * p.lx + p.ny * p.ly + p.nz * p.lz;
+    const float d = fmaxf(p.dot, 0.f);
+    float thr = 80.f;
+    if (mode == RN_PHONG_NP_BLACK) { p.s = sqrtf(r * r + g * g + bl * bl); thr = 150.f; }
+    else if (mode == RN_PHONG_TF_BLACK) p.s = sqrtf(r * r + g * g + bl * bl);
+    else if (mode == RN_PHONG_NP_WHITE) p.s = sqrtf((1.f - r) * (1.f - r) + (1.f - g) * (1.f - g) + (1.f - bl) * (1.f - bl));
+    else p.s = 1.7320508075688772f - sqrtf(r * r + g * g + bl * bl);
+    p.m = (mode == RN_PHONG_NO_MASK) ? 1.f : 1.f / (1.f + expf(-(255.f * p.s - thr)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p.dc[c] = k_diffuse * (d * lc[c]);
+        const float D = fminf(fmaxf(p.dc[c], 0.f), 1.f);
+        p.comp[c] = (mode == RN_PHONG_NO_MASK) ? ambient + D : p.m * (ambient + D) + (1.f - p.m);
+        sh[c] = fminf(fmaxf(p.comp[c], 0.f), 1.f);
+    }
+}
+
 __global__ void phong_kernel(const float* __restrict__ img, const float* __restrict__ light_dir,
-                             const float* __restrict__ light_col, float ambient, float k_diffuse,
-                             float* __restrict__ out, int B, int HW)
+                             const float* __restrict__ light_col, const float* __restrict__ albedo,
+                             float ambient, float k_diffuse, float* __restrict__ out, int B, int HW, int mode)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (long long)B * HW) return;
     const int b = (int)(p / HW);
-    const float r = img[p * 3 + 0], g = img[p * 3 + 1], bl = img[p * 3 + 2];
-    float lx = light_dir[b * 3 + 0], ly = light_dir[b * 3 + 1], lz = light_dir[b * 3 + 2];
-    const float ln = sqrtf(lx * lx + ly * ly + lz * lz);
-    lx /= ln; ly /= ln; lz /= ln;
-    const float nx = r - 0.5f, ny = g - 0.5f, nz = bl - 0.5f;
-    const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-    float d = fmaxf((nx / nn) * lx + (ny / nn) * ly + (nz / nn) * lz, 0.f);
-    const float m = 1.f / (1.f + expf(-(255.f * sqrtf(r * r + g * g + bl * bl) - 150.f)));
+    PhongPix px; float sh[3];
+    phong_eval(img[p * 3 + 0], img[p * 3 + 1], img[p * 3 + 2], light_dir + b * 3, light_col + b * 3,
+               ambient, k_diffuse, mode, px, sh);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[p * 3 + c] = albedo ? sh[c] * albedo[p * 3 + c] : sh[c];
+}
+
+// grid = (blocks per item, B): a block's pixels share the light, so d/d light is one block reduction + 3 atomics
+__global__ __launch_bounds__(256)
+void phong_bwd_kernel(const float* __restrict__ img, const float* __restrict__ light_dir,
+                      const float* __restrict__ light_col, const float* __restrict__ albedo,
+                      float ambient, float k_diffuse, const float* __restrict__ dout,
+                      float* __restrict__ dimg, float* __restrict__ dlight, float* __restrict__ dalbedo,
+                      int HW, int mode)
+{
+    __shared__ float red[3][4];
+    const int b = blockIdx.y;
+    float gl[3] = {0.f, 0.f, 0.f};                      // d loss / d unit light, this thread's pixels
+    PhongPix px;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gridDim.x * 256) {
+        const long long p = (long long)b * HW + q;
+        const float r = img[p * 3 + 0], g = img[p * 3 + 1], bl = img[p * 3 + 2];
+        float sh[3];
+        phong_eval(r, g, bl, light_dir + b * 3, light_col + b * 3, ambient, k_diffuse, mode, px, sh);
+        float dd = 0.f, dm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float go = dout[p * 3 + c];
+            if (albedo) {
+                if (dalbedo) dalbedo[p * 3 + c] = go * sh[c];
+                go *= albedo[p * 3 + c];
+            }
+            const float gc = (px.comp[c] >= 0.f && px.comp[c] <= 1.f) ? go : 0.f;
+            const float D = fminf(fmaxf(px.dc[c], 0.f), 1.f);
+            if (mode != RN_PHONG_NO_MASK) dm += gc * (ambient + D - 1.f);
+            const float gD = (mode == RN_PHONG_NO_MASK) ? gc : gc * px.m;
+            if (px.dc[c] >= 0.f && px.dc[c] <= 1.f) dd += gD * k_diffuse * light_col[b * 3 + c];
+        }
+        const float gdot = px.dot > 0.f ? dd : 0.f;
+        // n = v/|v|:  dv = (dn - n (n.dn)) / |v|,  dn = gdot * l^
+        const float ndl = px.dot;                       // n . l^
+        float gi[3] = {gdot * (px.lx - px.nx * ndl) / px.nn, gdot * (px.ly - px.ny * ndl) / px.nn,
+                       gdot * (px.lz - px.nz * ndl) / px.nn};
+        gl[0] += gdot * px.nx; gl[1] += gdot * px.ny; gl[2] += gdot * px.nz;
+        if (mode != RN_PHONG_NO_MASK) {
+            const float gs = 255.f * dm * px.m * (1.f - px.m);
+            if (mode == RN_PHONG_NP_WHITE) {
+                const float f = -gs / px.s;
+                gi[0] += f * (1.f - r); gi[1] += f * (1.f - g); gi[2] += f * (1.f - bl);
+            } else {
+                const float nrm = sqrtf(r * r + g * g + bl * bl);
+                const float f = (mode == RN_PHONG_TF_WHITE ? -gs : gs) / nrm;
+                gi[0] += f * r; gi[1] += f * g; gi[2] += f * bl;
+            }
+        }
+        if (dimg) { dimg[p * 3 + 0] = gi[0]; dimg[p * 3 + 1] = gi[1]; dimg[p * 3 + 2] = gi[2]; }
+    }
+    if (!dlight) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float dc = fminf(fmaxf(k_diffuse * (d * light_col[b * 3 + c]), 0.f), 1.f);
-        out[p * 3 + c] = fminf(fmaxf(m * (ambient + dc) + (1.f - m), 0.f), 1.f);
+        float v = gl[c];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // l^ = l/|l|:  dl = (dl^ - l^ (l^ . dl^)) / |l|
+        float lx = light_dir[b * 3 + 0], ly = light_dir[b * 3 + 1], lz = light_dir[b * 3 + 2];
+        const float ln = sqrtf(lx * lx + ly * ly + lz * lz);
+        lx /= ln; ly /= ln; lz /= ln;
+        const float g0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const float g1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float g2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const float ldg = lx * g0 + ly * g1 + lz * g2;
+        unsafeAtomicAdd(dlight + b * 3 + 0, (g0 - lx * ldg) / ln);
+        unsafeAtomicAdd(dlight + b * 3 + 1, (g1 - ly * ldg) / ln);
+        unsafeAtomicAdd(dlight + b * 3 + 2, (g2 - lz * ldg) / ln);
+    }
+}
+
+static int phong_args_ok(const float* normals, const float* light_dir, const float* light_col, int B, int H, int W, int mode)
+{
+    return normals && light_dir && light_col && B >= 1 && H >= 1 && W >= 1 && mode >= RN_PHONG_NP_BLACK && mode <= RN_PHONG_NO_MASK;
+}
+
+extern "C" int rn_phong_composite_ex_fwd(const float* normals, const float* light_dir, const float* light_col,
+                                         const float* albedo, float ambient, float k_diffuse, float* out,
+                                         int B, int H, int W, int mask_mode, void* stream)
+{
+    if (!phong_args_ok(normals, light_dir, light_col, B, H, W, mask_mode) || !out)
+        return rn_set_error(RN_E_INVALID, "rn_phong_composite_ex_fwd: bad argument");
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(phong_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       normals, light_dir, light_col, albedo, ambient, k_diffuse, out, B, H * W, mask_mode);
+    return rn_check_launch("phong_composite");
 }
 
 extern "C" int rn_phong_composite_fwd(const float* normals, const float* light_dir, const float* light_col,
                                       float ambient, float k_diffuse, float* out, int B, int H, int W, void* stream)
 {
-    if (!normals || !light_dir || !light_col || !out || B < 1 || H < 1 || W < 1)
-        return rn_set_error(RN_E_INVALID, "rn_phong_composite_fwd: bad argument");
-    const long long n = (long long)B * H * W;
-    hipLaunchKernelGGL(phong_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       normals, light_dir, light_col, ambient, k_diffuse, out, B, H * W);
-    return rn_check_launch("phong_composite");
+    return rn_phong_composite_ex_fwd(normals, light_dir, light_col, nullptr, ambient, k_diffuse, out, B, H, W,
+                                     RN_PHONG_NP_BLACK, stream);
+}
+
+extern "C" int rn_phong_composite_bwd(const float* normals, const float* light_dir, const float* light_col,
+                                      const float* albedo, float ambient, float k_diffuse, const float* dout,
+                                      float* dnormals, float* dlight_dir, float* dalbedo,
+                                      int B, int H, int W, int mask_mode, void* stream)
+{
+    if (!phong_args_ok(normals, light_dir, light_col, B, H, W, mask_mode) || !dout)
+        return rn_set_error(RN_E_INVALID, "rn_phong_composite_bwd: bad argument");
+    if (dalbedo && !albedo) return rn_set_error(RN_E_INVALID, "rn_phong_composite_bwd: dalbedo without albedo");
+    const int HW = H * W;
+    int bx = (HW + 256 * 8 - 1) / (256 * 8);           // 8 pixels per thread: few atomics per item
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(phong_bwd_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       normals, light_dir, light_col, albedo, ambient, k_diffuse, dout, dnormals, dlight_dir, dalbedo,
+                       HW, mask_mode);
+    return rn_check_launch("phong_composite_bwd");
 }

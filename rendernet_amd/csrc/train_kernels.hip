@@ -9,6 +9,7 @@
 // :133-144; the residual's gradient is dy itself -- after the sigmoid factor -- and needs no kernel):
 //     dt = dy * y*(1-y)            if sigmoid   (needs y)
 //     dz = dt * (z > 0 ? 1 : alpha[c]),  dalpha[c] += sum dt * min(z, 0)      if PReLU  (needs z)
+//     dz = dy * (y < 0 ? y + 1 : 1)                                            if ELU    (needs y; TF's EluGrad)
 //     dbias[c] += sum dz
 // Rows are [M, C] channels-last.  dz may alias dy.  dbias/dalpha are accumulated with atomics.
 // ---------------------------------------------------------------------------------------------
@@ -34,6 +35,7 @@ void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
     if (a.act & RN_ACT_PRELU) al = reinterpret_cast<const float4*>(a.alpha)[g];
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, sa[4] = {0.f, 0.f, 0.f, 0.f};
     const bool has_s = (a.act & RN_ACT_SIGMOID) != 0, has_p = (a.act & RN_ACT_PRELU) != 0;
+    const bool has_e = (a.act & RN_ACT_ELU) != 0;
     const float aa[4] = {al.x, al.y, al.z, al.w};
     // UNR rows in flight per thread: the loop is pure streaming (12-16 B in, 16 B out per lane), so the
     // loads of all UNR rows are issued before the first use
@@ -47,7 +49,7 @@ void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
                 const size_t e = (size_t)r * G + g;
                 d[u] = reinterpret_cast<const float4*>(a.dy)[e];
                 if (has_p) zv[u] = reinterpret_cast<const float4*>(a.z)[e];
-                if (has_s) yv[u] = reinterpret_cast<const float4*>(a.y)[e];
+                if (has_s || has_e) yv[u] = reinterpret_cast<const float4*>(a.y)[e];
             }
         }
 #pragma unroll
@@ -60,6 +62,11 @@ void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
                     const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) dv[q] *= yy[q] * (1.f - yy[q]);
+                }
+                if (has_e) {
+                    const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dv[q] = yy[q] < 0.f ? dv[q] * (yy[q] + 1.f) : dv[q];
                 }
                 if (has_p) {
                     const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
@@ -111,6 +118,7 @@ void epilogue_bwd_gen_kernel(const EpiBwdArgs a)
         const int c = (int)(e % a.C);
         float d = a.dy[e];
         if (a.act & RN_ACT_SIGMOID) { const float yv = a.y[e]; d *= yv * (1.f - yv); }
+        if (a.act & RN_ACT_ELU) { const float yv = a.y[e]; d = yv < 0.f ? d * (yv + 1.f) : d; }
         if (a.act & RN_ACT_PRELU) {
             const float zv = a.z[e];
             atomicAdd(&sa[c], d * fminf(zv, 0.f));
@@ -136,7 +144,7 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
 {
     if (!dy || M < 1 || C < 1) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: bad arguments");
     if ((act & RN_ACT_PRELU) && (!z || !alpha)) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: PReLU needs z and alpha");
-    if ((act & RN_ACT_SIGMOID) && !y) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: sigmoid needs y");
+    if ((act & (RN_ACT_SIGMOID | RN_ACT_ELU)) && !y) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: sigmoid / ELU need y");
     EpiBwdArgs a{dy, z, y, alpha, dz, dbias, dalpha, (long long)M, C, act, 0};
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 4;
@@ -261,6 +269,23 @@ extern "C" int rn_adam_step(float* param, const float* grad, float* m, float* v,
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
                        n4, n, lr_t, beta1, beta2, eps, grad_scale);
     return rn_check_launch("rn_adam_step");
+}
+
+// tf.train.GradientDescentOptimizer (the four latent-variable optimisers of the inverse-rendering loop,
+// Reconstruct_RenderNet_Face.py:397-413): p -= lr * g.  Latents are a few hundred floats: one small launch.
+__global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ grad, size_t n, float lr)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        param[i] -= lr * grad[i];
+}
+
+extern "C" int rn_sgd_step(float* param, const float* grad, size_t n, float lr, void* stream)
+{
+    if (!param || !grad || n < 1) return rn_set_error(RN_E_INVALID, "rn_sgd_step: bad arguments");
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, n, lr);
+    return rn_check_launch("rn_sgd_step");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -79,8 +79,10 @@ def pack_conv_transpose(w_tf, stride):
     return PackedWeight(w_tf, L.RN_PACK_CONVT_S1 if stride == 1 else L.RN_PACK_CONVT_S2, w_tf.dim() - 2)
 
 
-def _act_code(alpha, sigmoid):
-    return (L.RN_ACT_PRELU if alpha is not None else 0) | (L.RN_ACT_SIGMOID if sigmoid else 0)
+def _act_code(alpha, sigmoid, elu=False):
+    if elu and (alpha is not None or sigmoid):
+        raise L.RenderNetHipError("ELU does not combine with PReLU / sigmoid in one epilogue")
+    return (L.RN_ACT_PRELU if alpha is not None else 0) | (L.RN_ACT_SIGMOID if sigmoid else 0) | (L.RN_ACT_ELU if elu else 0)
 
 
 class _ForwardOnly(torch.autograd.Function):
@@ -168,12 +170,15 @@ class TrainContext:
     along every conv call so that autograd schedules the backward of layers whose data input does
     not require grad (the first conv reads the resampled voxels)."""
 
-    def __init__(self, grad_of, on_ready=None, device="cuda"):
-        self.grad_of = grad_of            # {data_ptr: grad tensor}
+    def __init__(self, grad_of=None, on_ready=None, device="cuda", frozen=False):
+        self.grad_of = grad_of or {}      # {data_ptr: grad tensor}
         self.on_ready = on_ready          # callable(data_ptr) or None
+        self.frozen = frozen              # pretrained weights (inverse rendering): input gradients only, no wgrad
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
 
     def grad(self, t):
+        if self.frozen:
+            return None
         g = self.grad_of.get(t.data_ptr())
         if g is None:
             raise L.RenderNetHipError("no gradient buffer registered for a parameter of shape %s" % (tuple(t.shape),))
@@ -230,12 +235,12 @@ class _Conv(torch.autograd.Function):
     forward (plus the saved pre-activation when training), three backward (epilogue, dgrad, wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor):
+    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False):
         _chk_dev(x, pw.data, bias, alpha, residual)
         ev = LAUNCH_HOOK(mode, tuple(x.shape), pw) if LAUNCH_HOOK is not None else None
         if ev is not None:
             ev[0].record()
-        act = _act_code(alpha, sigmoid)
+        act = _act_code(alpha, sigmoid, elu)
         train = anchor is not None
         y = torch.empty(_out_shape(mode, x, pw, stride), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:
@@ -245,7 +250,7 @@ class _Conv(torch.autograd.Function):
         if ev is not None:
             ev[1].record()
         if train:
-            ctx.save_for_backward(x, z, y if sigmoid else None)
+            ctx.save_for_backward(x, z, y if (sigmoid or elu) else None)
             ctx.cfg = (pw, bias, alpha, residual is not None, tuple(ksize), tuple(stride), act, mode, TRAIN)
         return y
 
@@ -259,7 +264,7 @@ class _Conv(torch.autograd.Function):
         M = dy.numel() // C
         # 1. epilogue backward: dz (new buffer only when the values change), dbias, dalpha
         dz = torch.empty_like(dy) if act else dy
-        if act or bias is not None:
+        if act or (bias is not None and not tc.frozen):
             L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), L.ptr(y), L.ptr(alpha), L.ptr(dz) if act else None,
                                         L.ptr(tc.grad(bias)) if bias is not None else None,
                                         L.ptr(tc.grad(alpha)) if alpha is not None else None,
@@ -269,20 +274,22 @@ class _Conv(torch.autograd.Function):
             if act & L.RN_ACT_SIGMOID:
                 raise L.RenderNetHipError("backward of sigmoid + residual in one epilogue is not supported")
             d_res = dy                      # PReLU sits before the residual add: its gradient is dy itself
-        # 2. wgrad, accumulated into the registered gradient view (TF layout)
+        # 2. wgrad, accumulated into the registered gradient view (TF layout); none with frozen weights
         dw = tc.grad(pw.w_tf)
         unit = all(int(v) == 1 for v in stride)
-        if mode == "conv3d":
+        if mode in ("conv3d", "conv3d_transpose"):
             B, H, W, D, Cin = x.shape
+        else:
+            B, H, W, Cin = x.shape
+        if dw is None:
+            rc = 0
+        elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
         elif mode == "conv2d":
-            B, H, W, Cin = x.shape
             rc = lib.rn_conv2d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
         elif mode == "conv2d_transpose":
-            B, H, W, Cin = x.shape
             rc = lib.rn_conv2d_transpose_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, ksize[0], stride[0], st)
         else:
-            B, H, W, D, Cin = x.shape
             rc = lib.rn_conv3d_transpose_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, ksize[0], stride[0], st)
         L.check(rc, "rn_%s_wgrad" % mode)
         # 3. dgrad
@@ -299,8 +306,9 @@ class _Conv(torch.autograd.Function):
             else:
                 rc = lib.rn_conv3d_transpose_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, ksize[0], stride[0], st)
             L.check(rc, "rn_%s_dgrad" % mode)
-        tc.ready(pw.w_tf, bias, alpha)
-        return dx, None, None, None, d_res, None, None, None, None, None
+        if not tc.frozen:
+            tc.ready(pw.w_tf, bias, alpha)
+        return dx, None, None, None, d_res, None, None, None, None, None, None
 
 
 def _prep(x, pw, mode_cin):
@@ -310,31 +318,31 @@ def _prep(x, pw, mode_cin):
     return x
 
 
-def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode):
+def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, elu=False):
     anchor = TRAIN.anchor if (TRAIN is not None and torch.is_grad_enabled()) else None
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor)
+    return _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu)
 
 
-def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False):
+def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False, elu=False):
     x = _prep(x, pw, 4)
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d", elu)
 
 
-def conv2d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False):
+def conv2d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False, elu=False):
     x = _prep(x, pw, 3)
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d", elu)
 
 
-def conv2d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False):
+def conv2d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False, elu=False):
     x = _prep(x, pw, 3)
     if stride[0] != stride[1] or pw.kdims[0] != pw.kdims[1]:
         raise L.RenderNetHipError("conv2d_transpose: square kernels/strides only")
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d_transpose")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d_transpose", elu)
 
 
-def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False):
+def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False, elu=False):
     x = _prep(x, pw, 4)
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d_transpose")
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d_transpose", elu)
 
 
 class _Projection(_ForwardOnly):
@@ -388,7 +396,7 @@ class _FC(torch.autograd.Function):
         B, fin = x.shape
         fout = w.shape[1]
         dz = torch.empty_like(dy) if act else dy
-        if act or bias is not None:
+        if act or (bias is not None and not tc.frozen):
             L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), None, L.ptr(alpha), L.ptr(dz) if act else None,
                                         L.ptr(tc.grad(bias)) if bias is not None else None,
                                         L.ptr(tc.grad(alpha)) if alpha is not None else None, B, fout, act, st),
@@ -396,7 +404,8 @@ class _FC(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         L.check(lib.rn_fully_connected_bwd(L.ptr(x), L.ptr(w), L.ptr(dz), L.ptr(dx), L.ptr(tc.grad(w)), B, fin, fout, st),
                 "rn_fully_connected_bwd")
-        tc.ready(w, bias, alpha)
+        if not tc.frozen:
+            tc.ready(w, bias, alpha)
         return dx, None, None, None, None
 
 
@@ -415,13 +424,52 @@ def prelu(x, alpha):
     return y
 
 
-def phong_composite(normals, light_dir, light_col, ambient, k_diffuse):
-    """normals [B,H,W,3] in [0,1]; light_dir, light_col [B,3] -> shaded [B,H,W,3]."""
+PHONG_MODES = {"np_black": L.RN_PHONG_NP_BLACK, "np_white": L.RN_PHONG_NP_WHITE, "tf_black": L.RN_PHONG_TF_BLACK,
+               "tf_white": L.RN_PHONG_TF_WHITE, "none": L.RN_PHONG_NO_MASK}
+
+
+class _Phong(torch.autograd.Function):
+    """Phong composite (all flavours of tools/Phong_shading.py) with TF's gradients w.r.t. the normal map, the light
+    direction and the albedo it is multiplied with (Reconstruct_RenderNet_Face.py:377-378)."""
+
+    @staticmethod
+    def forward(ctx, normals, light_dir, light_col, albedo, ambient, k_diffuse, mode):
+        _chk_dev(normals, light_dir, light_col, albedo)
+        B, H, W, _ = normals.shape
+        out = torch.empty_like(normals)
+        L.check(L.lib().rn_phong_composite_ex_fwd(L.ptr(normals), L.ptr(light_dir), L.ptr(light_col), L.ptr(albedo),
+                                                  ambient, k_diffuse, L.ptr(out), B, H, W, mode, L.stream_ptr()),
+                "rn_phong_composite_ex_fwd")
+        ctx.save_for_backward(normals, light_dir, light_col, albedo)
+        ctx.cfg = (ambient, k_diffuse, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        normals, light_dir, light_col, albedo = ctx.saved_tensors
+        ambient, k_diffuse, mode = ctx.cfg
+        B, H, W, _ = normals.shape
+        dout = dout.contiguous()
+        dn = torch.empty_like(normals) if ctx.needs_input_grad[0] else None
+        dl = torch.zeros_like(light_dir) if ctx.needs_input_grad[1] else None
+        da = torch.empty_like(albedo) if (albedo is not None and ctx.needs_input_grad[3]) else None
+        L.check(L.lib().rn_phong_composite_bwd(L.ptr(normals), L.ptr(light_dir), L.ptr(light_col), L.ptr(albedo),
+                                               ambient, k_diffuse, L.ptr(dout), L.ptr(dn), L.ptr(dl), L.ptr(da),
+                                               B, H, W, mode, L.stream_ptr()), "rn_phong_composite_bwd")
+        return dn, dl, None, da, None, None, None
+
+
+def phong_composite(normals, light_dir, light_col, ambient, k_diffuse, mode="np_black", albedo=None):
+    """normals [B,H,W,3] in [0,1]; light_dir, light_col [B,3] -> shading [B,H,W,3] (times `albedo` when given).
+    mode: mask flavour, see include/rendernet_hip.h (np_black = the demo)."""
     normals = normals.contiguous().float()
-    _chk_dev(normals, light_dir, light_col)
-    B, H, W, _ = normals.shape
-    out = torch.empty_like(normals)
-    L.check(L.lib().rn_phong_composite_fwd(L.ptr(normals), L.ptr(light_dir.contiguous().float()),
-                                           L.ptr(light_col.contiguous().float()), float(ambient), float(k_diffuse),
-                                           L.ptr(out), B, H, W, L.stream_ptr()), "rn_phong_composite_fwd")
-    return out
+    if normals.dim() != 4 or normals.shape[-1] != 3:
+        raise L.RenderNetHipError("phong_composite: normals must be [B,H,W,3], got %s" % (tuple(normals.shape),))
+    B = normals.shape[0]
+    light_dir = light_dir.float().expand(B, 3).contiguous()
+    light_col = light_col.float().expand(B, 3).contiguous()
+    if albedo is not None:
+        albedo = albedo.contiguous().float()
+        if albedo.shape != normals.shape:
+            raise L.RenderNetHipError("phong_composite: albedo shape %s != normals shape %s" % (tuple(albedo.shape), tuple(normals.shape)))
+    return _Phong.apply(normals, light_dir, light_col, albedo, float(ambient), float(k_diffuse), PHONG_MODES[mode])

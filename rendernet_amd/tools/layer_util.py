@@ -4,9 +4,9 @@ Same names, argument order and defaults as the reference builders; tensors are t
 tensors in TF's channels-last layout; variables live in rendernet_amd.variables (TF names).
 Differences forced by the move off TF graph mode are limited to:
   * `weight_initializer_type` takes the initialiser factories of rendernet_amd.variables;
-  * every builder accepts two extra keyword arguments, `activation_alpha` / `residual` /
-    `sigmoid`, used by the fused call sites (prelu / tf.add / tf.nn.sigmoid folded into the conv
-    epilogue).  Calling `prelu(conv3d(...))` unfused, as the reference spells it, also works.
+  * every builder accepts the extra keyword arguments `activation_alpha` / `residual` /
+    `sigmoid` (and `elu` on conv3d_transpose), used by the fused call sites (prelu / tf.add /
+    tf.nn.sigmoid / tf.nn.elu folded into the conv epilogue).  Calling `prelu(conv3d(...))` unfused, as the reference spells it, also works.
 """
 from .. import ops
 from .. import variables as V
@@ -103,13 +103,14 @@ def conv2d_transpose(x, num_outputs, kernel_size=(4, 4), stride=(1, 1), pad='SAM
 def conv3d_transpose(x, num_output, kernel_size=(4, 4, 4), stride=(1, 1, 1), pad='SAME', if_bias=True, reuse=False,
                      scope="conv3d_transpose", trainable=True, weight_initializer=None, bias_initializer=None,
                      weight_initializer_type=random_normal_initializer(stddev=0.02),
-                     activation_alpha=None, residual=None, sigmoid=False):
-    """tools/layer_util.py:269-309.  Filter layout [k1,k2,k3,Cout,Cin] (:284)."""
+                     activation_alpha=None, residual=None, sigmoid=False, elu=False):
+    """tools/layer_util.py:269-309.  Filter layout [k1,k2,k3,Cout,Cin] (:284).  `elu` folds the tf.nn.elu of the
+    shape decoder (Reconstruct_RenderNet_Face.py:49-68) into the epilogue."""
     assert pad == "SAME"
     w, wname, b = _conv_vars(scope, list(kernel_size) + [num_output, x.shape[-1]], if_bias,
                              weight_initializer, bias_initializer, weight_initializer_type, num_output)
     pw = _store().packed(wname, lambda: ops.pack_conv_transpose(w, stride[0]))
-    return ops.conv3d_transpose(x, pw, b, activation_alpha, residual, tuple(stride), sigmoid)
+    return ops.conv3d_transpose(x, pw, b, activation_alpha, residual, tuple(stride), sigmoid, elu)
 
 
 def fully_connected(input_, output_size, reuse=False, scope='fully_connected', if_bias=True, weight_initializer=None,

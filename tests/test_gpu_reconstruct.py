@@ -1,0 +1,237 @@
+"""Inverse rendering through the frozen renderer (Reconstruct_RenderNet_Face.py) on the HIP path
+vs the CPU oracle: every Phong composite flavour and its gradient, the ELU epilogue and its backward, the shape
+decoder, and one full step of the latent optimisation (losses, four latent gradients, SGD update).  -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import io_phong as OP
+from oracle import layers as OL
+from oracle import reconstruct as OR
+
+pytestmark = pytest.mark.gpu
+
+
+def _phong_inputs(seed=0, B=3, H=37, W=29):
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(0.02, 0.98, (B, H, W, 3)).astype(np.float32)
+    # a band of pixels on each mask's transition so that the mask gradient is exercised
+    img[0, 0, :] = np.linspace(0.815, 0.822, W, dtype=np.float32)[:, None]                  # sqrt(3)-|img| ~ 80/255
+    img[1, 1, :] = np.linspace(0.17, 0.20, W, dtype=np.float32)[:, None]                    # |img| ~ 80/255
+    img[2, 2, :] = np.linspace(0.33, 0.35, W, dtype=np.float32)[:, None]                    # |img| ~ 150/255
+    img[2, 3, :] = 1.0 - np.linspace(0.17, 0.20, W, dtype=np.float32)[:, None]              # |1-img| ~ 80/255
+    light = rng.standard_normal((B, 3)).astype(np.float32)
+    col = rng.uniform(0.5, 1.0, (B, 3)).astype(np.float32)
+    albedo = rng.uniform(0, 1, (B, H, W, 3)).astype(np.float32)
+    return img, light, col, albedo
+
+
+def _oracle_phong(mode, img, light, col, ambient, kd):
+    """float64 torch graph of the flavour `mode` (TF functions; the NumPy masks restated with torch ops)."""
+    if mode == "tf_white":
+        return OR.tf_phong_composite(img, light, col, ambient, kd)
+    if mode == "tf_black":
+        return OR.tf_phong_composite(img, light, col, ambient, kd, with_black_background=True)
+    if mode == "none":
+        return OR.tf_phong_composite(img, light, col, ambient, kd, with_mask=False)
+    diffuse = OR.tf_phong_shading(img, light, col, kd)
+    if mode == "np_black":
+        mask = torch.sigmoid(255. * torch.linalg.vector_norm(img, dim=3, keepdim=True) - 150)
+    else:
+        mask = torch.sigmoid(255. * torch.linalg.vector_norm(1. - img, dim=3, keepdim=True) - 80)
+    return torch.clamp(mask * (ambient + diffuse) + (1 - mask), 0., 1.)
+
+
+@pytest.mark.parametrize("mode", ["np_black", "np_white", "tf_black", "tf_white", "none"])
+@pytest.mark.parametrize("with_albedo", [False, True])
+def test_phong_composite_forward_and_gradient(mode, with_albedo):
+    from rendernet_amd import ops
+    img, light, col, albedo = _phong_inputs()
+    ambient, kd = 0.1, 0.9
+    # NumPy twin of the reference where it exists
+    if mode.startswith("np") or mode == "none":
+        want_np = OP.np_phong_composite(img, light, col, ambient, kd, background_col="black" if mode == "np_black" else "white",
+                                        with_mask=mode != "none")
+    i64 = torch.from_numpy(img).double().requires_grad_(True)
+    l64 = torch.from_numpy(light).double().requires_grad_(True)
+    a64 = torch.from_numpy(albedo).double().requires_grad_(True)
+    want = _oracle_phong(mode, i64, l64, torch.from_numpy(col).double(), ambient, kd)
+    if with_albedo:
+        want = want * a64
+    elif mode.startswith("np") or mode == "none":
+        assert np.abs(want.detach().numpy() - want_np).max() < 3e-5      # float32 NumPy twin vs float64 (transition band)
+    i = torch.from_numpy(img).cuda().requires_grad_(True)
+    l = torch.from_numpy(light).cuda().requires_grad_(True)
+    a = torch.from_numpy(albedo).cuda().requires_grad_(True)
+    got = ops.phong_composite(i, l, torch.from_numpy(col).cuda(), ambient, kd, mode, albedo=a if with_albedo else None)
+    # the transition band has slope 255/4 per unit of |img|: float32 rounding of the norm shows up at ~1e-5
+    assert np.abs(got.detach().cpu().numpy() - want.detach().numpy()).max() <= 3e-5
+    wgt = np.random.default_rng(9).standard_normal(img.shape).astype(np.float32)
+    (want * torch.from_numpy(wgt).double()).sum().backward()
+    (got * torch.from_numpy(wgt).cuda()).sum().backward()
+    gi, gl = i.grad.cpu().numpy(), l.grad.cpu().numpy()
+    ri, rl = i64.grad.numpy(), l64.grad.numpy()
+    # per-pixel gradients: relative to the largest one, except pixels whose clip / max decisions sit within float32
+    # rounding of a kink (none in this data: assert everything)
+    assert np.abs(gi - ri).max() <= 2e-4 * np.abs(ri).max() + 1e-6, (np.abs(gi - ri).max(), np.abs(ri).max())
+    assert np.abs(gl - rl).max() <= 2e-4 * np.abs(rl).max() + 1e-6, (gl, rl)
+    if mode != "none":
+        band = {"tf_white": (0, 0), "tf_black": (1, 1), "np_black": (2, 2), "np_white": (2, 3)}[mode]
+        assert np.abs(ri[band[0], band[1]]).max() > 1.0           # the mask gradient is really in play
+    if with_albedo:
+        assert np.abs(a.grad.cpu().numpy() - a64.grad.numpy()).max() <= 1e-5
+
+
+def test_numpy_front_end_white_background_and_shading():
+    from rendernet_amd.tools import Phong_shading
+    img, light, col, _ = (a[2:3] for a in _phong_inputs(3))
+    got = Phong_shading.np_phong_composite(img, light, col, 0.05, 0.8, background_col="white")
+    assert isinstance(got, np.ndarray)
+    assert np.abs(got - OP.np_phong_composite(img, light, col, 0.05, 0.8, background_col="white")).max() <= 3e-5
+    sh = Phong_shading.tf_phong_shading(torch.from_numpy(img).cuda(), torch.from_numpy(light).cuda(), torch.from_numpy(col).cuda(), 0.8)
+    assert np.abs(sh.cpu().numpy() - OP.np_phong_shading(img, light, col, 0.8)).max() <= 2e-6
+    az = torch.tensor([[0.3]], device="cuda")
+    lp = Phong_shading.tf_generate_light_pos(az, 0.7, 1).cpu().numpy()
+    assert np.allclose(lp, [[math.sin(0.7) * math.cos(0.3), math.sin(0.7) * math.sin(0.3), math.cos(0.7)]], atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 4, 4, 32, 16, 2), (1, 8, 8, 8, 8, 8, 2), (2, 5, 6, 7, 16, 12, 1), (1, 16, 16, 16, 8, 1, 1)])
+def test_conv3d_transpose_elu_forward_and_input_gradient(shape):
+    """tf.nn.elu(conv3d_transpose(x)) (Reconstruct_RenderNet_Face.py:49-68) fused in the epilogue; frozen weights:
+    only the input gradient, through TF's EluGrad (dy * (y + 1) for y < 0)."""
+    from rendernet_amd import ops
+    B, H, W, D, Cin, Cout, s = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, H, W, D, Cin)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, 4, Cout, Cin)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    want = torch.nn.functional.elu(OL.conv3d_transpose(xt, torch.from_numpy(w), torch.from_numpy(b), (s, s, s)))
+    assert (want < 0).float().mean() > 0.2
+    wgt = rng.standard_normal(tuple(want.shape)).astype(np.float32)
+    (want * torch.from_numpy(wgt)).sum().backward()
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    pw = ops.pack_conv_transpose(torch.from_numpy(w).cuda(), s)
+    bd = torch.from_numpy(b).cuda()
+    with ops.training(ops.TrainContext(frozen=True)):
+        got = ops.conv3d_transpose(xd, pw, bd, stride=(s, s, s), elu=True)
+    ref = np.abs(want.detach().numpy()).max()
+    assert np.abs(got.detach().cpu().numpy() - want.detach().numpy()).max() <= 2e-5 * ref + 1e-6
+    (got * torch.from_numpy(wgt).cuda()).sum().backward()
+    gref = np.abs(xt.grad.numpy()).max()
+    assert np.abs(xd.grad.cpu().numpy() - xt.grad.numpy()).max() <= 1e-4 * gref + 1e-6
+    # inference path (no training context) gives the same values
+    with torch.no_grad():
+        got2 = ops.conv3d_transpose(xd, pw, bd, stride=(s, s, s), elu=True)
+    assert torch.equal(got2, got.detach())
+
+
+def _tiny_setup(B=2):
+    from rendernet_amd import reconstruct as RC
+    from rendernet_amd.texture import tiny_texture_spec, init_texture_weights
+    ts, ds = tiny_texture_spec(), RC.tiny_shape_decoder_spec()
+    w = dict(init_texture_weights(ts, seed=77, perturb=True))
+    w.update(RC.init_shape_decoder_weights(ds, seed=78, perturb=True))
+    w["g_conv4/weights"] = w["g_conv4/weights"] * 30           # give the random-init volume some structure
+    rng = np.random.default_rng(6)
+    lat = dict(vector=rng.standard_normal((B, ds.z_dim)).astype(np.float32) * 2,
+               param=np.array([[4.36, 0.52, 1.0], [4.0, 0.9, 1.0]], np.float32)[:B],
+               texture=rng.standard_normal((B, ts.z_dim)).astype(np.float32),
+               light=np.array([[4.2], [5.1]], np.float32)[:B])
+    target = rng.uniform(0, 1, (B, 128, 128, 3)).astype(np.float32)
+    rec = RC.Reconstructor(ts, ds, w, batch_size=B, light_elevation_deg=75.0, shape_eta=0.8, pose_eta=0.01, tex_eta=0.8,
+                           light_eta=0.4)
+    rec.assign(**lat)
+    return rec, ts, ds, w, lat, target
+
+
+def test_shape_decoder_matches_oracle():
+    from rendernet_amd import reconstruct as RC
+    from rendernet_amd import variables as V
+    rec, ts, ds, w, lat, _ = _tiny_setup()
+    V.set_default_store(rec.store)
+    taps = {}
+    with torch.no_grad():
+        got = RC.decoder_3d_pretrained(torch.from_numpy(lat["vector"]).cuda(), ds, taps)
+    otaps = {}
+    want = OR.decoder_3d_torch(torch.from_numpy(lat["vector"]), {k: torch.from_numpy(v) for k, v in w.items()}, ds.base, ds.chans, otaps)
+    for k in otaps:
+        err, ref = np.abs(taps[k].cpu().numpy() - otaps[k]).max(), np.abs(otaps[k]).max()
+        assert err <= 2e-4 * ref + 1e-6, (k, err, ref)
+    assert got.shape == (2, 16, 16, 16, 1)
+    assert np.abs(got.cpu().numpy() - want.numpy()).max() <= 1e-4
+    assert want.numpy().std() > 0.01                              # not the flat 0.5 volume
+
+
+def test_inverse_rendering_step_matches_oracle():
+    """recon_loss [B], the gradients of the four latent groups (shape code through decoder + resampler + net, pose
+    through the resampler's matrix, texture code, light azimuth through the Phong composite), and the SGD update."""
+    from rendernet_amd import ops
+    rec, ts, ds, w, lat, target = _tiny_setup()
+    taps = {}
+    compos, img, nrm, shape = rec.forward(taps)
+    loss = rec.loss_and_backward(compos, target).cpu().numpy().copy()
+    M = ops.pose_to_affine(torch.from_numpy(lat["param"]).cuda(), ts.size, ts.new_size).cpu().numpy()
+    oloss, ograds, oout = OR.losses_and_grads(lat["vector"], lat["param"], lat["texture"], lat["light"], target, w, M, ts.size,
+                                              ts.new_size, ts.tex_res, (ts.n_res1, ts.n_res2, ts.n_res3), ds.base, ds.chans,
+                                              rec.elevation, (1.0, 1.0, 1.0), 0.0, 1.0, ts.tex_c0)
+    assert np.abs(shape.detach().cpu().numpy() - oout["shape"]).max() <= 1e-4
+    assert np.abs(taps["net_in"].detach().cpu().numpy() - oout["net_in"]).max() <= 1e-4
+    assert np.abs(img.detach().cpu().numpy() - oout["img"]).max() <= 1e-3
+    assert np.abs(nrm.detach().cpu().numpy() - oout["normal"]).max() <= 1e-3
+    assert np.abs(compos.detach().cpu().numpy() - oout["compos"]).max() <= 1e-3
+    assert np.abs(loss - oloss).max() <= 1e-4 * np.abs(oloss).max(), (loss, oloss)
+    old = rec.values()
+    grads = {k: v.grad.detach().cpu().numpy().copy() for k, v in rec.latents.items()}
+    for name, tol in (("vector", 2e-3), ("texture", 2e-3), ("light", 2e-3), ("param", 5e-3)):
+        ref, err = np.abs(ograds[name]).max(), np.abs(grads[name] - ograds[name]).max()
+        assert ref > 0 and err <= tol * ref + 1e-9, "%s: grad err %g vs max|ref| %g" % (name, err, ref)
+        print("%s: relative gradient error %.3g" % (name, err / ref))
+    rec.apply_gradients()
+    new = rec.values()
+    for name, eta in rec.etas.items():
+        assert np.allclose(new[name], old[name] - eta * grads[name], rtol=1e-6, atol=1e-7), name
+    assert rec.global_step == 1
+    # a second full step runs and returns the losses of its own forward
+    l2 = rec.step(target).cpu().numpy()
+    assert l2.shape == (2,) and np.isfinite(l2).all()
+
+
+def test_latent_descent_reduces_the_loss():
+    """Optimising only through the frozen nets, from a perturbed start, towards an image the graph itself rendered."""
+    rec, ts, ds, w, lat, _ = _tiny_setup()
+    with torch.no_grad():
+        target = rec.forward()[0].cpu().numpy()
+    rng = np.random.default_rng(12)
+    rec.assign(texture=lat["texture"] + 0.5 * rng.standard_normal(lat["texture"].shape).astype(np.float32),
+               light=lat["light"] + 0.3)
+    rec.etas.update(vector=0.0, param=0.0, texture=20.0, light=5.0)
+    losses = [rec.step(target).cpu().numpy().sum() for _ in range(12)]
+    assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_full_size_inverse_rendering_step():
+    """Reference sizes (64^3 -> 128^3 -> 512^2, five hypotheses): one step runs, every latent receives a finite
+    non-zero gradient; prints the step time."""
+    import time
+    from rendernet_amd import reconstruct as RC
+    rec = RC.Reconstructor(batch_size=5)
+    rng = np.random.default_rng(1)
+    rec.assign(vector=np.full((5, 200), 0.5, np.float32), param=RC.create_param_center(5, 270, 60, 90, 30),
+               texture=rng.standard_normal((5, 199)).astype(np.float32),
+               light=(np.linspace(230, 320, num=5) * math.pi / 180.0)[:, None])
+    target = rng.uniform(0, 1, (5, 512, 512, 3)).astype(np.float32)
+    tgt = torch.from_numpy(target).cuda()
+    l0 = rec.step(tgt).cpu().numpy()
+    for k, v in rec.latents.items():
+        g = v.grad.cpu().numpy()
+        assert np.isfinite(g).all() and np.abs(g).max() > 0, k
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rec.step(tgt)
+    torch.cuda.synchronize()
+    print("inverse-rendering step, 5 hypotheses at 64^3 -> 512^2: %.1f ms" % ((time.perf_counter() - t0) / 3 * 1e3))
+    assert l0.shape == (5,) and np.isfinite(l0).all()
