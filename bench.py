@@ -153,11 +153,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU render path)")
+    # RN_SHARE_GPU=1 + RN_DIST_BACKEND=gloo: several ranks on one device, control collectives over gloo -- only for
+    # smoke-testing the multi-rank launch path on a single-GPU box (RCCL refuses two ranks on one device)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not os.environ.get("RN_SHARE_GPU"):
+            raise SystemExit("LOCAL_RANK=%d but only %d HIP device(s) visible" % (local_rank, ndev))
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rendernet_amd import ops
     from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights

@@ -22,6 +22,28 @@ def read_binvox(path):
     return np.transpose(data, (0, 2, 1))
 
 
+def write_binvox_bytes(data, dims, translate=(0.0, 0.0, 0.0), scale=1.0, axis_order='xyz'):
+    """tools/binvox_rw.py:175-226 as the per-voxel state machine it is (pure-Python loop: small cases only)."""
+    out = bytearray()
+    out += ('#binvox 1\n' + 'dim ' + ' '.join(map(str, dims)) + '\n' + 'translate ' + ' '.join(map(str, translate)) + '\n' +
+            'scale ' + str(scale) + '\n' + 'data\n').encode('latin-1')
+    flat = (data.flatten() if axis_order == 'xzy' else np.transpose(data, (0, 2, 1)).flatten()).astype(np.uint8)
+    state, ctr = int(flat[0]), 0
+    for c in flat:
+        c = int(c)
+        if c == state:
+            ctr += 1
+            if ctr == 255:                      # :212-215
+                out += bytes((state, ctr))
+                ctr = 0
+        else:                                   # :216-220
+            out += bytes((state, ctr))
+            state, ctr = c, 1
+    if ctr > 0:                                 # :222-224
+        out += bytes((state, ctr))
+    return bytes(out)
+
+
 def compute_pose_param(azimuth, elevation, radius):
     """RenderNet_demo.py:33-38 (== tools/data_util.py:111-118)."""
     phi = azimuth * math.pi / 180.0

@@ -58,6 +58,17 @@ void resample_prepare_kernel(const float* __restrict__ vox, const float* __restr
                              unsigned* __restrict__ ws_nb, int S, int N, int NC)
 {
     const int b = blockIdx.y;
+    // the LAST block of each item only builds the matrix: the double-precision trigonometry is a ~4 us dependent
+    // chain on one lane, which used to sit behind the loads of block 0 on the kernel's critical path
+    const int nblk = gridDim.x - 1;
+    if ((int)blockIdx.x == nblk) {
+        if (threadIdx.x == 0) {
+            float* m = ws_mat + MAT_STRIDE * b;
+            if (FROM_POSE) pose_to_affine_t(mat_or_pose + 3 * b, S, N, m);
+            else for (int q = 0; q < 12; ++q) m[q] = mat_or_pose[12 * b + q];
+        }
+        return;
+    }
     int nonbin = (CT == 1) ? 0 : 1;            // some non-zero voxel differs from 1.0f (occupancy grids are {0,1})
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int VW = S >= 32 ? S >> 5 : 1;
@@ -99,12 +110,7 @@ void resample_prepare_kernel(const float* __restrict__ vox, const float* __restr
     if (live && (threadIdx.x & 15) == 0) ws_occ[((size_t)b * NC + cz) * NC + cy] = cellbits;
     // every (block, item) slot is rewritten by every call: no zeroing, no atomics
     nonbin = __syncthreads_or(nonbin);
-    if (threadIdx.x == 0) ws_nb[(size_t)b * gridDim.x + blockIdx.x] = (unsigned)nonbin;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float* m = ws_mat + MAT_STRIDE * b;
-        if (FROM_POSE) pose_to_affine_t(mat_or_pose + 3 * b, S, N, m);
-        else for (int q = 0; q < 12; ++q) m[q] = mat_or_pose[12 * b + q];
-    }
+    if (threadIdx.x == 0) ws_nb[(size_t)b * nblk + blockIdx.x] = (unsigned)nonbin;
 }
 
 __device__ __forceinline__ float coord_t(float m0, float m1, float m2, float m3, float x, float y, float z)
@@ -162,7 +168,7 @@ struct TiledArgs {
     const float* ws_mat;     // [B,MAT_STRIDE]
     const unsigned* ws_occ;  // [B,NC,NC]
     const unsigned* ws_vbit; // [B,S,S,VW]
-    const unsigned* ws_nb;   // [B, nprep]  per prepare-block flag: a non-zero voxel other than 1.0f was seen
+    unsigned* ws_nb;         // [B, nprep] per prepare-block flag: a non-zero voxel other than 1.0f was seen; then [B]: their OR (classify)
     int nprep;
     unsigned* ws_colmask;    // [B, ph/8, pw/8]  bit kt = tile (column, kt) is a candidate
     uint2* ws_box;           // [B, ph/8, pw/8, 32]  box of tile kt: {bx0|bx1<<8|by0<<16|by1<<24, bz0|bz1<<8}
@@ -218,6 +224,14 @@ void resample_classify_kernel(const TiledArgs a)
     const long long col = (long long)blockIdx.x * 4 + wave;
     if (col >= (long long)a.B * nti * ntj) return;
     const int tj = (int)(col % ntj), ti = (int)((col / ntj) % nti), b = (int)(col / ((long long)ntj * nti));
+    if (ti == 0 && tj == 0) {
+        // the item's first column also folds the prepare blocks' "non-binary voxel seen" flags into one word, so that
+        // a sampler workgroup reads one scalar instead of walking nprep of them
+        unsigned nb = 0u;
+        for (int q = lane; q < a.nprep; q += 64) nb |= a.ws_nb[(size_t)b * a.nprep + q];
+        const unsigned long long any = __ballot(nb != 0u);
+        if (lane == 0) a.ws_nb[(size_t)a.B * a.nprep + b] = any ? 1u : 0u;
+    }
     float m[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) m[q] = a.ws_mat[MAT_STRIDE * b + q];
@@ -329,8 +343,7 @@ void resample_main_kernel(const TiledArgs a)
     float m[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) m[q] = mp[q];
-    unsigned nonbin = 0;
-    for (int q = 0; q < a.nprep; ++q) nonbin |= a.ws_nb[(size_t)b * a.nprep + q];
+    const unsigned nonbin = a.ws_nb[(size_t)a.B * a.nprep + b];
     const bool binary = CT == 1 && nonbin == 0u && a.debug != 5;
 
     // ---- a. the boxes the classifier recorded (uniform addresses -> scalar loads, no barrier) ----
@@ -535,7 +548,8 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
     unsigned* ws_nb = reinterpret_cast<unsigned*>(ws + o_nb);
     unsigned* ws_colmask = reinterpret_cast<unsigned*>(ws + o_mask);
     uint2* ws_box = reinterpret_cast<uint2*>(ws + o_box);
-    dim3 pgrid((NC * NC * 16 + 255) / 256, B);
+    const int nprep = (NC * NC * 16 + 255) / 256;             // prepare blocks (= flag slots) per item
+    dim3 pgrid(nprep + 1, B);                                 // + the matrix block
     if (C == 1) {
         if (from_pose) hipLaunchKernelGGL((resample_prepare_kernel<1, true>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
         else hipLaunchKernelGGL((resample_prepare_kernel<1, false>), pgrid, dim3(256), 0, st, vox, mat_or_pose, ws_mat, ws_occ, ws_vbit, ws_nb, S, N, NC);
@@ -557,7 +571,7 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
     if (ratio < 1) ratio = 1;
     const long long groups = nfill > (nsub + ratio - 1) / ratio ? nfill : (nsub + ratio - 1) / ratio;
     if (groups * (ratio + 1) > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
-    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, (int)pgrid.x, ws_colmask, ws_box, out, B, S, N, NC, h0, w0, ph, pw,
+    TiledArgs a{vox, ws_mat, ws_occ, ws_vbit, ws_nb, nprep, ws_colmask, ws_box, out, B, S, N, NC, h0, w0, ph, pw,
                 image_layout, dbg, (int)ratio, (int)nfill, (int)nsub};
     hipLaunchKernelGGL(resample_classify_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, st, a);
     rc = rn_check_launch("resample_classify");

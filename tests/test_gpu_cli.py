@@ -70,3 +70,34 @@ def test_demo_cli_renders_and_names_files_like_the_reference(tmp_path):
                                            RenderNet_demo.AMBIENT_IN, RenderNet_demo.K_DIFFUSE).cpu().numpy()
     want = OP.np_phong_composite(normals, light, RenderNet_demo.LIGHT_COL, RenderNet_demo.AMBIENT_IN, RenderNet_demo.K_DIFFUSE)
     assert np.abs(got - want).max() <= 1e-5
+
+
+def test_reconstruct_script_runs_and_writes_the_reference_outputs(tmp_path, capsys):
+    """`python Reconstruct_RenderNet_Face.py <config.json>` (config_reconstruction_RenderNet.json keys): shaded target,
+    two latent-descent steps of the five hypotheses at full size, per-hypothesis dumps with the reference's file names."""
+    from PIL import Image
+    import Reconstruct_RenderNet_Face
+    from rendernet_amd.tools import binvox_rw
+    rng = np.random.default_rng(0)
+    for name in ("albedo.png", "normal.png"):
+        Image.fromarray((rng.random((512, 512, 3)) * 255).astype(np.uint8)).save(str(tmp_path / name))
+    cfg = {"target_albedo": str(tmp_path / "albedo.png"), "target_normal": str(tmp_path / "normal.png"),
+           "target_azimuth_light": 294, "target_elevation_light": 105, "weight_dir": str(tmp_path / "nope"),
+           "weight_dir_decoder": str(tmp_path / "nope2"), "gpu": 0, "batch_size": 5, "z_dim": 200, "inner_step": 2,
+           "max_epochs": 1, "threshold": 0.1, "shape_eta": 0.8, "pose_eta": 0.01, "tex_eta": 0.8, "light_eta": 0.4,
+           "keep_prob": 1.0, "decay_steps": 90000, "trained_model_name": "RenderNet_recon", "sample_save": str(tmp_path / "out"),
+           "checkpoint_secs": 7200}
+    cfgp = str(tmp_path / "config.json")
+    json.dump(cfg, open(cfgp, "w"))
+    Reconstruct_RenderNet_Face.main([cfgp, "--max-steps", "2"])
+    out = capsys.readouterr().out
+    assert "BEST LOSS" in out and "BEST PARAM" in out
+    files = sorted(os.listdir(cfg["sample_save"]))
+    assert "shaded_target.png" in files and "shading.png" in files and "config.json" in files and "2_loss_.txt.npz" in files
+    jpgs = [f for f in files if f.endswith(".jpg")]
+    assert len(jpgs) == 5 and all(f.split("_")[1] == "2" for f in jpgs)
+    vox = [f for f in files if f.endswith(".binvox")]
+    assert len(vox) == 5
+    with open(os.path.join(cfg["sample_save"], vox[0]), "rb") as fh:
+        assert binvox_rw.read_as_3d_array(fh).data.shape == (64, 64, 64)
+    assert np.load(os.path.join(cfg["sample_save"], "2_loss_.txt.npz"))["arr_0"].shape == (5,)

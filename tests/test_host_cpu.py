@@ -199,3 +199,27 @@ def test_data_loader_tar_and_pose_parsing(tmp_path):
     # colour images keep 3 channels
     ims3 = next(data_util.data_loader(cfg, tarp, str(tmp_path), flatten=False, img_res=32))[0]
     assert ims3.shape == (2, 32, 32, 3) and np.array_equal(ims3[0], imgs[0].astype(np.float32))
+
+
+def test_binvox_writer_matches_reference_state_machine(tmp_path):
+    """tools/binvox_rw.py:175-239: the vectorised writer emits the bytes of the reference's per-voxel state machine
+    (runs cut at 255, the (value, 0) pair after a run that is a multiple of 255) and round-trips through the reader."""
+    import io
+    from rendernet_amd.tools import binvox_rw as B
+    from oracle import io_phong as OP
+    rng = np.random.default_rng(0)
+    cases = [np.zeros((8, 8, 8), bool), np.ones((8, 8, 8), bool), rng.random((7, 9, 9)) < 0.3, rng.random((16, 16, 16)) < 0.02]
+    d = np.zeros((255 * 3, 1, 1), bool); d[255 * 2:] = True            # 510 zeros, 255 ones (final run a multiple of 255)
+    cases.append(d)
+    d = np.zeros((255 * 3 + 7, 1, 1), bool); d[255:510] = True         # 255 zeros, 255 ones, 262 zeros
+    cases.append(d)
+    for d in cases:
+        f = io.BytesIO()
+        B.write(B.Voxels(d, list(d.shape), [0.0, 0.0, 0.0], 1.0, 'xyz'), f)
+        assert f.getvalue() == OP.write_binvox_bytes(d, list(d.shape))
+        assert np.array_equal(B.read_as_3d_array(io.BytesIO(f.getvalue())).data, d)
+    path = str(tmp_path / "v.binvox")
+    B.save_binvox(cases[3], path)
+    with open(path, 'rb') as fh:
+        m = B.read_as_3d_array(fh)
+    assert np.array_equal(m.data, cases[3]) and m.dims == [16, 16, 16] and m.scale == 1.0
