@@ -287,6 +287,190 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st)
     return rn_check_launch("conv_wgrad");
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3x3, stride 1, 32 -> 32 channels (the 21 convs of the 3-D encoder's residual stack,
+// RenderNet_Shader.py:48-64): depth-run variant.  The generic kernel gives one workgroup ONE tap, so the
+// G rows (and the A rows, shifted) are re-read 27 times through L2 -- 8 flop per byte, L2-bound at
+// 55-73 TFLOP/s.  Here a workgroup owns one (t0,t1) pair and accumulates its THREE depth taps from one
+// staged slab: per stage 4 (b,h,w) columns x 32 depth positions of G (16 KiB) and the same columns of A
+// shifted by (t0-1, t1-1) with one halo row on either side in depth (4 x 34 rows, 17 KiB; rows outside
+// the volume come back as zeros from the buffer bounds check) -- tap t2 of position d is slab row d+t2.
+// 24 flop per staged byte.  Wave w reduces column w: 16 k-steps x 3 taps per stage, three 32x32
+// accumulators; the four waves' partials are summed through LDS and added to dw with fp32 atomics
+// (3072 per workgroup).  blockIdx % 8 = split % 8: the nine pairs that stream the same slabs share an XCD.
+// ------------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+    const float* a; const float* g; float* dw;
+    unsigned a_bytes, g_bytes;
+    int H, W, D, ncols, ndch, nitems, ipw, nsplit;
+};
+
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
+{
+    constexpr int C = 32, COLS = 4, TD = 32, ROWS = TD + 2, NROWS = COLS * ROWS;     // 136 slab rows
+    constexpr int ASZ = NROWS * C;                      // 4352 floats: 17 DMA instructions of 8 rows
+    constexpr int GSZ = COLS * TD * C;                  // 4096 floats: 16 DMA instructions
+    constexpr int NAI = NROWS / 8;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);         // [2][136][32]
+    float* Gs = As + 2 * ASZ;                           // [2][128][32]
+    __shared__ unsigned colA[2][COLS], colG[2][COLS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    int id = blockIdx.x;
+    const int xs = id & 7; id >>= 3;
+    const int pair = id % 9, split = (id / 9) * 8 + xs;
+    if (split >= a.nsplit) return;
+    const int t0 = pair / 3, t1 = pair % 3;
+    const int ibeg = split * a.ipw, iend = min(a.nitems, ibeg + a.ipw);
+    if (ibeg >= iend) return;
+
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.g_bytes, 0x00020000);
+
+    // DMA assignment.  A: wave w issues instructions q = w, w+4, ... (< 17); lane -> slab row 8q + lane/8,
+    // 16-B chunk lane%8.  G: wave w issues q = 4w .. 4w+3; lane -> row 8q + lane/8.
+    int acol[5], arow[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int q = wave + 4 * p;
+        const int rr = q * 8 + (lane >> 3);
+        acol[p] = (q < NAI) ? rr / ROWS : 0;
+        arow[p] = (q < NAI) ? rr % ROWS : -0x40000000;
+    }
+    const unsigned cbytes = (unsigned)((lane & 7) * 16);
+    int gcol[4], grow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = (wave * 4 + j) * 8 + (lane >> 3);
+        gcol[j] = rr / TD; grow[j] = rr % TD;
+    }
+
+    auto setup_cols = [&](int buf, int item) {
+        if (tid < COLS) {
+            const int col = (item / a.ndch) * COLS + tid;
+            unsigned ao = OOB, go = OOB;
+            if (item < iend && col < a.ncols) {
+                const int w = col % a.W, h = (col / a.W) % a.H, b = col / (a.W * a.H);
+                const int hh = h + t0 - 1, ww = w + t1 - 1;
+                if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
+                    ao = (unsigned)((b * a.H + hh) * a.W + ww) * (unsigned)(a.D * C * 4);
+                go = (unsigned)col * (unsigned)(a.D * C * 4);
+            }
+            colA[buf][tid] = ao; colG[buf][tid] = go;
+        }
+    };
+    auto issue_dma = [&](int buf, int item, int stage) {
+        const int d0 = (item % a.ndch) * TD;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            if (p < 4 || wave == 0) {
+                const unsigned cb = colA[buf][acol[p]];
+                const int dd = d0 - 1 + arow[p];
+                const unsigned off = ((cb & OOB) || (unsigned)dd >= (unsigned)a.D) ? OOB : cb + (unsigned)dd * (C * 4) + cbytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(As + stage * ASZ + (wave + 4 * p) * 256), 16, off, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned cb = colG[buf][gcol[j]];
+            const int dd = d0 + grow[j];
+            const unsigned off = ((cb & OOB) || dd >= a.D) ? OOB : cb + (unsigned)dd * (C * 4) + cbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void*)(Gs + stage * GSZ + (wave * 4 + j) * 256), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    setup_cols(0, ibeg);
+    setup_cols(1, ibeg + 1);
+    __syncthreads();
+    issue_dma(0, ibeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int item = ibeg; item < iend; ++item) {
+        const int n = item - ibeg;
+        if (item + 1 < iend) issue_dma((n + 1) & 1, item + 1, cur ^ 1);
+        // the column table of item + 2 goes where item's was: item's DMA was issued one iteration ago, and the
+        // table of item + 1 (read just above) sits in the other slot
+        const float* Ab = As + cur * ASZ + (wave * ROWS + lh) * C + li;     // slab row (2kk + lh) + t2
+        const float* Gb = Gs + cur * GSZ + (wave * TD + lh) * C + li;
+        float g[2], x0[2], x1[2], x2[2];
+        g[0] = Gb[0]; x0[0] = Ab[0]; x1[0] = Ab[C]; x2[0] = Ab[2 * C];
+#pragma unroll
+        for (int kk = 0; kk < TD / 2; ++kk) {
+            if (kk + 1 < TD / 2) {
+                const int o = (kk + 1) * 2 * C;
+                g[(kk + 1) & 1] = Gb[o]; x0[(kk + 1) & 1] = Ab[o]; x1[(kk + 1) & 1] = Ab[o + C]; x2[(kk + 1) & 1] = Ab[o + 2 * C];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[kk & 1], g[kk & 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[kk & 1], g[kk & 1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x2[kk & 1], g[kk & 1], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        setup_cols(n & 1, item + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // sum the four waves' partial tiles through LDS (the stage buffers are dead), then one atomic per output
+    float* red = As;                                    // [4 waves][3 taps][32 ca][32 cg] = 48 KiB
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ca = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        red[((wave * 3 + 0) * C + ca) * C + li] = acc0[r];
+        red[((wave * 3 + 1) * C + ca) * C + li] = acc1[r];
+        red[((wave * 3 + 2) * C + ca) * C + li] = acc2[r];
+    }
+    __syncthreads();
+    float* dwp = a.dw + (size_t)pair * 3 * C * C;       // taps (t0,t1,0..2) are adjacent in [3,3,3,Ca,Cg]
+    for (int e = tid; e < 3 * C * C; e += 256) {
+        const float v = (red[e] + red[3 * C * C + e]) + (red[2 * 3 * C * C + e] + red[3 * 3 * C * C + e]);
+        unsafeAtomicAdd(dwp + e, v);
+    }
+}
+
+static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, int H, int W, int D,
+                              unsigned a_bytes, unsigned g_bytes, hipStream_t st)
+{
+    Wgrad3Args a;
+    a.a = A; a.g = G; a.dw = dw; a.a_bytes = a_bytes; a.g_bytes = g_bytes;
+    a.H = H; a.W = W; a.D = D;
+    a.ncols = B * H * W;
+    a.ndch = (D + 31) / 32;
+    a.nitems = ((a.ncols + 3) / 4) * a.ndch;
+    static const int target_wgs = getenv("RN_WGRAD_WGS") ? atoi(getenv("RN_WGRAD_WGS")) : 3072;
+    int ns = (target_wgs + 8) / 9;
+    if (ns > (a.nitems + 3) / 4) ns = (a.nitems + 3) / 4;          // at least 4 stages per workgroup
+    if (ns < 1) ns = 1;
+    a.ipw = (a.nitems + ns - 1) / ns;
+    a.nsplit = (a.nitems + a.ipw - 1) / a.ipw;
+    const long long nb = (long long)((a.nsplit + 7) / 8) * 72;
+    const size_t lds = (size_t)2 * (136 * 32 + 128 * 32) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_k3d32_kernel, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch("conv_wgrad_k3d32");
+}
+
 // A [B,I0,I1,I2,Ca], G [B,O0,O1,O2,Cg] -> dw [K0,K1,K2,Ca,Cg] (accumulated)
 int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const int* I, int Ca,
                          const int* O, int Cg, const int* K, const int* S, const int* P, hipStream_t st)
@@ -322,6 +506,10 @@ int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const
     if (M <= 0 || M > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: M=%lld", M);
     a.M = (int)M;
     const int taps = K[0] * K[1] * K[2];
+    static const bool no_k3d = getenv("RN_WGRAD_NO_K3D") != nullptr;
+    if (!no_k3d && Ca == 32 && Cg == 32 && K[0] == 3 && K[1] == 3 && K[2] == 3 && S[0] == 1 && S[1] == 1 && S[2] == 1 &&
+        P[0] == 1 && P[1] == 1 && P[2] == 1 && O[0] == I[0] && O[1] == I[1] && O[2] == I[2])
+        return launch_wgrad_k3d32(A, G, dw, B, I[0], I[1], I[2], a.a_bytes, a.g_bytes, st);
     if (Ca % 4 != 0 || Cg % 4 != 0 || Ca < 8) {
         // narrow path: one thread per (tap, ca)
         if ((long long)taps * Ca > 1024 || Cg > 16)

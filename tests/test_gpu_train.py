@@ -63,6 +63,8 @@ LAYER_CASES = [
     ("conv3d", 2, (8, 8, 4), 16, 32, 3, (1, 1, 1), True, False),       # e_conv3
     ("conv3d", 2, (8, 8, 4), 32, 32, 3, (1, 1, 1), True, False),       # res1 first conv (PReLU)
     ("conv3d", 1, (5, 7, 3), 32, 32, 3, (1, 1, 1), False, True),       # res1 second conv (residual), ragged
+    ("conv3d", 3, (4, 5, 40), 32, 32, 3, (1, 1, 1), True, False),      # depth-run wgrad: two depth chunks, ragged second one
+    ("conv3d", 1, (6, 6, 32), 32, 32, 3, (1, 1, 1), False, False),     # depth-run wgrad: one full 32-deep chunk per column
     ("conv2d", 2, (16, 16), 256, 256, 3, (1, 1), True, False),         # res2-like: 128x128 wgrad tiles
     ("conv2d", 1, (9, 11), 128, 64, 3, (1, 1), False, True),           # ragged, 128x128 tile with channel tail
     ("conv2d", 2, (8, 8), 256, 128, 4, (1, 1), True, False),           # e_conv5-like 4x4 (pad 1,2)
