@@ -379,8 +379,10 @@ void resample_main_kernel(const TiledArgs a)
                 for (int half = 0; half < 2; ++half) {
                     const int r = tid + 256 * half;
                     if (r < rows) {
-                        const int z = (int)(((float)r + 0.5f) * rny), y = r - z * ny;
-                        const unsigned* vr = a.ws_vbit + (((size_t)b * S + bz0 + z) * S + by0 + y) * VW + xw0;
+                        // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): every factor here is < 2^12
+                        const int z = (int)(((float)r + 0.5f) * rny), y = r - __mul24(z, ny);
+                        const unsigned* vr = a.ws_vbit + (size_t)b * S * S * VW +
+                                             (unsigned)(__mul24(__mul24(bz0 + z, S) + by0 + y, VW) + xw0);
                         // the 32 bits starting at voxel bx0: the only 64-bit shift of this row (none per sample)
                         const unsigned long long w64 = ((unsigned long long)((xw0 + 1 < VW) ? vr[1] : 0u) << 32) | vr[0];
                         rv[tt][half] = (unsigned)(w64 >> (bx0 - xw0 * 32));
@@ -430,7 +432,7 @@ void resample_main_kernel(const TiledArgs a)
             const int sx0 = u.x0 - bx0, sx1 = u.x1 - bx0;
             if (vt[tt]) {
                 // a sample whose eight taps are all zero is exactly zero
-                const int rz0 = (u.z0 - bz0) * ny, rz1 = (u.z1 - bz0) * ny, ry0 = u.y0 - by0, ry1 = u.y1 - by0;
+                const int rz0 = __mul24(u.z0 - bz0, ny), rz1 = __mul24(u.z1 - bz0, ny), ry0 = u.y0 - by0, ry1 = u.y1 - by0;
                 w00 = vrows[tt][rz0 + ry0]; w01 = vrows[tt][rz0 + ry1];
                 w10 = vrows[tt][rz1 + ry0]; w11 = vrows[tt][rz1 + ry1];
                 hit = ((w00 | w01 | w10 | w11) & ((1u << sx0) | (1u << sx1))) != 0u;
