@@ -17,9 +17,7 @@ two-head texture net of `rendernet_amd.texture` (same layers; the reference only
 `pretrained_key_map` translates the keys of its `*.txt.npz` weight folders).
 """
 from dataclasses import dataclass
-import glob
 import math
-import os
 
 import numpy as np
 import torch
@@ -30,6 +28,7 @@ from . import variables as V
 from .texture import TextureSpec, texture_variable_shapes, init_texture_weights, decoder_texture, RenderNetTexture
 from .tools import layer_util as LU
 from .tools import Phong_shading as Phong
+from .tools.model_util import load_weights  # noqa: F401  (tools/model_util.py:26-39)
 from .tools.resampling_voxel_grid import rotation_resampling_to_image
 from .variables import random_normal_initializer
 
@@ -97,15 +96,6 @@ def decoder_3d_pretrained(z_in, spec=None, taps=None):
 # ---------------------------------------------------------------------------------------------
 # pretrained weight folders (tools/model_util.py:26-39): one `<key>.txt.npz` per tensor, arr_0
 # ---------------------------------------------------------------------------------------------
-def load_weights(weight_dir):
-    """tools/model_util.py:26-39: {file stem up to the first '.': arr_0}."""
-    out = {}
-    for path in glob.glob(os.path.join(weight_dir, "*.txt.npz")):
-        with np.load(path) as data:
-            out[os.path.basename(path).split('.')[0]] = data['arr_0']
-    return out
-
-
 def pretrained_key_map(tex_spec=None, dec_spec=None):
     """{key in the reference's weight dicts: variable name here}.  Keys are the TF variable names with '/' -> '_' and
     the outer 'encoder' / 'texture_encoder' scope dropped (Reconstruct_RenderNet_Face.py:40-326); the pretrained

@@ -129,3 +129,19 @@ def test_every_path_of_the_tiled_resampler_is_bit_exact(fixtures_vox):
         want = OR.transform_voxel_to_match_image(OR.resampling_affine(vox, m_inv, N, mode="ordered"))
         got = tf_resampling_affine(_dev(vox), _dev(m_inv), N, image_layout=True).cpu().numpy()
         assert np.array_equal(got, want), "scales %s: max |diff| = %g" % (scales, np.abs(got - want).max())
+
+
+def test_empty_and_full_grids(fixtures_vox):
+    """Degenerate occupancies: an all-zero grid (no candidate tile anywhere: the output is pure fill), an all-one
+    grid (every tile a candidate, clamped border taps everywhere) and a single occupied voxel in a corner."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    S, N = 64, 128
+    corner = np.zeros((1, S, S, S, 1), np.float32)
+    corner[0, 0, S - 1, 0, 0] = 1.0
+    vox = np.concatenate([np.zeros((1, S, S, S, 1), np.float32), np.ones((1, S, S, S, 1), np.float32), corner])
+    poses = np.stack([demo_pose(250, 60, 3.3), demo_pose(10, 30, 2.0), demo_pose(135, 80, 5.0)])
+    m_inv = OR.inverse_affine(poses, S, N)
+    want = OR.transform_voxel_to_match_image(OR.resampling_affine(vox, m_inv, N, mode="ordered"))
+    got = tf_resampling_affine(_dev(vox), _dev(m_inv), N, image_layout=True).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert not got[0].any() and got[1].max() <= 1.0 + 1e-6 and got[2].any()
