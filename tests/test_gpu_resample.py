@@ -139,9 +139,11 @@ def test_empty_and_full_grids(fixtures_vox):
     corner = np.zeros((1, S, S, S, 1), np.float32)
     corner[0, 0, S - 1, 0, 0] = 1.0
     vox = np.concatenate([np.zeros((1, S, S, S, 1), np.float32), np.ones((1, S, S, S, 1), np.float32), corner])
-    poses = np.stack([demo_pose(250, 60, 3.3), demo_pose(10, 30, 2.0), demo_pose(135, 80, 5.0)])
+    poses = np.stack([demo_pose(250, 60, 3.3), demo_pose(10, 30, 2.0), demo_pose(135, 80, 3.3)])
     m_inv = OR.inverse_affine(poses, S, N)
     want = OR.transform_voxel_to_match_image(OR.resampling_affine(vox, m_inv, N, mode="ordered"))
     got = tf_resampling_affine(_dev(vox), _dev(m_inv), N, image_layout=True).cpu().numpy()
     assert np.array_equal(got, want)
-    assert not got[0].any() and got[1].max() <= 1.0 + 1e-6 and got[2].any()
+    # all-one grid: samples outside the volume along an axis take both taps from the clamped border voxel with weights
+    # that cancel only up to rounding (a few 1e-5), exactly as the reference's clamp-then-weight arithmetic does
+    assert not got[0].any() and got[1].max() <= 1.0 + 1e-5 and got[1].min() >= -1e-4 and got[2].any()
