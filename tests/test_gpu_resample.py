@@ -133,11 +133,12 @@ def test_every_path_of_the_tiled_resampler_is_bit_exact(fixtures_vox):
 
 def test_empty_and_full_grids(fixtures_vox):
     """Degenerate occupancies: an all-zero grid (no candidate tile anywhere: the output is pure fill), an all-one
-    grid (every tile a candidate, clamped border taps everywhere) and a single occupied voxel in a corner."""
+    grid (every tile a candidate, clamped border taps everywhere) and two isolated voxels (a corner, an interior one)."""
     from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
     S, N = 64, 128
     corner = np.zeros((1, S, S, S, 1), np.float32)
-    corner[0, 0, S - 1, 0, 0] = 1.0
+    corner[0, 0, S - 1, 0, 0] = 1.0                                       # border voxel: only clamped taps reach it
+    corner[0, 5, 40, 17, 0] = 1.0                                         # and one isolated interior voxel
     vox = np.concatenate([np.zeros((1, S, S, S, 1), np.float32), np.ones((1, S, S, S, 1), np.float32), corner])
     poses = np.stack([demo_pose(250, 60, 3.3), demo_pose(10, 30, 2.0), demo_pose(135, 80, 3.3)])
     m_inv = OR.inverse_affine(poses, S, N)
