@@ -235,3 +235,18 @@ def test_full_size_inverse_rendering_step():
     torch.cuda.synchronize()
     print("inverse-rendering step, 5 hypotheses at 64^3 -> 512^2: %.1f ms" % ((time.perf_counter() - t0) / 3 * 1e3))
     assert l0.shape == (5,) and np.isfinite(l0).all()
+
+
+def test_numpy_phong_front_end_matches_reference_outputs():
+    """The HIP composite behind np_phong_composite vs outputs of the reference's own NumPy functions
+    (tests/golden/reference_vectors.npz, tools/Phong_shading.py:138-228) incl. pixels on both masks' transition bands."""
+    import os
+    from conftest import GOLDEN_DIR
+    from rendernet_amd.tools import Phong_shading
+    ref = np.load(os.path.join(GOLDEN_DIR, "reference_vectors.npz"))
+    img, light, col = ref["phong_img"].astype(np.float32), ref["phong_light"].astype(np.float32), ref["phong_col"].astype(np.float32)
+    for key, kw in (("phong_black", dict(background_col="Black")), ("phong_white", dict(background_col="white")),
+                    ("phong_nomask", dict(with_mask=False))):
+        got = Phong_shading.np_phong_composite(img, light, col, 0.1, 0.9, **kw)
+        # float32 kernel vs the reference's float64 NumPy: the transition band has slope 64 per unit of |img|
+        assert np.abs(got - ref[key]).max() <= 3e-5, key

@@ -148,3 +148,22 @@ def test_empty_and_full_grids(fixtures_vox):
     # all-one grid: samples outside the volume along an axis take both taps from the clamped border voxel with weights
     # that cancel only up to rounding (a few 1e-5), exactly as the reference's clamp-then-weight arithmetic does
     assert not got[0].any() and got[1].max() <= 1.0 + 1e-5 and got[1].min() >= -1e-4 and got[2].any()
+
+
+def test_hip_resampler_matches_the_reference_np_interpolate_bit_for_bit():
+    """tests/golden/reference_vectors.npz holds outputs of the REFERENCE'S OWN np_interpolate
+    (tools/resampling_voxel_grid.py:19-128, the NumPy twin of tf_interpolate) for the chair fixture at the demo pose,
+    every 37th sample of the 128^3 grid: the HIP kernel's samples at those points are identical."""
+    import os
+    from conftest import GOLDEN_DIR
+    from rendernet_amd.tools.resampling_voxel_grid import tf_resampling_affine
+    ref = np.load(os.path.join(GOLDEN_DIR, "reference_vectors.npz"))
+    chair = np.unpackbits(ref["interp_chair_demo_pose_ordered_vox"]).reshape(1, 64, 64, 64, 1).astype(np.float32)
+    got = tf_resampling_affine(_dev(chair), _dev(ref["interp_chair_M_inv"]), 128, image_layout=False).cpu().numpy().reshape(-1)
+    want = ref["interp_chair_demo_pose_ordered_out"]
+    assert np.count_nonzero(want) > 100
+    assert np.array_equal(got[5::37], want)
+    # float-valued volume through the general (non-occupancy-grid) path: scale the chair by 0.37
+    got2 = tf_resampling_affine(_dev(chair * np.float32(0.37)), _dev(ref["interp_chair_M_inv"]), 128, image_layout=False)
+    nz = want != 0
+    assert np.abs(got2.cpu().numpy().reshape(-1)[5::37][nz] / np.float32(0.37) - want[nz]).max() <= 1e-6
