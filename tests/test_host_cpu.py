@@ -242,3 +242,23 @@ def test_texture_crop_helpers_share_one_window():
     g = torch.Generator().manual_seed(0)
     a2, _, c2 = M.tf_random_crop_voxel_texture_image(v, t, im, 4, generator=g)
     assert a2.shape == (2, 4, 4, 4, 1) and c2.shape == (2, 16, 16, 3)
+
+
+def test_create_tar_feeds_the_tar_reader(tmp_path):
+    """tools/create_TAR.py -> tools/utils.py::NpyTarReader: PNG members come back as (float32 image, name without extension)."""
+    from PIL import Image
+    from rendernet_amd.tools.create_TAR import create_tar
+    from rendernet_amd.tools.utils import NpyTarReader
+    rng = np.random.default_rng(0)
+    imgs = {}
+    for name in ("model_chair_a_p250_t30_r3.3", "model_chair_b_p10_t100_r3.3"):
+        arr = (rng.random((16, 16)) * 255).astype(np.uint8)
+        Image.fromarray(arr).save(str(tmp_path / (name + ".png")))
+        imgs[name] = arr
+    (tmp_path / "notes.txt").write_text("ignored")
+    tarp = str(tmp_path / "set.tar")
+    assert create_tar(str(tmp_path), tarp) == 2
+    got = dict((n, im) for im, n in NpyTarReader(tarp))
+    assert set(got) == set(imgs)
+    for n in imgs:
+        assert got[n].dtype == np.float32 and np.array_equal(got[n], imgs[n].astype(np.float32))
