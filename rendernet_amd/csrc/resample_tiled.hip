@@ -587,6 +587,8 @@ int rn_launch_resample_tiled(const float* vox, const float* mat_or_pose, bool fr
     // at B=24: 4 -> 63 us, 6 -> 58, 8 -> 59, 12 -> 60, 16 -> 65 (fill workgroups spaced further apart start later,
     // closer together they crowd the samplers out of the CUs)
     long long ratio = 2 * ((nsub + nfill - 1) / nfill);
+    static const int ratio_env = getenv("RN_RS_RATIO") ? atoi(getenv("RN_RS_RATIO")) : 0;   // tuning knob
+    if (ratio_env > 0) ratio = ratio_env;
     if (ratio < 1) ratio = 1;
     const long long groups = nfill > (nsub + ratio - 1) / ratio ? nfill : (nsub + ratio - 1) / ratio;
     if (groups * (ratio + 1) > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "resample: grid too large");
