@@ -161,25 +161,26 @@ void conv_wgrad_kernel(const WgradArgs a)
             issue_dma(s + 1, cur ^ 1);
             if (s + 2 < nstage) load_tab(s + 2);
         }
-        const float* Ab = As + cur * ASZ + lh * BM + wm * WTM + li;
-        const float* Gb = Gs + cur * GSZ + lh * BN + wn * WTN + li;
+        // lane li owns the TM (TN) ADJACENT channels li*TM.. of the wave tile, so that one ds_read_b64 feeds both
+        // 32x32 sub-tiles (sub-tile i = channels {li*TM + i}: an interleaved row set, undone in the epilogue)
+        const float* Ab = As + cur * ASZ + lh * BM + wm * WTM + li * TM;
+        const float* Gb = Gs + cur * GSZ + lh * BN + wn * WTN + li * TN;
         // Fragment reads run ONE k-step ahead of the MFMAs that consume them (two register sets, fully
         // unrolled): issued behind the MFMAs of the same step, each read's LDS latency (~100+ cycles) would
         // open a bubble in the matrix pipe after every 4 MFMAs (256 cycles) -- measured 122 -> see DESIGN.md.
         constexpr int KS = BK / 2 / WK;
-        float af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = Ab[wk * 2 * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Gb[wk * 2 * BN + j * 32];
+        typedef float fragA __attribute__((ext_vector_type(TM)));
+        typedef float fragG __attribute__((ext_vector_type(TN)));
+        fragA af[2];
+        fragG bf[2];
+        af[0] = *reinterpret_cast<const fragA*>(Ab + wk * 2 * BM);
+        bf[0] = *reinterpret_cast<const fragG*>(Gb + wk * 2 * BN);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             if (kk + 1 < KS) {
                 const int ks = (kk + 1) * WK + wk;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = Ab[ks * 2 * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = Gb[ks * 2 * BN + j * 32];
+                af[(kk + 1) & 1] = *reinterpret_cast<const fragA*>(Ab + ks * 2 * BM);
+                bf[(kk + 1) & 1] = *reinterpret_cast<const fragG*>(Gb + ks * 2 * BN);
             }
             __builtin_amdgcn_sched_barrier(0);     // keep the reads above the MFMAs (the scheduler sinks them back)
 #pragma unroll
@@ -198,13 +199,13 @@ void conv_wgrad_kernel(const WgradArgs a)
     float* dwt = a.dw + (size_t)tap * a.Ca * a.Cg;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int cg = cg0 + wn * WTN + j * 32 + li;
+        const int cg = cg0 + wn * WTN + li * TN + j;
         if (cg >= a.Cg) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ca = ca0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ca = ca0 + wm * WTM + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TM + i;
                 if (ca < a.Ca) unsafeAtomicAdd(dwt + (size_t)ca * a.Cg + cg, acc[i][j][r]);
             }
         }
