@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 130            /* 0.1.3: + ELU epilogue, differentiable Phong composite */
+#define RN_VERSION 140            /* 0.1.4: + Winograd F(2x2,3x3) path for the stride-1 3x3 2-D convs */
 
 /* error codes */
 #define RN_OK              0
@@ -46,6 +46,13 @@ extern "C" {
                                      becomes a flipped forward conv                               */
 #define RN_PACK_CONVT_S2    2     /* TF conv_transpose filter [4,4,(4,)Cout,Cin], stride 2:
                                      becomes 2^nd sub-pixel phase filters of 2 taps per dim       */
+
+#define RN_PACK_CONV_WINO       3  /* TF conv filter [3,3,Cin,Cout] -> Winograd F(2x2,3x3) transformed U = G g G^T
+                                     (16 planes, 16*Cin*Cout floats; Cin % 16 == 0, Cout % 32 == 0) for
+                                     rn_conv2d_wino_fwd                                                          */
+#define RN_PACK_CONVT_S1_WINO   4  /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same
+                                     transform: the input gradient of a stride-1 3x3 conv through
+                                     rn_conv2d_wino_fwd                                                          */
 
 int rn_version(void);
 const char* rn_last_error(void);
@@ -137,6 +144,18 @@ int rn_conv3d_transpose_fwd(const float* x, const float* w_packed, const float* 
 
 int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, const float* alpha,
                       float* y, int B, int H, int W, int D, int C, void* stream);
+
+/* Winograd F(2x2,3x3) form of rn_conv2d_fwd for the 3x3, stride-1, SAME convs of the 2-D trunk -- res_block_2d and
+ * the *_skip convs (tools/layer_util.py:101-104; RenderNet_Shader.py:71-84, :91-99), 86.9 % of the path's FLOPs: same
+ * arguments, epilogue and result (to fp32 rounding: the transforms reassociate the sum), 2.25x fewer multiplies, all
+ * in fp32.  w_wino comes from rn_pack_weights(RN_PACK_CONV_WINO); packed with RN_PACK_CONVT_S1_WINO from the layer's
+ * own TF filter it computes the layer's input gradient (dz [B,H,W,Cout_fwd] -> dx [B,H,W,Cin_fwd]).  preact may be
+ * NULL (see rn_conv2d_fwd_train).  rn_conv2d_wino_supported: 1 when this library takes (Cin, Cout) on that path
+ * (Cin % 16 == 0, Cout % 32 == 0, and the environment does not set RN_NO_WINOGRAD), else 0 -- use rn_conv2d_fwd. */
+int rn_conv2d_wino_supported(int Cin, int Cout);
+int rn_conv2d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
+                       const float* residual, float* y, float* preact,
+                       int B, int H, int W, int Cin, int Cout, int act, void* stream);
 
 /* fully_connected (tools/layer_util.py:311-343): y[B,out] = act(x[B,in] @ w[in,out] + bias).
  * w is the TF matrix unpacked ([in,out] row-major). */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("RN_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libre
 
 RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID, RN_ACT_ELU = 0, 1, 2, 4
 RN_PHONG_NP_BLACK, RN_PHONG_NP_WHITE, RN_PHONG_TF_BLACK, RN_PHONG_TF_WHITE, RN_PHONG_NO_MASK = 0, 1, 2, 3, 4
-RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2 = 0, 1, 2
+RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2, RN_PACK_CONV_WINO, RN_PACK_CONVT_S1_WINO = 0, 1, 2, 3, 4
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -32,6 +32,8 @@ SIGNATURES = {
     "rn_conv2d_transpose_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "rn_conv3d_transpose_fwd": (_c_int, [_c_vp] * 6 + [_c_int] * 9 + [_c_vp]),
     "rn_projection_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp]),
+    "rn_conv2d_wino_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "rn_prelu_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_int, _c_vp]),
     "rn_phong_composite_fwd": (_c_int, [_c_vp] * 3 + [_c_f, _c_f, _c_vp] + [_c_int] * 3 + [_c_vp]),

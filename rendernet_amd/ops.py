@@ -48,12 +48,26 @@ class PackedWeight:
         self.data = torch.empty(n, dtype=torch.float32, device=w_tf.device)
         self.w_tf = w_tf                  # the TF-layout master copy (what the optimiser updates)
         self._dgrad = None
+        # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 2-D filters whose channel counts the kernel takes;
+        # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
+        self.wino = None
+        wkind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO}.get(kind)
+        if (wkind is not None and ndim == 2 and self.kdims == [3, 3]
+                and lib.rn_conv2d_wino_supported(self.cin, self.cout)):
+            nw = lib.rn_packed_weight_floats(wkind, ndim, L.ivec(self.kdims), self.cin, self.cout)
+            if nw == 0:
+                raise L.RenderNetHipError("rn_packed_weight_floats (Winograd): %s" % lib.rn_last_error().decode())
+            self.wino_kind = wkind
+            self.wino = torch.empty(nw, dtype=torch.float32, device=w_tf.device)
         self.repack()
 
     def repack(self):
         """Re-derive the packed copies from the TF-layout master (after an optimiser step)."""
         L.check(L.lib().rn_pack_weights(self.kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
                                         L.ptr(self.w_tf), L.ptr(self.data), L.stream_ptr()), "rn_pack_weights")
+        if self.wino is not None:
+            L.check(L.lib().rn_pack_weights(self.wino_kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
+                                            L.ptr(self.w_tf), L.ptr(self.wino), L.stream_ptr()), "rn_pack_weights (Winograd)")
         if self._dgrad is not None:
             self._dgrad.repack()
 
@@ -88,7 +102,8 @@ def _act_code(alpha, sigmoid, elu=False):
 class _ForwardOnly(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
-        raise NotImplementedError("rendernet_amd: backward (training step, SURVEY K13) is not implemented yet")
+        raise NotImplementedError("rendernet_amd: this inference-only entry has no backward; inside ops.training(...) "
+                                  "the projection unit runs through the differentiable conv2d path instead")
 
 
 class _Resample(torch.autograd.Function):
@@ -213,6 +228,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
         return lib.rn_conv3d_fwd_train(*a, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d":
         B, H, W, Cin = x.shape
+        if pw.wino is not None and tuple(stride) == (1, 1):
+            return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *a[2:], B, H, W, Cin, pw.cout, act, st)
         return lib.rn_conv2d_fwd_train(*a, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d_transpose":
         B, H, W, Cin = x.shape
@@ -299,6 +316,10 @@ class _Conv(torch.autograd.Function):
             dp = pw.dgrad_pack(unit)
             if mode == "conv3d":
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+            elif mode == "conv2d" and unit and dp.wino is not None:
+                # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
+                rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
+                                            B, H, W, pw.cout, Cin, 0, st)
             elif mode == "conv2d":
                 rc = lib.rn_conv2d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode == "conv2d_transpose":

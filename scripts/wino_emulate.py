@@ -1,0 +1,124 @@
+"""Lane-level NumPy emulation of csrc/conv_wino.hip (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA).
+
+A development tool, not a product path: it restates the kernel's INDEX arithmetic -- block id -> (m-block,
+n-block), the LDS-DMA lane -> (pixel, chunk) map with its swizzle, the fragment-read addresses, the MFMA
+operand / accumulator lane maps, the packed filter layout of RN_PACK_CONV_WINO and the epilogue's output
+addressing -- so that all of it can be checked against a plain convolution on a CPU-only box before a GPU
+minute is spent.  tests/test_wino_layout.py runs it on small ragged shapes.
+"""
+import numpy as np
+
+WPW, WPH = 34, 18
+WNPIX = WPW * WPH
+WRAW_PIECES = 39
+WRAW_B = WRAW_PIECES * 1024
+WU_B = 16 * 4 * 32 * 16
+
+G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float32)
+
+
+def pack_wino(w_tf, transposed=False):
+    """TF conv filter [3,3,Cin,Cout] (or, transposed=True, a conv_transpose-style [3,3,Cout,Cin] read with
+    flipped taps) -> U = G g G^T packed [Cout/32][Cin/16][16 xi][4 kq][32 n][4 r], channel c = step*16 + kq*4 + r."""
+    w = np.asarray(w_tf, np.float32)
+    if transposed:
+        w = w[::-1, ::-1].transpose(0, 1, 3, 2)
+    cin, cout = w.shape[2], w.shape[3]
+    assert cin % 16 == 0 and cout % 32 == 0
+    u = np.einsum("ip,pqcn,jq->ijcn", G, w, G).astype(np.float32)          # [4,4,Cin,Cout]
+    u = u.reshape(16, cin // 16, 4, 4, cout // 32, 32)                    # xi, step, kq, r, nb, n
+    return np.ascontiguousarray(u.transpose(4, 1, 0, 2, 5, 3)).reshape(-1)
+
+
+def block_map(bid, mblocks, nblocks):
+    T = mblocks * nblocks
+    e = bid
+    if bid < (T & ~255):
+        s = bid >> 3
+        e = (s >> 5) * 256 + (bid & 7) * 32 + (s & 31)
+    per = 8 * nblocks
+    g, full = e // per, mblocks >> 3
+    rem, gs, g0 = e - g * per, 8, g
+    if g >= full:
+        rem, gs, g0 = e - full * per, mblocks - full * 8, full
+    return g0 * 8 + rem % gs, rem // gs
+
+
+def conv_wino_emulated(x, u_packed, cout, bias=None):
+    """x [B,H,W,Cin] float32 -> y [B,H,W,Cout]; follows the kernel thread by thread (vectorised over lanes)."""
+    B, H, W, Cin = x.shape
+    xf = np.ascontiguousarray(x, np.float32).reshape(-1)
+    y = np.full((B, H, W, cout), np.nan, np.float32)
+    bh, bw = (H + 15) // 16, (W + 31) // 32
+    mblocks, nblocks, nstep = B * bh * bw, cout // 32, Cin // 16
+    lane = np.arange(64)
+    l16, kq = lane & 15, lane >> 4
+    seen = set()
+    for bid in range(mblocks * nblocks):
+        mb, nb = block_map(bid, mblocks, nblocks)
+        assert (mb, nb) not in seen
+        seen.add((mb, nb))
+        bx, by, b = mb % bw, (mb // bw) % bh, mb // (bw * bh)
+        y0, x0 = by * 16 - 1, bx * 32 - 1
+        acc = np.zeros((8, 16, 2, 64, 4), np.float32)                     # wave, xi, nt, lane, r
+        for s in range(nstep):
+            lds = np.zeros((WRAW_B + WU_B) // 4, np.float32)
+            for wave in range(8):
+                for i in range(5):                                        # raw patch pieces
+                    p = wave + 8 * i
+                    if p >= WRAW_PIECES:
+                        continue
+                    q = p * 16 + (lane >> 2)
+                    py, px = q // WPW, q % WPW
+                    iy, ix = y0 + py, x0 + px
+                    ok = (q < WNPIX) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
+                    off = ((b * H + iy) * W + ix) * Cin * 4 + (((lane & 3) ^ ((px >> 1) & 3)) * 16) + s * 64
+                    for ln in range(64):
+                        dst = (p * 1024 + ln * 16) // 4
+                        lds[dst:dst + 4] = xf[off[ln] // 4: off[ln] // 4 + 4] if ok[ln] else 0.0
+                for i in range(4):                                        # filter pieces
+                    g = (nb * nstep + s) * 32768 + wave * 4096 + i * 1024
+                    dst = (WRAW_B + (wave * 4 + i) * 1024) // 4
+                    lds[dst:dst + 256] = u_packed[g // 4: g // 4 + 256]
+            for wave in range(8):
+                raddr = [(2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4) for hj in range(2)]
+                uaddr = WRAW_B + kq * 512 + l16 * 16
+                d = np.zeros((4, 4, 64, 4), np.float32)
+                for ai in range(4):
+                    for bi in range(4):
+                        ad = (raddr[bi >> 1] + (ai * WPW + bi) * 64) // 4
+                        d[ai, bi] = lds[ad[:, None] + np.arange(4)]
+                t = np.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])           # [i][bi]
+                v = np.stack([t[:, 0] - t[:, 2], t[:, 1] + t[:, 2], t[:, 2] - t[:, 1], t[:, 1] - t[:, 3]], 1)  # [i][j]
+                for xi in range(16):
+                    vv = v[xi // 4, xi % 4]                                                   # [lane, s]
+                    for nt in range(2):
+                        ad = (uaddr + xi * 2048 + nt * 256) // 4
+                        bb = lds[ad[:, None] + np.arange(4)]                                  # [lane, s]
+                        # MFMA 16x16x4 x4: A[row=l16][k=4kq+s], B[k=4kq+s][col=l16]
+                        A = np.zeros((16, 16), np.float32)
+                        Bm = np.zeros((16, 16), np.float32)
+                        A[l16[:, None], (4 * kq)[:, None] + np.arange(4)] = vv
+                        Bm[(4 * kq)[:, None] + np.arange(4), l16[:, None]] = bb
+                        D = A @ Bm                                                            # [row, col]
+                        # D -> lane (col = l16, rows 4kq..4kq+3)
+                        acc[wave, xi, nt] += D[(4 * kq)[:, None] + np.arange(4), l16[:, None]]
+        for wave in range(8):
+            ty = wave
+            for nt in range(2):
+                n = nb * 32 + nt * 16 + l16
+                for r in range(4):
+                    M = acc[wave, :, nt, :, r].reshape(4, 4, 64)
+                    sc = np.stack([M[:, 0] + M[:, 1] + M[:, 2], M[:, 1] - M[:, 2] - M[:, 3]], 1)   # [i][dx][lane]
+                    Y = np.stack([sc[0] + sc[1] + sc[2], sc[1] - sc[2] - sc[3]])                   # [dy][dx][lane]
+                    tx = 4 * kq + r
+                    for dy in range(2):
+                        for dx in range(2):
+                            oy, ox = by * 16 + 2 * ty + dy, bx * 32 + 2 * tx + dx
+                            if oy >= H:
+                                continue
+                            ok = ox < W
+                            val = Y[dy, dx] + (bias[n] if bias is not None else 0.0)
+                            y[b, oy, ox[ok], n[ok]] = val[ok]
+    assert len(seen) == mblocks * nblocks
+    return y

@@ -194,3 +194,60 @@ def test_bad_arguments_raise():
         ops.conv2d(torch.zeros((1, 4, 4, 8), device="cuda"), pw)       # channel mismatch
     with pytest.raises(RenderNetHipError):
         ops.conv2d(torch.zeros((1, 4, 4, 16)), pw)                     # CPU tensor: no fallback
+
+
+# Winograd F(2x2,3x3) path (csrc/conv_wino.hip): ragged H/W (partial tile blocks, odd sizes), several column blocks
+# (W > 32), Cin = 16 / 48 (1 and 3 steps), Cout = 32 / 96, the bench widths, batch spanning m-block groups.
+WINO_CASES = [
+    (2, 16, 16, 256, 256),
+    (1, 9, 11, 128, 64),
+    (1, 37, 70, 16, 32),
+    (3, 33, 5, 48, 96),
+    (2, 64, 64, 64, 64),
+    (1, 16, 16, 1024, 512),
+    (12, 32, 32, 32, 32),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd(case):
+    """rn_conv2d_wino_fwd vs the oracle conv, vs the direct implicit-GEMM kernel on the same filter, and its packed
+    filter vs the NumPy statement of the layout (scripts/wino_emulate.pack_wino)."""
+    from rendernet_amd import ops
+    from scripts.wino_emulate import pack_wino
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (3, 3, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    assert pw.wino is not None, "the Winograd pack must exist for a 3x3 filter with Cin%16==0, Cout%32==0"
+    want_u = pack_wino(w)
+    assert np.abs(pw.wino.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    y0 = OL.conv2d(x, w, b, (1, 1))
+    _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "wino")
+    res = _rand(rng, *y0.shape)
+    want = OL.prelu(y0, alpha) + torch.from_numpy(res)
+    got = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+    _close(got, want, "wino+prelu+res")
+    _close(ops.conv2d(_dev(x), pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "wino+sigmoid")
+    # A/B against the direct kernel (same entry, Winograd pack dropped)
+    pd = ops.pack_conv(_dev(w))
+    pd.wino = None
+    direct = ops.conv2d(_dev(x), pd, _dev(b), _dev(alpha), _dev(res))
+    assert float((got - direct).abs().max()) <= 2e-5 * float(direct.abs().max())
+    # input gradient through the transposed Winograd pack == the direct dgrad kernel's result
+    dp = pw.dgrad_pack(True)
+    assert dp.wino is not None
+    dz = _dev(_rand(rng, B, H, W, Cout))
+    from rendernet_amd import _lib as L
+    dx_w = torch.empty((B, H, W, Cin), device="cuda")
+    L.check(L.lib().rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx_w), None, B, H, W, Cout, Cin, 0,
+                                       L.stream_ptr()), "rn_conv2d_wino_fwd (dgrad)")
+    dx_d = torch.empty_like(dx_w)
+    L.check(L.lib().rn_conv2d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx_d), B, H, W, Cin, Cout, L.ivec([3, 3]), L.ivec([1, 1]),
+                                    L.stream_ptr()), "rn_conv2d_dgrad")
+    want_dx = OL.conv2d_transpose(dz.cpu().numpy(), w.transpose(0, 1, 3, 2).copy(), None, (1, 1))   # [k,k,Cout_T=Cin,Cin_T=Cout]
+    _close(dx_w, want_dx, "wino dgrad vs oracle")
+    assert float((dx_w - dx_d).abs().max()) <= 2e-5 * float(dx_d.abs().max())
