@@ -2,19 +2,23 @@
 """Headline benchmark: rendered frames/s, 64^3 voxel -> 512x512 Phong-shader forward, batch 24 per
 GPU (BASELINE.json configs[1]), on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                                   # N=1, the headline line (+ roofline, parity, cpu_baseline)
+    python bench.py --gpus N [--scaling weak|strong]  # spawns N ranks itself (torch.distributed.run) ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # ... or is launched as N ranks
+    python bench.py --mode texture | stress | train   # BASELINE configs[2], [4], [3]
 
-A "step" is one pass of the whole hot path over one batch per rank: fused resampler
-(pose -> 128^3 image-aligned grid) + the 75-conv RenderNet forward, inputs already resident in HBM.
-Frames are independent, so ranks shard by batch with no data-path collective (weak scaling:
-every rank renders its own batch of 24; value = all frames / max-over-ranks time).
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields `roofline`, `cpu_baseline`).
+A "step" is one pass of the whole hot path over one batch per rank: fused resampler (pose -> image-aligned grid)
++ the RenderNet forward, inputs already resident in HBM.  Frames are independent, so ranks shard by batch with no
+data-path collective.  --scaling weak: every rank renders its own batch (value = all frames / max-over-ranks
+time); --scaling strong: ONE batch is split over the ranks in contiguous blocks (24 -> 24/12/6/3 frames per GPU,
+SURVEY.md §8e).  Rank 0 prints ONE JSON line (fields: README / DESIGN.md §5).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,32 +28,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FIXTURES = ["chair", "bunny", "table", "suzanne", "teapot"]
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
-GMAC_PER_FRAME = 1056.874         # SURVEY.md §8(d) / App. B (1-channel head)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense, exact fp32
+PARITY_TOL = 1e-3                 # north_star: per-pixel L-inf vs the reference render
+# SURVEY.md §8(d) / App. B / BASELINE.md §2: algorithmic GMAC per frame (direct-convolution counting rule)
+GMAC_PER_FRAME = {"render": 1056.874, "texture": 268.790 + 0.66, "stress": 16280.4}
 
 
-def synthetic_batch(batch):
-    """item i = fixture[i mod 5]; pose az=(250+15i) mod 360, el=60, r=3.3."""
+def fixtures_vox():
     from rendernet_amd.tools import binvox_rw
     vox = []
     for n in FIXTURES:
         with open(os.path.join(ROOT, "binvox", n + ".binvox"), "rb") as f:
             vox.append(binvox_rw.read_as_3d_array(f).data.astype(np.float32)[..., None])
-    vox = np.stack([vox[i % 5] for i in range(batch)])
+    return vox
+
+
+def bench_poses(batch):
     az = (250.0 + 15.0 * np.arange(batch)) % 360.0
     poses = np.stack([az * np.pi / 180.0, np.full(batch, (90 - 60) * np.pi / 180.0), np.full(batch, 3.3 / 3.3)], 1)
-    return vox, poses.astype(np.float32)
+    return poses.astype(np.float32)
 
 
-def cpu_baseline(weights, frames=4):
-    """The oracle (CPU restatement of the TF graph; the reference itself needs TensorFlow 1.x, which
-    is not installable -- SURVEY.md F4) timed on this box's host cores on a bounded sample."""
+def synthetic_batch(batch, upsample=1):
+    """item i = fixture[i mod 5]; pose az=(250+15i) mod 360, el=60, r=3.3.  upsample=2: each fixture
+    nearest-neighbour-upsampled to 128^3 (the stress config)."""
+    vox = fixtures_vox()
+    if upsample > 1:
+        vox = [v.repeat(upsample, 0).repeat(upsample, 1).repeat(upsample, 2) for v in vox]
+    return np.stack([vox[i % 5] for i in range(batch)]), bench_poses(batch)
+
+
+def texture_codes(batch, z_dim=199):
+    """texture codes ~N(0,1), seed 7 (Reconstruct_RenderNet_Face.py:464 uses randn)."""
+    return np.random.default_rng(7).standard_normal((batch, z_dim)).astype(np.float32)
+
+
+def pick_threads():
+    """The thread count that runs the dominant conv fastest on this box (all cores of a large host oversubscribe
+    oneDNN on a batch this small)."""
     import torch
-    from oracle import rendernet as ON
-    from oracle import resample as OR
-    vox, poses = synthetic_batch(frames)
-    # pick the thread count that runs the dominant conv fastest on this box (all cores of a large
-    # host oversubscribe oneDNN on a batch this small)
     import torch.nn.functional as F
     ncpu = os.cpu_count() or 1
     xx, ww = torch.randn(1, 1024, 64, 64), torch.randn(1024, 1024, 3, 3)
@@ -63,16 +80,35 @@ def cpu_baseline(weights, frames=4):
         if best is None or dt < best:
             best, cores = dt, th
     torch.set_num_threads(cores)
+    return cores, ncpu
+
+
+def cpu_baseline(weights, frames=4):
+    """The oracle (CPU restatement of the TF graph; the reference itself needs TensorFlow 1.x, which is not
+    installable -- SURVEY.md F4) timed on this box's host cores on a bounded sample: the first `frames` frames of
+    the bench batch as one batched pass, then one single-frame pass (BASELINE.md §3 asks for a B=24 pass and three
+    B=1 passes: ~2 min of CPU work, cut to the ~20-30 s the bench contract allows).  Returns (record, images):
+    the images are the oracle's render of those frames -- the parity reference for the timed GPU output."""
+    from oracle import rendernet as ON
+    from oracle import resample as OR
+    cores, ncpu = pick_threads()
+    vox, poses = synthetic_batch(frames)
     t0 = time.time()
-    x = OR.net_input(vox, poses, 64, 128)
-    out = ON.rendernet_forward(x, weights)
+    out = ON.rendernet_forward(OR.net_input(vox, poses, 64, 128), weights)
     dt = time.time() - t0
+    t1 = time.time()
+    ON.rendernet_forward(OR.net_input(vox[:1], poses[:1], 64, 128), weights)
+    dt1 = time.time() - t1
     assert out.shape == (frames, 512, 512, 1)
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames (chair, bunny, table, suzanne) at the bench poses, one fp32 pass of the NumPy/torch-CPU oracle "
-                      "(resampler + full 237M-parameter net), %.1f s" % (frames, dt)}
+    rec = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+           "single_frame_s": round(dt1, 2),
+           "sample": "frames 0-%d of the bench batch (chair, bunny, table, suzanne at the bench poses) as one fp32 pass of "
+                     "the NumPy/torch-CPU oracle (resampler + full 237M-parameter net) on %d threads of a %d-core host: "
+                     "%.1f s; one more single-frame pass: %.1f s" % (frames - 1, cores, ncpu, dt, dt1)}
+    return rec, np.asarray(out)
 
 
+# ----------------------------------------------------------------------------------------------------------------
 def train_main(args, world, rank, local_rank):
     """BASELINE configs[3]: Phong-shader training step, batch 24 per GPU (global batch 24*N), crop `--patch`,
     BCE loss, Adam; gradients summed across ranks with bucketed RCCL all-reduces overlapped with backward."""
@@ -113,21 +149,224 @@ def train_main(args, world, rank, local_rank):
     assert np.isfinite(lossv)
     if rank == 0:
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
-        fwd_tflop = 2e-3 * GMAC_PER_FRAME * (p / float(spec.new_size)) ** 2
+        fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2
         sps = B * world * args.steps / elapsed
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": args.rccl_ranks,
             "config": {"workload": "Phong shader training step (resampler+crop, forward, BCE, dgrad+wgrad, bucketed "
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
-            "approx_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
+            "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
             "final_loss": lossv}), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def build_workload(mode, device):
+    """-> dict(render(vox, aux, poses) -> image tensor, inputs(batch) -> (vox, aux, poses) numpy, spec, weights, ...)."""
+    import torch
+    if mode in ("render", "stress"):
+        from rendernet_amd.shader import Renderer, ShaderSpec, stress_spec, init_shader_weights
+        spec = stress_spec(1) if mode == "stress" else ShaderSpec().check()
+        weights = init_shader_weights(spec, seed=1234, perturb=True)
+        r = Renderer(spec, weights, device=device)
+        up = 2 if mode == "stress" else 1
+
+        def inputs(batch):
+            v, p = synthetic_batch(batch, up)
+            return v, None, p
+        name = ("Phong shader forward (resampler + RenderNet 1-ch head), 5 shipped binvox fixtures cycled, 64^3 -> 128^3 -> "
+                "512x512, seeded random weights (237.3M params)") if mode == "render" else \
+               ("high-res stress: Phong shader forward, 5 fixtures upsampled to 128^3 -> 256^3 -> 1024x1024, every 2-D "
+                "width doubled (projection 64*32 = 2048), seeded random weights (948M params)")
+        return {"render": lambda v, a, p: r.render(v, p), "inputs": inputs, "spec": spec, "weights": weights,
+                "name": name, "out_hw": 4 * spec.new_size, "out_ch": spec.out_ch, "trunk": (spec.new_size // 2, spec.w_res2)}
+    from rendernet_amd.texture import TextureRenderer, TextureSpec, init_texture_weights
+    spec = TextureSpec().check()
+    weights = init_texture_weights(spec, seed=1234, perturb=True)
+    r = TextureRenderer(spec, weights, device=device)
+
+    def inputs(batch):
+        v, p = synthetic_batch(batch)
+        return v, texture_codes(batch, spec.z_dim), p
+
+    def render(v, a, p):
+        img, nrm = r.render(v, a, p)
+        return torch.cat([img, nrm], dim=3)
+    return {"render": render, "inputs": inputs, "spec": spec, "weights": weights,
+            "name": "texture + normal face render (RenderNet_Texture_Face_Normal.py): geometry 64^3 + 199-d texture code -> "
+                    "texture decoder -> 2 resamplers (1+4 channels) -> 16-channel net -> two 512x512x3 heads, seeded weights",
+            "out_hw": 4 * spec.new_size, "out_ch": 6, "trunk": (spec.new_size // 2, spec.w_res2)}
+
+
+def render_main(args, world, rank, local_rank):
+    import torch
+    import torch.distributed as dist
+    from rendernet_amd import ops
+    from rendernet_amd.parallel import shard_range
+
+    mode = args.mode
+    wl = build_workload(mode, "cuda:%d" % local_rank)
+    B = args.batch
+    if args.scaling == "strong":
+        # ONE batch of B frames split over the ranks in contiguous blocks (SURVEY.md §8e)
+        if B < world:
+            raise SystemExit("--scaling strong: batch %d < %d ranks" % (B, world))
+        vox_np, aux_np, poses_np = wl["inputs"](B)
+        lo, hi = shard_range(B, rank, world)
+        vox_np, poses_np = vox_np[lo:hi], poses_np[lo:hi]
+        aux_np = None if aux_np is None else aux_np[lo:hi]
+        total_frames = B
+    else:
+        vox_np, aux_np, poses_np = wl["inputs"](B)
+        poses_np = poses_np.copy()
+        poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)    # every rank its own pose set: independent shards
+        total_frames = B * world
+    vox = torch.as_tensor(vox_np).cuda()
+    poses = torch.as_tensor(poses_np).cuda()
+    aux = None if aux_np is None else torch.as_tensor(aux_np).cuda()
+    nloc = vox.shape[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    hw, wtrunk = wl["trunk"]
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = wl["render"](vox, aux, poses)
+        # dominant kernel = the 3x3 conv of the res2 trunk (21 launches per step): bracket each of its launches with HIP
+        # events on the launch stream during the timed region; same for the resampler's launches
+        events, rs_events = [], []
+
+        def hook(m, xshape, pw):
+            if m == "resample":
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                rs_events.append((ev, xshape))
+                return ev
+            if m == "conv2d" and pw.cin == wtrunk and pw.cout == wtrunk and pw.kdims[0] == 3:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events.append((ev, pw.wino is not None))
+                return ev
+            return None
+
+        ops.LAUNCH_HOOK = hook
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = wl["render"](vox, aux, poses)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.LAUNCH_HOOK = None
+
+    assert out.shape == (nloc, wl["out_hw"], wl["out_hw"], wl["out_ch"])
+    assert bool(torch.isfinite(out).all())
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank != 0:
+        return
+
+    fps = total_frames * args.steps / elapsed
+    gmac = GMAC_PER_FRAME[mode]
+    metric = {"render": "rendered frames/sec, 64^3 voxel->512x512 Phong, batch 24",
+              "texture": "rendered frames/sec, texture+normal face render 64^3 -> two 512x512x3 maps, batch 24",
+              "stress": "rendered frames/sec, 128^3 voxel->1024x1024 Phong (high-res stress), batch 8"}[mode]
+    res = {
+        "metric": metric, "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": args.rccl_ranks,
+        "config": {"workload": wl["name"], "batch_per_gpu": nloc if args.scaling == "weak" else "%d split over %d" % (B, world),
+                   "global_batch": total_frames,
+                   "parallelism": "batch-sharded x%d, no data-path collective (RCCL: timing barrier + max-reduce only)" % world},
+        # throughput priced as if every conv were a direct convolution (the counting rule of SURVEY.md §8d) over the fp32
+        # MFMA peak.  The Winograd kernel executes 2.25x fewer multiplies on 87 % of those FLOPs, so this number is no
+        # longer bounded by 1; `roofline` below is on EXECUTED MFMA FLOPs and is.
+        "direct_equiv_fraction_of_fp32_peak": round(fps / world * gmac * 2e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "effective_tflops_direct_equiv": round(fps / world * gmac * 2e-3, 2),
+    }
+    if events:
+        kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in events]))
+        wino = all(w for _, w in events)
+        M = nloc * hw * hw
+        direct_flop = 2.0 * M * 9 * wtrunk * wtrunk                    # M*K*N*2 (SURVEY App. B)
+        exec_flop = direct_flop * 16.0 / 36.0 if wino else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
+        achieved = exec_flop / (kern_ms * 1e-3) / 1e12
+        traffic, tsrc = read_traffic("conv_wino_res2" if wino else "conv_igemm_res2") if (mode == "render" and nloc == 24) else (None, None)
+        res["roofline"] = {
+            "kernel": ("conv_wino_kernel (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA, fused transforms)" if wino else
+                       "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA)") + " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc),
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(kern_ms, 4),
+            "launches_timed": len(events), "flop_per_launch": exec_flop,
+            "flop_basis": "executed MFMA FLOPs = 2*(M/4)*16*Cin*Cout" if wino else "2*M*9*Cin*Cout",
+            "effective_tflops_direct_equiv": round(direct_flop / (kern_ms * 1e-3) / 1e12, 2),
+            "traffic": traffic, "traffic_source": tsrc}
+    if rs_events:
+        # second roofline of the path: the resampler is HBM-bound (SURVEY.md §8d: per frame and channel 1 MiB (64^3) source
+        # read + 8 MiB (128^3) grid written); all its launches of a step are summed
+        per_step = len(rs_events) // args.steps
+        rs_ms = float(np.sum([a.elapsed_time(b) for (a, b), _ in rs_events])) / args.steps
+        rs_bytes = float(sum(4.0 * np.prod(sh) * (1 + 8) for _, sh in rs_events[:per_step]))
+        rtraffic, rsrc = read_traffic("resampler") if (mode == "render" and nloc == 24) else (None, None)
+        res["roofline_resampler"] = {
+            "kernel": "resample_prepare + resample_classify + resample_main (csrc/resample_tiled.hip), %d call(s) per step" % per_step,
+            "bound": "hbm", "achieved": round(rs_bytes / (rs_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 8000.0, 4), "avg_ms": round(rs_ms, 4),
+            "launches_timed": len(rs_events), "bytes_per_call": rs_bytes, "traffic": rtraffic, "traffic_source": rsrc}
+    if world == 1 and mode == "render" and not args.no_cpu_baseline:
+        rec, want = cpu_baseline(wl["weights"], frames=min(4, nloc))
+        got = out[:want.shape[0]].cpu().numpy()
+        err = float(np.abs(got - want).max())
+        res["cpu_baseline"] = rec
+        # parity ON the benched configuration: the oracle's render of frames 0-3 of this very batch vs the output of the
+        # timed run (same sess.run feed as RenderNet_demo.py:47-51: voxels + pose -> encoder/output:0)
+        res["parity"] = {"frames": int(want.shape[0]), "max_abs_err": err, "tol": PARITY_TOL, "ok": err <= PARITY_TOL,
+                         "reference": "oracle (NumPy/torch-CPU restatement of the TF graph), fp32"}
+        if err > PARITY_TOL:
+            print(json.dumps(res), flush=True)
+            raise SystemExit("PARITY FAILURE: max|gpu - oracle| = %g > %g on the benched frames" % (err, PARITY_TOL))
+    print(json.dumps(res), flush=True)
+
+
+def read_traffic(key):
+    """HBM-side bytes per launch from profiles/traffic.json (rocprofv3 --pmc passes, scripts/collect_pmc.sh).  The file
+    records the git revision of the kernel sources it was measured on; a stale file yields (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+        ent = tj["kernels"][key]
+    except Exception:
+        return None, "no entry %r in profiles/traffic.json" % key
+    want = kernel_sources_digest()
+    if ent.get("csrc_digest") != want:
+        return None, "stale: profiles/traffic.json[%s] was collected on csrc digest %s, this build is %s" % (key, ent.get("csrc_digest"), want)
+    return ent.get("hbm_bytes_per_launch"), "profiles/traffic.json[%s], git %s, csrc digest %s" % (key, ent.get("git"), want)
+
+
+def kernel_sources_digest():
+    """sha256 (first 12 hex) over rendernet_amd/csrc/* -- ties counter evidence to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rendernet_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(n.encode())
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -135,32 +374,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24, help="frames per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["render", "train"], default="render",
-                    help="render = the headline metric (BASELINE configs[1]); train = the training step of "
-                         "configs[3] (forward + backward + gradient all-reduce + Adam), reported in samples/s")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (weak) / per step in total (strong); "
+                                                           "default 24, stress mode 8")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle leg (and with it the parity check)")
+    ap.add_argument("--mode", choices=["render", "train", "texture", "stress"], default="render",
+                    help="render = the headline metric (BASELINE configs[1]); texture = configs[2]; stress = configs[4] "
+                         "(128^3 -> 1024^2, batch 8); train = the training step of configs[3] (samples/s)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.mode == "stress" else 24
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU render path)")
+    ndev = torch.cuda.device_count()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # launched as ONE process but asked for N GPUs: become the launcher (one rank per GPU over RCCL) instead of silently
+        # running a single rank
+        if ndev < args.gpus and not os.environ.get("RN_SHARE_GPU"):
+            raise SystemExit("--gpus %d but only %d HIP device(s) are visible" % (args.gpus, ndev))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    import torch.distributed as dist
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # RN_SHARE_GPU=1 + RN_DIST_BACKEND=gloo: several ranks on one device, control collectives over gloo -- only for
     # smoke-testing the multi-rank launch path on a single-GPU box (RCCL refuses two ranks on one device)
-    ndev = torch.cuda.device_count()
     if local_rank >= ndev:
         if not os.environ.get("RN_SHARE_GPU"):
             raise SystemExit("LOCAL_RANK=%d but only %d HIP device(s) visible" % (local_rank, ndev))
         local_rank %= ndev
     torch.cuda.set_device(local_rank)
+    args.rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes)
@@ -169,110 +426,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from rendernet_amd import ops
-    from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
-
-    if args.mode == "train":
-        return train_main(args, world, rank, local_rank)
-    spec = ShaderSpec().check()
-    weights = init_shader_weights(spec, seed=1234, perturb=True)
-    renderer = Renderer(spec, weights, device="cuda:%d" % local_rank)
-    B = args.batch
-    vox_np, poses_np = synthetic_batch(B)
-    # each rank renders a different pose set (rank-shifted azimuths): independent shards
-    poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)
-    vox = torch.as_tensor(vox_np).cuda()
-    poses = torch.as_tensor(poses_np).cuda()
-
-    def barrier():
-        torch.cuda.synchronize()
+        # one real collective over the backend before anything is timed: every rank contributes 1
+        one = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        if int(one.item()) != world:
+            raise SystemExit("all-reduce over %s returned %g, expected %d" % (backend, float(one.item()), world))
+        args.rccl_ranks = world if backend == "nccl" else 0
+    try:
+        if args.mode == "train":
+            train_main(args, world, rank, local_rank)
+        else:
+            render_main(args, world, rank, local_rank)
+    finally:
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = renderer.render(vox, poses)
-        # dominant kernel = the res2 3x3 1024->1024 conv (21 launches/step, 73 % + 3.7 % of FLOPs):
-        # bracket each of its launches with HIP events on the launch stream during the timed region
-        events, rs_events = [], []
-
-        def hook(mode, xshape, pw):
-            if mode == "resample":
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                rs_events.append(ev)
-                return ev
-            if mode == "conv2d" and pw.cin == spec.w_res2 and pw.cout == spec.w_res2 and pw.kdims[0] == 3:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                events.append(ev)
-                return ev
-            return None
-
-        ops.LAUNCH_HOOK = hook
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = renderer.render(vox, poses)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        ops.LAUNCH_HOOK = None
-
-    assert out.shape == (B, 512, 512, spec.out_ch)
-    assert bool(torch.isfinite(out).all())
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    if rank == 0:
-        frames = B * world * args.steps
-        fps = frames / elapsed
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
-        flop_per_launch = 2.0 * (B * 64 * 64) * (9 * spec.w_res2) * spec.w_res2     # M*K*N*2
-        achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms else None
-        traffic = rs_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("conv_igemm_res2_hbm_bytes_per_launch")
-                rs_traffic = tj.get("resampler", {}).get("hbm_bytes_per_call")
-            except Exception:
-                traffic = rs_traffic = None
-        res = {
-            "metric": "rendered frames/sec, 64^3 voxel->512x512 Phong, batch 24",
-            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Phong shader forward (resampler + RenderNet 1-ch head), 5 shipped binvox fixtures "
-                                   "cycled, 64^3 -> 128^3 -> 512x512, seeded random weights (237.3M params)",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "batch-sharded x%d, no collective" % world},
-            "fraction_of_fp32_conv_roofline": round(fps / world * GMAC_PER_FRAME * 2e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "roofline": {"kernel": "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA) on res2 3x3 1024->1024 @64x64xB",
-                         "bound": "mfma", "achieved": round(achieved, 2) if achieved else None,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4) if achieved else None,
-                         "avg_launch_ms": round(kern_ms, 4) if kern_ms else None,
-                         "launches_timed": len(events), "flop_per_launch": flop_per_launch,
-                         "traffic": traffic},
-        }
-        if rs_events:
-            # second roofline of the path: the resampler is HBM-bound (9 437 184 algorithmic bytes per
-            # frame = 1 MiB source read + 8 MiB grid written); its three launches are bracketed together
-            rs_ms = float(np.mean([a.elapsed_time(b) for a, b in rs_events]))
-            rs_bytes = B * 9437184.0
-            res["roofline_resampler"] = {
-                "kernel": "resample_prepare + resample_classify + resample_main (csrc/resample_tiled.hip)",
-                "bound": "hbm", "achieved": round(rs_bytes / (rs_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(rs_bytes / (rs_ms * 1e-3) / 1e9 / 8000.0, 4), "avg_ms": round(rs_ms, 4),
-                "launches_timed": len(rs_events), "bytes_per_call": rs_bytes, "traffic": rs_traffic if B == 24 else None}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(weights)
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

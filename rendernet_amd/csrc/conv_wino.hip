@@ -17,8 +17,9 @@
 //     16x8 tiles (32x16 outputs) x 32 output channels x all 16 xi.  Its RAW 34x18-pixel input patch goes
 //     global -> LDS, 16 channels per stage (SAME padding from the buffer bounds check);
 //   * the input transform B^T d B happens at fragment-read time: wave w owns tile row w; a lane reads the
-//     16 pixels of its tile (ds_read_b128 = 4 channels each) and 32 vector adds give the 16 xi fragments
-//     -- one VALU per MFMA, and no two waves transform the same tile;
+//     16 pixels of its tile (ds_read_b128 = 4 channels each) and 32 vector adds give the 16 xi fragments;
+//     no two waves transform the same tile.  fp32 MFMA runs at the fp32 VECTOR rate and the adds measurably
+//     take issue time from it, so they are v_pk_add_f32 (one packed add per MFMA pair);
 //   * per xi the wave multiplies its 16 tiles x 32 channels (two 16x16 MFMA tiles), so all 16 xi of a
 //     (tile, channel) sit in one lane and the output transform A^T M A is a per-lane sum; the epilogue
 //     (bias, PReLU, residual, pre-activation) applies to the 2x2 outputs directly.
@@ -40,15 +41,36 @@ struct WinoArgs {
 namespace {
 constexpr int WPW = 34, WPH = 18;         // patch: 32+2 columns, 16+2 rows
 constexpr int WNPIX = WPW * WPH;          // 612
-constexpr int WRAW_PIECES = 39;           // 1 KiB DMA pieces of 16 pixels x 64 B (612 -> 624 pixel slots)
-constexpr int WRAW_B = WRAW_PIECES * 1024;   // bytes per raw stage (39 936)
+constexpr int WRAW_PIECES = 40;           // 1 KiB DMA pieces of 16 pixels x 64 B (612 -> 640 pixel slots: 5 per wave)
+constexpr int WRAW_B = WRAW_PIECES * 1024;   // bytes per raw stage (40 960)
 constexpr int WU_B = 16 * 4 * 32 * 16;    // bytes per U stage (32 768)
 constexpr unsigned WOOB = 0x80000000u;
 }
 
 size_t rn_wino_lds_bytes() { return (size_t)2 * WRAW_B + 2 * WU_B; }
 
-// PROBE (measurement only, RN_WINO_PROBE): bit 0 = skip the input transform, bit 1 = no DMA inside the loop
+__device__ __forceinline__ f32x4 pk_add(f32x4 x, f32x4 y)
+{
+    f32x4 r;
+    asm("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %1, %4, %5"
+        : "=&v"(*reinterpret_cast<double*>(&r)), "=&v"(*(reinterpret_cast<double*>(&r) + 1))
+        : "v"(*reinterpret_cast<double*>(&x)), "v"(*reinterpret_cast<double*>(&y)),
+          "v"(*(reinterpret_cast<double*>(&x) + 1)), "v"(*(reinterpret_cast<double*>(&y) + 1)));
+    return r;
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 x, f32x4 y)
+{
+    f32x4 r;
+    asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %4, %5 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(*reinterpret_cast<double*>(&r)), "=&v"(*(reinterpret_cast<double*>(&r) + 1))
+        : "v"(*reinterpret_cast<double*>(&x)), "v"(*reinterpret_cast<double*>(&y)),
+          "v"(*(reinterpret_cast<double*>(&x) + 1)), "v"(*(reinterpret_cast<double*>(&y) + 1)));
+    return r;
+}
+
+// PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
+// 2 = no DMA inside the loop (wrong results), 4 = input transform with plain v_add/v_sub instead of v_pk_add_f32,
+// 8 = all DMAs of a step at its top instead of interleaved with the MFMAs.
 template <int PROBE>
 __global__ __launch_bounds__(512, 1)
 void conv_wino_kernel(const WinoArgs a)
@@ -83,7 +105,7 @@ void conv_wino_kernel(const WinoArgs a)
     const __amdgpu_buffer_rsrc_t ursrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
 
-    // raw-patch DMA: piece p = wave + 8 i (i < 5, p < 39) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane
+    // raw-patch DMA: piece p = wave + 8 i (i < 5) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane
     // fetches LOGICAL chunk (lane%4) ^ swz(px) into physical slot lane%4, swz(px) = (px>>1)&3 (two lanes of a
     // ds_read_b128 group at most share a 16-B slot)
     unsigned roff[5];
@@ -106,7 +128,10 @@ void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
     for (int hj = 0; hj < 2; ++hj)
         raddr[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
-    const unsigned uaddr = (unsigned)(2 * WRAW_B + kq * 512 + l16 * 16);
+    unsigned uaddr = (unsigned)(2 * WRAW_B + kq * 512 + l16 * 16);
+    // opaque to the optimiser: keeps ONE base register + 16-bit immediates (xi*2048 + nt*256 + stage*32768 < 65536) for the
+    // 64 filter-fragment reads instead of one hoisted address register each
+    asm volatile("" : "+v"(uaddr));
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -116,20 +141,48 @@ void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][nt][r] = 0.f;
 
-#define WINO_DMA(s, stage)                                                                                \
+    // DMA number idx_ (0..8) of this wave into `stage`: 0..4 = raw-patch pieces (per-lane offsets ro_[]), 5..8 = filter
+    // pieces (per-lane offset uo_, step offset us_ in an SGPR).  A step that has no successor still issues them, with
+    // out-of-range offsets: the hardware then writes zeros into the stage nobody reads -- no branches in the loop.
+#define WINO_DMA_ONE(stage, idx_)                                                                         \
     {                                                                                                     \
-        const unsigned c_ = (unsigned)(s) * 64u;                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_)                                                  \
-            if (wave + 8 * i_ < WRAW_PIECES)                                                              \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (stage) * WRAW_B + (wave + 8 * i_) * 1024), \
-                                                         16, roff[i_] + c_, 0, 0, 0);                     \
-        const unsigned g_ = uoff + (unsigned)(s) * 32768u;                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (stage) * WU_B + (wave * 4 + i_) * 1024), \
-                                                     16, g_ + (unsigned)i_ * 1024u, 0, 0, 0);             \
+        if ((idx_) < 5) {                                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (stage) * WRAW_B + (wave + 8 * (idx_)) * 1024), \
+                                                     16, ro_[(idx_) < 5 ? (idx_) : 0], 0, 0, 0);          \
+        } else {                                                                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (stage) * WU_B + (wave * 4 + (idx_) - 5) * 1024), \
+                                                     16, uo_, us_ + (unsigned)((idx_) - 5) * 1024u, 0, 0);    \
+        }                                                                                                 \
     }
+#define WINO_DMA_SETUP(s, DO)                                                                             \
+        unsigned ro_[5];                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) ro_[i_] = (DO) ? roff[i_] + (unsigned)(s) * 64u : WOOB; \
+        const unsigned uo_ = (DO) ? uoff : WOOB;                                                          \
+        const unsigned us_ = (DO) ? (unsigned)(s) * 32768u : 0u;
+#define WINO_DMA(stage)                                                                                   \
+    { _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) WINO_DMA_ONE(stage, i_); }
 
-    // one 16-channel step on stage STG
+    // 4x4 input transform of one xi row: t = (B^T d)[i][*], v = t B
+#define WINO_ROW(i)                                                                                       \
+            f32x4 t_[4], v_[4];                                                                           \
+            if (PROBE & 1) {                                                                              \
+                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi) v_[bi] = d_[i][bi];                      \
+            } else if (!(PROBE & 4)) {                                                                    \
+                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                          \
+                    t_[bi] = i == 0 ? pk_sub(d_[0][bi], d_[2][bi]) : i == 1 ? pk_add(d_[1][bi], d_[2][bi]) \
+                           : i == 2 ? pk_sub(d_[2][bi], d_[1][bi]) : pk_sub(d_[1][bi], d_[3][bi]);        \
+                v_[0] = pk_sub(t_[0], t_[2]); v_[1] = pk_add(t_[1], t_[2]); v_[2] = pk_sub(t_[2], t_[1]); \
+                v_[3] = pk_sub(t_[1], t_[3]);                                                             \
+                asm volatile("s_nop 1" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[3]));             \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                          \
+                    t_[bi] = i == 0 ? d_[0][bi] - d_[2][bi] : i == 1 ? d_[1][bi] + d_[2][bi]              \
+                           : i == 2 ? d_[2][bi] - d_[1][bi] : d_[1][bi] - d_[3][bi];                      \
+                v_[0] = t_[0] - t_[2]; v_[1] = t_[1] + t_[2]; v_[2] = t_[2] - t_[1]; v_[3] = t_[1] - t_[3]; \
+            }
+
+    // one 16-channel step on stage STG; the next step's nine DMAs (into stage STG^1) are issued one at a time behind the
+    // MFMA groups of xi 0..8 (all at the top of the step: 7.64 ms instead of 7.10 on res2 -- they stall the step's head)
 #define WINO_COMPUTE(STG)                                                                                 \
     {                                                                                                     \
         const char* rb_ = smem + (STG) * WRAW_B;                                                          \
@@ -139,15 +192,7 @@ void conv_wino_kernel(const WinoArgs a)
             _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                              \
                 d_[ai][bi] = *reinterpret_cast<const f32x4*>(rb_ + raddr[bi >> 1] + (ai * WPW + bi) * 64); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-            f32x4 t_[4], v_[4];                                                                           \
-            if (PROBE & 1) {                                                                              \
-                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi) v_[bi] = d_[i][bi];                      \
-            } else {                                                                                      \
-                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                          \
-                    t_[bi] = i == 0 ? d_[0][bi] - d_[2][bi] : i == 1 ? d_[1][bi] + d_[2][bi]              \
-                           : i == 2 ? d_[2][bi] - d_[1][bi] : d_[1][bi] - d_[3][bi];                      \
-                v_[0] = t_[0] - t_[2]; v_[1] = t_[1] + t_[2]; v_[2] = t_[2] - t_[1]; v_[3] = t_[1] - t_[3]; \
-            }                                                                                             \
+            WINO_ROW(i)                                                                                   \
             _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
                 const f32x4 b0_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048);             \
                 const f32x4 b1_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048 + 256);       \
@@ -155,6 +200,7 @@ void conv_wino_kernel(const WinoArgs a)
                     acc[i * 4 + jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_[jj][s_], b0_[s_], acc[i * 4 + jj][0], 0, 0, 0); \
                     acc[i * 4 + jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_[jj][s_], b1_[s_], acc[i * 4 + jj][1], 0, 0, 0); \
                 }                                                                                         \
+                if (!(PROBE & 10) && i * 4 + jj < 9) WINO_DMA_ONE((STG) ^ 1, i * 4 + jj);                 \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -164,18 +210,29 @@ void conv_wino_kernel(const WinoArgs a)
         __syncthreads();                                                                                  \
     }
 
-    WINO_DMA(0, 0);
+    {
+        WINO_DMA_SETUP(0, true);
+        WINO_DMA(0);
+    }
     WINO_SYNC();
     for (int s = 0; s < a.nstep; s += 2) {
-        if (!(PROBE & 2) && s + 1 < a.nstep) WINO_DMA(s + 1, 1);
-        WINO_COMPUTE(0);
+        const bool m1_ = s + 1 < a.nstep, m2_ = s + 2 < a.nstep;
+        {
+            WINO_DMA_SETUP(s + 1, m1_);
+            if ((PROBE & 10) == 8) WINO_DMA(1);
+            WINO_COMPUTE(0);
+        }
         WINO_SYNC();
-        if (s + 1 < a.nstep) {
-            if (!(PROBE & 2) && s + 2 < a.nstep) WINO_DMA(s + 2, 0);
+        if (m1_) {
+            WINO_DMA_SETUP(s + 2, m2_);
+            if ((PROBE & 10) == 8) WINO_DMA(0);
             WINO_COMPUTE(1);
             WINO_SYNC();
         }
     }
+#undef WINO_DMA_SETUP
+#undef WINO_ROW
+#undef WINO_DMA_ONE
 #undef WINO_SYNC
 #undef WINO_COMPUTE
 #undef WINO_DMA
@@ -263,7 +320,8 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     static const int probe = getenv("RN_WINO_PROBE") ? atoi(getenv("RN_WINO_PROBE")) : 0;
     const size_t lds = rn_wino_lds_bytes();
     auto kern = probe == 1 ? conv_wino_kernel<1> : probe == 2 ? conv_wino_kernel<2> : probe == 3 ? conv_wino_kernel<3>
-                                                                                                  : conv_wino_kernel<0>;
+              : probe == 4 ? conv_wino_kernel<4> : probe == 8 ? conv_wino_kernel<8> : probe == 12 ? conv_wino_kernel<12>
+              : conv_wino_kernel<0>;
     // per launch: the attribute is per device, and a process may drive several
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mblocks * a.nblocks)), dim3(512), lds, st, a);

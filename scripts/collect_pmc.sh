@@ -1,0 +1,41 @@
+#!/bin/bash
+# Regenerate the counter evidence of the three roofline kernels on the CURRENT build (run on the GPU box):
+#   * the dominant conv  -- Winograd kernel on the res2 shape (scripts/wino_bench.py --shapes 64x1024)
+#   * the 3-D encoder kernel (scripts/layer_bench.py --only res1)
+#   * the resampler's three launches (scripts/layer_bench.py --only resample)
+# One rocprofv3 --pmc pass per counter set (SQ set | FETCH_SIZE | WRITE_SIZE | TCC hit/miss), --kernel-trace only (no
+# other trace domain beside --pmc).  Summaries land in $OUT (default gpurun_out/pmc); scripts/pmc_to_traffic.py then
+# rewrites profiles/traffic.json with the csrc digest + git revision the numbers belong to.
+#   usage (from the build container):  gpurun -- "GIT_REV=$(git rev-parse --short HEAD) bash scripts/collect_pmc.sh"
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=${OUT:-$R/gpurun_out/pmc}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+TCC="TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum"
+run() {  # name, counter-set tag, counters..., then "--" and the command
+    local name=$1 tag=$2; shift 2
+    local ctrs=()
+    while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+    shift
+    rocprofv3 --kernel-trace --output-format csv --pmc "${ctrs[@]}" -d "$OUT/$name.$tag" -o "$tag" -- "$@" > "$OUT/$name.$tag.log" 2>&1
+}
+for tag in sq fetch write tcc; do
+    case $tag in
+        sq) C=$SQ ;; fetch) C="FETCH_SIZE" ;; write) C="WRITE_SIZE" ;; tcc) C=$TCC ;;
+    esac
+    run wino $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --wino-only
+    run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5
+done
+for name in wino res1 resample; do
+    flt=""; [ $name = wino ] && flt=conv_wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = resample ] && flt=resample_
+    : > "$OUT/$name.txt"
+    for tag in sq fetch write tcc; do
+        f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)
+        [ -n "$f" ] && python "$R/scripts/pmc_summary.py" "$f" "$flt" >> "$OUT/$name.txt"
+    done
+done
+python "$R/scripts/pmc_to_traffic.py" "$OUT" "$OUT/traffic.json"
+echo "wrote $OUT/{wino,res1,resample}.txt and $OUT/traffic.json"

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--shapes", type=str, default="64x1024,64x512")
+    ap.add_argument("--wino-only", action="store_true")
     args = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
     for sh in args.shapes.split(","):
@@ -36,6 +37,8 @@ def main():
             res["wino"] = ms
             print("%s B=%d  winograd %8.3f ms  %7.2f TFLOP/s direct-equivalent, %7.2f TFLOP/s executed"
                   % (sh, B, ms, flop / ms / 1e9, flop / 2.25 / ms / 1e9), flush=True)
+        if args.wino_only:
+            continue
         wn = pw.wino
         pw.wino = None
         ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)

@@ -10,7 +10,7 @@ import numpy as np
 
 WPW, WPH = 34, 18
 WNPIX = WPW * WPH
-WRAW_PIECES = 39
+WRAW_PIECES = 40
 WRAW_B = WRAW_PIECES * 1024
 WU_B = 16 * 4 * 32 * 16
 
@@ -66,8 +66,6 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
             for wave in range(8):
                 for i in range(5):                                        # raw patch pieces
                     p = wave + 8 * i
-                    if p >= WRAW_PIECES:
-                        continue
                     q = p * 16 + (lane >> 2)
                     py, px = q // WPW, q % WPW
                     iy, ix = y0 + py, x0 + px

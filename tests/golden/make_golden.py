@@ -6,6 +6,8 @@ oracle restatement, not to TF outputs -- "parity unpinned" in the sense of oracl
   tiny_shader.npz             tiny spec (16^3 -> 32^3 -> 128^2), 3 frames, perturbed weights seed 1234
   full_chair_demo_pose.npz    reference-size net, binvox/chair.binvox at the demo default pose
                               (RenderNet_demo.py:81-98), 128x128 centre crop of logits and output
+  bench_frames.npz            (`make_golden.py bench_frames`) five frames of bench.py's batch, one per fixture
+  stress_bench_frames.npz     (`make_golden.py stress8`) the 8 frames of `bench.py --mode stress`, one crop each
 """
 import os
 import sys
@@ -71,9 +73,69 @@ def stress():
                         net_in_sum=np.float64(x.sum()), enc4_absmean=np.float64(np.abs(taps["enc4"]).mean()))
 
 
+BENCH_FRAMES = [0, 6, 12, 18, 9]          # of the bench batch: chair, bunny, table, suzanne, teapot at az 250, 340, 70, 160, 25
+CROPS = [(128, 128), (128, 256), (256, 128), (256, 256)]      # 128x128 crops tiling the central 256x256 (where the object is)
+
+
+def _bench_inputs(n, upsample=1):
+    """The synthetic batch of bench.py: item i = fixture[i mod 5], pose az = (250+15i) mod 360."""
+    names = ["chair", "bunny", "table", "suzanne", "teapot"]
+    vox = [read_binvox(os.path.join(ROOT, "binvox", m + ".binvox")).astype(np.float32) for m in names]
+    if upsample > 1:
+        vox = [v.repeat(upsample, 0).repeat(upsample, 1).repeat(upsample, 2) for v in vox]
+    v = np.stack([vox[i % 5] for i in range(n)])[..., None]
+    p = np.stack([pose((250.0 + 15.0 * i) % 360.0, 60.0, 3.3) for i in range(n)])
+    return v, p
+
+
+def bench_frames():
+    """Five frames OF THE BENCHED BATCH (BASELINE configs[1]; one per shipped fixture, five different azimuths) through
+    the full-size oracle: four 128x128 crops of the image and of the logits per frame, plus strided samples of the 3-D
+    encoder output (enc3_skip) and of the projection unit's output (enc4)."""
+    spec = ShaderSpec().check()
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox, poses = _bench_inputs(24)
+    out = {"frames": np.array(BENCH_FRAMES), "crops": np.array(CROPS)}
+    for k, i in enumerate(BENCH_FRAMES):
+        x = OR.net_input(vox[i:i + 1], poses[i:i + 1], 64, 128, mode="tf")
+        taps = {}
+        img = ON.rendernet_forward(x, w, taps)
+        out["output_%d" % k] = np.stack([img[0, r:r + 128, c:c + 128, 0] for r, c in CROPS])
+        out["logits_%d" % k] = np.stack([taps["logits"][0, r:r + 128, c:c + 128, 0] for r, c in CROPS])
+        out["enc3_skip_%d" % k] = taps["enc3_skip"][0, 3::8, 5::8, 1::4, :]
+        out["enc4_%d" % k] = taps["enc4"][0, 3::8, 5::8, :]
+        out["net_in_sum_%d" % k] = np.float64(x.sum())
+        print("bench frame", i, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "bench_frames.npz"), **out)
+
+
+def stress8():
+    """BASELINE config 5 at its configured batch: the 8 frames of `bench.py --mode stress` (fixtures upsampled x2, bench
+    poses) through the oracle, one 128x128 crop of image and logits per frame (the oracle needs minutes per frame)."""
+    from rendernet_amd.shader import stress_spec
+    spec = stress_spec(1)
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox, poses = _bench_inputs(8, 2)
+    out = {}
+    for i in range(8):
+        x = OR.net_input(vox[i:i + 1], poses[i:i + 1], 128, 256, mode="tf")
+        taps = {}
+        img = ON.rendernet_forward(x, w, taps)
+        out["output_%d" % i] = img[0, 448:576, 448:576, 0]
+        out["logits_%d" % i] = taps["logits"][0, 448:576, 448:576, 0]
+        print("stress frame", i, "done", flush=True)
+        np.savez_compressed(os.path.join(HERE, "stress_bench_frames.npz"), **out)
+
+
 if __name__ == "__main__":
     if "stress" in sys.argv:
         stress()
+        sys.exit(0)
+    if "bench_frames" in sys.argv:
+        bench_frames()
+        sys.exit(0)
+    if "stress8" in sys.argv:
+        stress8()
         sys.exit(0)
     tiny()
     full()

@@ -239,7 +239,9 @@ def test_conv2d_winograd(case):
     assert float((got - direct).abs().max()) <= 2e-5 * float(direct.abs().max())
     # input gradient through the transposed Winograd pack == the direct dgrad kernel's result
     dp = pw.dgrad_pack(True)
-    assert dp.wino is not None
+    assert (dp.wino is not None) == (Cout % 16 == 0 and Cin % 32 == 0)      # roles swap: K = Cout, N = Cin
+    if dp.wino is None:
+        return
     dz = _dev(_rand(rng, B, H, W, Cout))
     from rendernet_amd import _lib as L
     dx_w = torch.empty((B, H, W, Cin), device="cuda")
@@ -248,6 +250,81 @@ def test_conv2d_winograd(case):
     dx_d = torch.empty_like(dx_w)
     L.check(L.lib().rn_conv2d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx_d), B, H, W, Cin, Cout, L.ivec([3, 3]), L.ivec([1, 1]),
                                     L.stream_ptr()), "rn_conv2d_dgrad")
-    want_dx = OL.conv2d_transpose(dz.cpu().numpy(), w.transpose(0, 1, 3, 2).copy(), None, (1, 1))   # [k,k,Cout_T=Cin,Cin_T=Cout]
+    want_dx = OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1))       # w read as [k,k,Cout_T = Cin,Cin_T = Cout]
     _close(dx_w, want_dx, "wino dgrad vs oracle")
     assert float((dx_w - dx_d).abs().max()) <= 2e-5 * float(dx_d.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Inputs of 2 GiB and more: the kernels address their A operand with 32-bit byte offsets whose upper half is reserved
+# for the hardware zero fill, so the launchers split the batch into chunks that fit the window (conv_igemm.hip,
+# conv_wino.hip; conv3d_drun.hip hands such inputs to the implicit-GEMM kernel).  Each case: the big call vs the same
+# layer on single items (no chunking) for items on both sides of every chunk boundary, and vs the oracle on one item.
+# ---------------------------------------------------------------------------------------------------------------
+def _chunk_items(B, per_item_bytes):
+    chunk = int(0x7fffffff // per_item_bytes)
+    edges = sorted({0, B - 1, chunk - 1, chunk, min(B - 1, 2 * chunk - 1), min(B - 1, 2 * chunk)})
+    return chunk, [i for i in edges if 0 <= i < B]
+
+
+def test_conv_transpose_input_over_2gib_batch_chunks():
+    """e_conv10's shape (conv2d_transpose 4x4 s1 32->16 on 512x512 maps, RenderNet_Shader.py:121-123) at batch 64:
+    2.1 GiB of input, what an 8-way-larger batch per GPU would hit."""
+    from rendernet_amd import ops
+    B, H, W, Cin, Cout = 64, 512, 512, 32, 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=g)
+    assert x.numel() * 4 >= 2 ** 31
+    rng = np.random.default_rng(5)
+    w = _xavier(rng, (4, 4, Cout, Cin))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv_transpose(_dev(w), 1)
+    y = ops.conv2d_transpose(x, pw, _dev(b), _dev(alpha))
+    chunk, items = _chunk_items(B, H * W * Cin * 4)
+    assert chunk < B
+    for i in items:
+        yi = ops.conv2d_transpose(x[i:i + 1].clone(), pw, _dev(b), _dev(alpha))
+        assert torch.equal(y[i:i + 1], yi), "item %d differs between the chunked and the single-item launch" % i
+    i = items[len(items) // 2]
+    want = OL.prelu(OL.conv2d_transpose(x[i:i + 1].cpu().numpy(), w, b, (1, 1)), alpha)
+    _close(y[i:i + 1], want, "chunked conv2d_transpose vs oracle")
+    del x, y
+    torch.cuda.empty_cache()
+
+
+def test_winograd_and_conv3d_inputs_over_2gib_batch_chunks():
+    from rendernet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    rng = np.random.default_rng(6)
+    # Winograd kernel: 129 items of 64x64x1024 (the res2 input shape), 32 output channels to keep it cheap
+    B, H, W, Cin, Cout = 129, 64, 64, 1024, 32
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=g)
+    assert x.numel() * 4 >= 2 ** 31
+    w = _xavier(rng, (3, 3, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    pw = ops.pack_conv(_dev(w))
+    assert pw.wino is not None
+    y = ops.conv2d(x, pw, _dev(b))
+    chunk, items = _chunk_items(B, H * W * Cin * 4)
+    assert chunk < B
+    for i in items:
+        assert torch.equal(y[i:i + 1], ops.conv2d(x[i:i + 1].clone(), pw, _dev(b))), i
+    _close(y[items[1]:items[1] + 1], OL.conv2d(x[items[1]:items[1] + 1].cpu().numpy(), w, b, (1, 1)), "chunked winograd vs oracle")
+    del x, y
+    torch.cuda.empty_cache()
+    # 3-D encoder layer (3^3 32->32 on 64x64x32 maps): the depth-run kernel hands >= 2 GiB inputs to the implicit GEMM
+    B, H, W, D, C = 129, 64, 64, 32, 32
+    x = torch.randn((B, H, W, D, C), device="cuda", generator=g)
+    assert x.numel() * 4 >= 2 ** 31
+    w = _xavier(rng, (3, 3, 3, C, C))
+    b = _rand(rng, C) * 0.1
+    pw = ops.pack_conv(_dev(w))
+    y = ops.conv3d(x, pw, _dev(b))
+    chunk, items = _chunk_items(B, H * W * D * C * 4)
+    for i in items[:4]:
+        yi = ops.conv3d(x[i:i + 1].clone(), pw, _dev(b))                 # single item: the depth-run kernel
+        assert float((y[i:i + 1] - yi).abs().max()) <= 2e-5 * float(yi.abs().max()), i
+    _close(y[items[1]:items[1] + 1], OL.conv3d(x[items[1]:items[1] + 1].cpu().numpy(), w, b, (1, 1, 1)), "chunked conv3d vs oracle")
+    del x, y
+    torch.cuda.empty_cache()

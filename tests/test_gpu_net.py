@@ -122,3 +122,33 @@ def test_hipgraph_replay_matches_eager():
         got = replay(vox, poses)
         torch.cuda.synchronize()
         assert torch.equal(got, want)
+
+
+def test_bench_frames_match_golden(fixtures_vox):
+    """Parity ON the benched configuration (BASELINE configs[1]): five frames of bench.py's batch -- every shipped fixture,
+    five different azimuths -- rendered in one full-size call and compared with the committed oracle output
+    (tests/golden/make_golden.py bench_frames): four 128x128 crops of image and logits per frame, strided samples of the
+    3-D encoder output and of the projection unit's output."""
+    from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
+    from bench import synthetic_batch              # conftest.py puts the repo root on sys.path
+    g = np.load(os.path.join(GOLDEN_DIR, "bench_frames.npz"))
+    idx = [int(i) for i in g["frames"]]
+    vox, poses = synthetic_batch(24)
+    spec = ShaderSpec().check()
+    r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True))
+    taps = {}
+    out = r.render(vox[idx], poses[idx], taps=taps).cpu().numpy()
+    assert out.shape == (5, 512, 512, 1)
+    for k in range(5):
+        assert abs(float(taps["net_in"][k].double().sum()) - float(g["net_in_sum_%d" % k])) <= 1e-3 * float(g["net_in_sum_%d" % k])
+        e3 = taps["enc3_skip"][k, 3::8, 5::8, 1::4, :].cpu().numpy()
+        e4 = taps["enc4"][k, 3::8, 5::8, :].cpu().numpy()
+        for got, key in ((e3, "enc3_skip_%d" % k), (e4, "enc4_%d" % k)):
+            want = g[key]
+            assert np.abs(got - want).max() <= TAP_RTOL * np.abs(want).max() + 1e-6, key
+        for c, (r0, c0) in enumerate(g["crops"]):
+            crop = out[k, r0:r0 + 128, c0:c0 + 128, 0]
+            assert np.abs(crop - g["output_%d" % k][c]).max() <= OUT_ATOL, (k, c)
+            lg = np.log(crop.astype(np.float64) / (1 - crop.astype(np.float64)))
+            want = g["logits_%d" % k][c]
+            assert np.abs(lg - want).max() <= 5e-4 * np.abs(want).max() + 1e-5, (k, c)

@@ -45,3 +45,27 @@ def test_stress_batch_independence(stress_renderer, fixtures_vox):
     one = stress_renderer.render(vox[1:2], poses[1:2])
     assert torch.equal(both[1:2], one)
     assert bool(torch.isfinite(both).all()) and float(both.std()) > 0
+
+
+def test_stress_batch8_matches_golden(stress_renderer):
+    """BASELINE config 5 at its configured batch of 8 (the frames of `bench.py --mode stress`): one call, every frame's
+    centre crop against the committed oracle output (tests/golden/make_golden.py stress8)."""
+    path = os.path.join(GOLDEN_DIR, "stress_bench_frames.npz")
+    if not os.path.exists(path):
+        pytest.skip("stress batch golden not generated")
+    from bench import synthetic_batch              # conftest.py puts the repo root on sys.path
+    g = np.load(path)
+    vox, poses = synthetic_batch(8, 2)
+    out = stress_renderer.render(vox, poses).cpu().numpy()
+    assert out.shape == (8, 1024, 1024, 1)
+    n = 0
+    for i in range(8):
+        if "output_%d" % i not in g.files:
+            continue
+        crop = out[i, 448:576, 448:576, 0]
+        assert np.abs(crop - g["output_%d" % i]).max() <= 1e-3, i
+        lg = np.log(crop.astype(np.float64) / (1 - crop.astype(np.float64)))
+        want = g["logits_%d" % i]
+        assert np.abs(lg - want).max() <= 1e-3 * np.abs(want).max() + 1e-5, i
+        n += 1
+    assert n >= 4
