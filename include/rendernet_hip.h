@@ -47,12 +47,13 @@ extern "C" {
 #define RN_PACK_CONVT_S2    2     /* TF conv_transpose filter [4,4,(4,)Cout,Cin], stride 2:
                                      becomes 2^nd sub-pixel phase filters of 2 taps per dim       */
 
-#define RN_PACK_CONV_WINO       3  /* TF conv filter [3,3,Cin,Cout] -> Winograd F(2x2,3x3) transformed U = G g G^T
-                                     (16 planes, 16*Cin*Cout floats; Cin % 16 == 0, Cout % 32 == 0) for
-                                     rn_conv2d_wino_fwd                                                          */
-#define RN_PACK_CONVT_S1_WINO   4  /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same
-                                     transform: the input gradient of a stride-1 3x3 conv through
-                                     rn_conv2d_wino_fwd                                                          */
+#define RN_PACK_CONV_WINO       3  /* TF conv filter [3,3,Cin,Cout] (ndim 2) or [3,3,3,Cin,Cout] (ndim 3) -> Winograd
+                                     F(2x2,3x3) transformed U = G g G^T over the first two filter dims (16 planes,
+                                     16*Cin*Cout floats, x3 for 3-D; Cin % 16 == 0, Cout % 32 == 0) for
+                                     rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
+#define RN_PACK_CONVT_S1_WINO   4  /* TF conv_transpose filter [3,3,(3,)Cout,Cin], stride 1, taps flipped, same
+                                     transform: the input gradient of a stride-1 3x3(x3) conv through
+                                     rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
 
 int rn_version(void);
 const char* rn_last_error(void);
@@ -152,7 +153,15 @@ int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, 
  * own TF filter it computes the layer's input gradient (dz [B,H,W,Cout_fwd] -> dx [B,H,W,Cin_fwd]).  preact may be
  * NULL (see rn_conv2d_fwd_train).  rn_conv2d_wino_supported: 1 when this library takes (Cin, Cout) on that path
  * (Cin % 16 == 0, Cout % 32 == 0, and the environment does not set RN_NO_WINOGRAD), else 0 -- use rn_conv2d_fwd. */
+/* rn_conv3d_wino_fwd: the same for the 3x3x3, stride-1 convs of the 3-D encoder -- conv3d in res_block_3d and
+ * res1_skip (tools/layer_util.py:60-73; RenderNet_Shader.py:44-64): Winograd F(2x2,3x3) over (H,W), direct over the
+ * three depth taps (in channels-last [B,H,W,D,C] the three depth neighbours of a voxel are 3*C contiguous floats, so
+ * every output depth slice is a 2-D conv with 3*C input channels): 27 -> 12 multiplies per output and channel pair. */
 int rn_conv2d_wino_supported(int Cin, int Cout);
+int rn_conv3d_wino_supported(int Cin, int Cout);
+int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
+                       const float* residual, float* y, float* preact,
+                       int B, int H, int W, int D, int Cin, int Cout, int act, void* stream);
 int rn_conv2d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
                        const float* residual, float* y, float* preact,
                        int B, int H, int W, int Cin, int Cout, int act, void* stream);

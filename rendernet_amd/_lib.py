@@ -34,6 +34,8 @@ SIGNATURES = {
     "rn_projection_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
+    "rn_conv3d_wino_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv3d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),
     "rn_prelu_fwd": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_int, _c_vp]),
     "rn_phong_composite_fwd": (_c_int, [_c_vp] * 3 + [_c_f, _c_f, _c_vp] + [_c_int] * 3 + [_c_vp]),

@@ -97,7 +97,19 @@ extern "C" int rn_conv2d_wino_fwd(const float* x, const float* w_wino, const flo
     if (!x || !w_wino || !y) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: null pointer");
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: PReLU needs alpha");
-    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, Cin, Cout, act, (hipStream_t)stream);
+    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, 1, 1, Cin, Cout, act, (hipStream_t)stream);
+}
+
+extern "C" int rn_conv3d_wino_supported(int Cin, int Cout) { return rn_wino3d_supported(Cin, Cout) ? 1 : 0; }
+
+extern "C" int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
+                                  const float* residual, float* y, float* preact,
+                                  int B, int H, int W, int D, int Cin, int Cout, int act, void* stream)
+{
+    if (!x || !w_wino || !y) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: null pointer");
+    if (B < 1 || H < 1 || W < 1 || D < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: PReLU needs alpha");
+    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, D, 3, Cin, Cout, act, (hipStream_t)stream);
 }
 
 // Transposed conv, TF SAME with output = in*s (input-gradient of the SAME forward conv):

@@ -31,10 +31,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WinoArgs {
     const float* x; const float* u; const float* bias; const float* alpha; const float* res; float* y; float* z;
     unsigned x_bytes, u_bytes;
-    int B, H, W, Cin, Cout;
+    int B, H, W, D, Cin, Cout;  // D = 1: 2-D conv.  D > 1: 3x3x3 conv over [B,H,W,D,Cin], Winograd in (H,W), direct in D
+    int KD;                     // depth taps (1 or 3)
     int bh, bw;                 // 16x8-tile blocks per image along H (16 rows each) and W (32 columns each)
-    int mblocks, nblocks;       // B*bh*bw, Cout/32
-    int nstep;                  // Cin/16
+    int mblocks, nblocks;       // B*D*bh*bw, Cout/32
+    int spt;                    // 16-channel steps per depth tap = Cin/16; the K loop has KD*spt steps
     int act;
 };
 
@@ -68,9 +69,62 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 x, f32x4 y)
     return r;
 }
 
+// One block of work: which tiles / channels / K steps, and the per-lane DMA offsets that go with it.
+struct WinoBlock {
+    int by, bx, dz, b, nb;      // 16x8-tile block (rows by*16.., columns bx*32..), depth slice, batch item, n-block
+    int s_begin, s_end;         // K steps [s_begin, s_end) of 16 channels
+    unsigned roff[5];           // raw-patch DMA: per-lane byte offset of piece wave + 8 i at step 0 (WOOB = zero fill)
+    unsigned uoff;              // filter DMA: per-lane byte offset of this wave's first KiB at step 0
+};
+
+// work item `id` (0 <= id < mblocks*nblocks) -> block.  Enumeration e: groups of 8 m-blocks, n-major inside a group, so
+// that the 32 workgroups of one XCD (id % 8; one workgroup per CU, persistent, round r works on id = r*G + blockIdx)
+// stream 4 filter slabs and 8 patches between them, and the 8 XCDs of a round of 256 read the same 8 patches.
+__device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, int lane, WinoBlock& k)
+{
+    const int T = a.mblocks * a.nblocks;
+    int e = id;
+    if (id < (T & ~255)) { const int s = id >> 3; e = (s >> 5) * 256 + (id & 7) * 32 + (s & 31); }
+    const int per = 8 * a.nblocks;
+    const int g = e / per, full = a.mblocks >> 3;
+    int rem = e - g * per, gs = 8, g0 = g;
+    if (g >= full) { rem = e - full * per; gs = a.mblocks - full * 8; g0 = full; }
+    k.nb = rem / gs;
+    const int mb = g0 * 8 + rem % gs;
+    k.bx = mb % a.bw; k.by = (mb / a.bw) % a.bh; k.dz = (mb / (a.bw * a.bh)) % a.D; k.b = mb / (a.bw * a.bh * a.D);
+    // 3-D: output depth slice dz reads the KD*Cin contiguous floats of input depths dz-1..dz+1 at every (h, w) -- in
+    // channels-last [B,H,W,D,C] the conv IS a 2-D conv with 3*Cin channels per depth slice.  A depth tap outside the
+    // volume (SAME padding) is a run of `spt` whole steps of zeros: those steps are skipped.
+    k.s_begin = (a.KD == 3 && k.dz == 0) ? a.spt : 0;
+    k.s_end = a.KD * a.spt - ((a.KD == 3 && k.dz == a.D - 1) ? a.spt : 0);
+    const unsigned pix_bytes = (unsigned)a.D * (unsigned)a.Cin * 4u;
+    const unsigned win_off = (unsigned)((k.dz - (a.KD == 3 ? 1 : 0)) * a.Cin * 4);   // may wrap below 0: only used with s >= s_begin
+    const int y0 = k.by * 16 - 1, x0 = k.bx * 32 - 1;
+    // raw-patch DMA: piece p = wave + 8 i (i < 5) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane fetches
+    // LOGICAL chunk (lane%4) ^ swz(px) into physical slot lane%4, swz(px) = (px>>1)&3 (two lanes of a ds_read_b128
+    // group at most share a 16-B slot)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int p = wave + 8 * i;
+        const int q = p * 16 + (lane >> 2);
+        const int py = q / WPW, px = q - py * WPW;
+        const int iy = y0 + py, ix = x0 + px;
+        const bool ok = q < WNPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned o = (unsigned)((k.b * a.H + iy) * a.W + ix) * pix_bytes + win_off;
+        k.roff[i] = ok ? o + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16) : WOOB;
+    }
+    // filter DMA: the 32 KiB piece of (nb, step) is lane-linear; wave w moves KiB 4w .. 4w+3
+    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt)) * 32768u + (unsigned)wave * 4096u + (unsigned)lane * 16u;
+}
+
 // PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
 // 2 = no DMA inside the loop (wrong results), 4 = input transform with plain v_add/v_sub instead of v_pk_add_f32,
 // 8 = all DMAs of a step at its top instead of interleaved with the MFMAs.
+//
+// Persistent: the grid is one workgroup per CU; workgroup g works on items g, g + G, g + 2G, ...  The K loop runs
+// straight across item boundaries: during the LAST step of an item the first step of the NEXT item is fetched into the
+// free LDS stage, so the epilogue (output transform + stores) and the next item's cold start overlap its latency --
+// with 6 K steps per item (the 3-D encoder layers) prologue + epilogue used to cost as much as the steps themselves.
 template <int PROBE>
 __global__ __launch_bounds__(512, 1)
 void conv_wino_kernel(const WinoArgs a)
@@ -81,57 +135,20 @@ void conv_wino_kernel(const WinoArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
-
-    // block id -> (m-block, n-block).  Enumeration e: groups of 8 m-blocks, n-major inside a group, so that the 32
-    // workgroups resident on one XCD (block id % 8; one workgroup per CU) stream 4 filter slabs and 8 patches between
-    // them, and the 8 XCDs of a round of 256 read the same 8 patches.
-    int mb, nb;
-    {
-        const int T = a.mblocks * a.nblocks, id = blockIdx.x;
-        int e = id;
-        if (id < (T & ~255)) { const int s = id >> 3; e = (s >> 5) * 256 + (id & 7) * 32 + (s & 31); }
-        const int per = 8 * a.nblocks;
-        const int g = e / per, full = a.mblocks >> 3;
-        int rem = e - g * per, gs = 8, g0 = g;
-        if (g >= full) { rem = e - full * per; gs = a.mblocks - full * 8; g0 = full; }
-        nb = rem / gs;
-        mb = g0 * 8 + rem % gs;
-    }
-    const int bx = mb % a.bw, by = (mb / a.bw) % a.bh, b = mb / (a.bw * a.bh);
-    const int y0 = by * 16 - 1, x0 = bx * 32 - 1;
+    const int T = a.mblocks * a.nblocks, G = gridDim.x;
 
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
 
-    // raw-patch DMA: piece p = wave + 8 i (i < 5) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane
-    // fetches LOGICAL chunk (lane%4) ^ swz(px) into physical slot lane%4, swz(px) = (px>>1)&3 (two lanes of a
-    // ds_read_b128 group at most share a 16-B slot)
-    unsigned roff[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int p = wave + 8 * i;
-        const int q = p * 16 + (lane >> 2);
-        const int py = q / WPW, px = q - py * WPW;
-        const int iy = y0 + py, ix = x0 + px;
-        const bool ok = q < WNPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const unsigned e = (unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)a.Cin * 4u;
-        roff[i] = ok ? e + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16) : WOOB;
-    }
-    // filter DMA: the 32 KiB piece of (nb, step) is lane-linear; wave w moves KiB 4w .. 4w+3
-    const unsigned uoff = ((unsigned)nb * (unsigned)a.nstep) * 32768u + (unsigned)wave * 4096u + (unsigned)lane * 16u;
-
-    // fragment-read addresses (bytes).  Tile (ty, tx) = (wave, l16); pixel (2ty+ai, 2tx+bi) sits at q*64 with
+    // fragment-read addresses (bytes) in stage 0.  Tile (ty, tx) = (wave, l16); pixel (2ty+ai, 2tx+bi) sits at q*64 with
     // q = (2ty+ai)*34 + 2tx+bi, physical chunk kq ^ ((tx + (bi>>1)) & 3): two address registers, the rest immediates.
-    unsigned raddr[2];
+    unsigned raddr0[2];
 #pragma unroll
     for (int hj = 0; hj < 2; ++hj)
-        raddr[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
-    unsigned uaddr = (unsigned)(2 * WRAW_B + kq * 512 + l16 * 16);
-    // opaque to the optimiser: keeps ONE base register + 16-bit immediates (xi*2048 + nt*256 + stage*32768 < 65536) for the
-    // 64 filter-fragment reads instead of one hoisted address register each
-    asm volatile("" : "+v"(uaddr));
+        raddr0[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
+    const unsigned uaddr0 = (unsigned)(2 * WRAW_B + kq * 512 + l16 * 16);
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -141,27 +158,19 @@ void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][nt][r] = 0.f;
 
-    // DMA number idx_ (0..8) of this wave into `stage`: 0..4 = raw-patch pieces (per-lane offsets ro_[]), 5..8 = filter
-    // pieces (per-lane offset uo_, step offset us_ in an SGPR).  A step that has no successor still issues them, with
-    // out-of-range offsets: the hardware then writes zeros into the stage nobody reads -- no branches in the loop.
-#define WINO_DMA_ONE(stage, idx_)                                                                         \
+    // DMA number idx_ (0..8) of this wave into stage st_: 0..4 = raw-patch pieces (per-lane offsets ro_[]), 5..8 = filter
+    // pieces (per-lane offset uo_, step offset us_ in an SGPR).  When nothing follows, the offsets are out of range: the
+    // hardware then writes zeros into the stage nobody reads -- no branches in the loop.
+#define WINO_DMA_ONE(st_, idx_)                                                                           \
     {                                                                                                     \
         if ((idx_) < 5) {                                                                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (stage) * WRAW_B + (wave + 8 * (idx_)) * 1024), \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (st_) * WRAW_B + (wave + 8 * (idx_)) * 1024), \
                                                      16, ro_[(idx_) < 5 ? (idx_) : 0], 0, 0, 0);          \
         } else {                                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (stage) * WU_B + (wave * 4 + (idx_) - 5) * 1024), \
-                                                     16, uo_, us_ + (unsigned)((idx_) - 5) * 1024u, 0, 0);    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (st_) * WU_B + (wave * 4 + (idx_) - 5) * 1024), \
+                                                     16, uo_, us_ + (unsigned)((idx_) - 5) * 1024u, 0, 0); \
         }                                                                                                 \
     }
-#define WINO_DMA_SETUP(s, DO)                                                                             \
-        unsigned ro_[5];                                                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) ro_[i_] = (DO) ? roff[i_] + (unsigned)(s) * 64u : WOOB; \
-        const unsigned uo_ = (DO) ? uoff : WOOB;                                                          \
-        const unsigned us_ = (DO) ? (unsigned)(s) * 32768u : 0u;
-#define WINO_DMA(stage)                                                                                   \
-    { _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) WINO_DMA_ONE(stage, i_); }
-
     // 4x4 input transform of one xi row: t = (B^T d)[i][*], v = t B
 #define WINO_ROW(i)                                                                                       \
             f32x4 t_[4], v_[4];                                                                           \
@@ -181,98 +190,133 @@ void conv_wino_kernel(const WinoArgs a)
                 v_[0] = t_[0] - t_[2]; v_[1] = t_[1] + t_[2]; v_[2] = t_[2] - t_[1]; v_[3] = t_[1] - t_[3]; \
             }
 
-    // one 16-channel step on stage STG; the next step's nine DMAs (into stage STG^1) are issued one at a time behind the
-    // MFMA groups of xi 0..8 (all at the top of the step: 7.64 ms instead of 7.10 on res2 -- they stall the step's head)
-#define WINO_COMPUTE(STG)                                                                                 \
-    {                                                                                                     \
-        const char* rb_ = smem + (STG) * WRAW_B;                                                          \
-        const char* ub_ = smem + uaddr + (STG) * WU_B;                                                    \
-        f32x4 d_[4][4];                                                                                   \
-        _Pragma("unroll") for (int ai = 0; ai < 4; ++ai)                                                  \
-            _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                              \
-                d_[ai][bi] = *reinterpret_cast<const f32x4*>(rb_ + raddr[bi >> 1] + (ai * WPW + bi) * 64); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-            WINO_ROW(i)                                                                                   \
-            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                            \
-                const f32x4 b0_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048);             \
-                const f32x4 b1_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048 + 256);       \
-                _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                        \
-                    acc[i * 4 + jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_[jj][s_], b0_[s_], acc[i * 4 + jj][0], 0, 0, 0); \
-                    acc[i * 4 + jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v_[jj][s_], b1_[s_], acc[i * 4 + jj][1], 0, 0, 0); \
-                }                                                                                         \
-                if (!(PROBE & 10) && i * 4 + jj < 9) WINO_DMA_ONE((STG) ^ 1, i * 4 + jj);                 \
-            }                                                                                             \
-        }                                                                                                 \
-    }
-#define WINO_SYNC()                                                                                       \
-    {                                                                                                     \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-        __syncthreads();                                                                                  \
-    }
-
-    {
-        WINO_DMA_SETUP(0, true);
-        WINO_DMA(0);
-    }
-    WINO_SYNC();
-    for (int s = 0; s < a.nstep; s += 2) {
-        const bool m1_ = s + 1 < a.nstep, m2_ = s + 2 < a.nstep;
-        {
-            WINO_DMA_SETUP(s + 1, m1_);
-            if ((PROBE & 10) == 8) WINO_DMA(1);
-            WINO_COMPUTE(0);
-        }
-        WINO_SYNC();
-        if (m1_) {
-            WINO_DMA_SETUP(s + 2, m2_);
-            if ((PROBE & 10) == 8) WINO_DMA(0);
-            WINO_COMPUTE(1);
-            WINO_SYNC();
-        }
-    }
-#undef WINO_DMA_SETUP
-#undef WINO_ROW
-#undef WINO_DMA_ONE
-#undef WINO_SYNC
-#undef WINO_COMPUTE
-#undef WINO_DMA
-
-    // epilogue.  C/D layout of the 16x16 MFMA: col = lane&15 (channel), row = 4*(lane>>4) + r = the tile's tx.
-    // Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = acc[4i+j].
-    const int ty = wave;
+    WinoBlock cur, nxt;
+    int id = blockIdx.x;
+    if (id >= T) return;
+    wino_block(a, id, wave, lane, cur);
+    int stage = 0;
+    {   // the first step of the first item
+        unsigned ro_[5];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = nb * 32 + nt * 16 + l16;
-        const float bv = a.bias ? a.bias[n] : 0.f;
-        const float av = a.alpha ? a.alpha[n] : 0.f;
+        for (int i = 0; i < 5; ++i) ro_[i] = cur.roff[i] + (unsigned)cur.s_begin * 64u;
+        const unsigned uo_ = cur.uoff, us_ = (unsigned)cur.s_begin * 32768u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s_[4][2];                  // column transform of every xi row: M[i][*] A
+        for (int i = 0; i < 9; ++i) WINO_DMA_ONE(0, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (;;) {
+        const bool has_next = id + G < T;
+        if (has_next) wino_block(a, id + G, wave, lane, nxt);
+        for (int s = cur.s_begin; s < cur.s_end; ++s) {
+            // what the other stage receives during this step: the item's next step, or the next item's first, or nothing
+            const bool last = s + 1 == cur.s_end;
+            const bool fetch = !last || has_next;
+            unsigned ro_[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                ro_[i] = !fetch ? WOOB : last ? nxt.roff[i] + (unsigned)nxt.s_begin * 64u : cur.roff[i] + (unsigned)(s + 1) * 64u;
+            const unsigned uo_ = !fetch ? WOOB : last ? nxt.uoff : cur.uoff;
+            const unsigned us_ = !fetch ? 0u : last ? (unsigned)nxt.s_begin * 32768u : (unsigned)(s + 1) * 32768u;
+            const int st1 = stage ^ 1;
+            if ((PROBE & 10) == 8) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) WINO_DMA_ONE(st1, i);
+            }
+            // one 16-channel step on `stage`; the nine DMAs are issued one at a time behind the MFMA groups of xi 0..8
+            // (all at the top of the step: 7.64 ms instead of 7.10 on res2 -- they stall the step's head)
+            const char* rb0_ = smem + raddr0[0] + stage * WRAW_B;
+            const char* rb1_ = smem + raddr0[1] + stage * WRAW_B;
+            unsigned ua_ = uaddr0 + (unsigned)stage * WU_B;
+            asm volatile("" : "+v"(ua_));     // opaque: ONE base register + 16-bit immediates for the 32 filter-fragment reads
+            const char* ub_ = smem + ua_;
+            f32x4 d_[4][4];
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                    d_[ai][bi] = *reinterpret_cast<const f32x4*>(((bi >> 1) ? rb1_ : rb0_) + (ai * WPW + bi) * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                s_[i][0] = (acc[i * 4 + 0][nt][r] + acc[i * 4 + 1][nt][r]) + acc[i * 4 + 2][nt][r];
-                s_[i][1] = (acc[i * 4 + 1][nt][r] - acc[i * 4 + 2][nt][r]) - acc[i * 4 + 3][nt][r];
+                WINO_ROW(i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 b0_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048);
+                    const f32x4 b1_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048 + 256);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        // A operand = filter fragment, B operand = transformed-input fragment: the accumulator then holds
+                        // FOUR CONSECUTIVE CHANNELS of one tile per lane (rows = channels), which the epilogue stores as 16 B
+                        acc[i * 4 + jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0_[s_], v_[jj][s_], acc[i * 4 + jj][0], 0, 0, 0);
+                        acc[i * 4 + jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1_[s_], v_[jj][s_], acc[i * 4 + jj][1], 0, 0, 0);
+                    }
+                    if (!(PROBE & 10) && i * 4 + jj < 9) WINO_DMA_ONE(st1, i * 4 + jj);
+                }
             }
-            const int tx = 4 * kq + r;
+            if (!last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                stage = st1;
+            }
+        }
+        {
+        // epilogue of the finished item (its successor's first step is in flight).  C/D layout of the 16x16 MFMA with the
+        // filter as A: row = 4*(lane>>4) + r = channel within the 16-wide n-tile, col = lane&15 = the tile's tx: a lane
+        // holds channels 4kq..4kq+3 of tile (ty, tx) = (wave, l16) -> 16-B loads and stores, 128 contiguous bytes per pixel
+        // and workgroup.  Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = acc[4i+j].
+        const int ty = wave, tx = l16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = cur.nb * 32 + nt * 16 + 4 * kq;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
+            const f32x4 av = a.alpha ? *reinterpret_cast<const f32x4*>(a.alpha + n) : zero4;
+            f32x4 c_[4][2];                      // column transform of every xi row: M[i][*] A
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c_[i][0] = (acc[i * 4 + 0][nt] + acc[i * 4 + 1][nt]) + acc[i * 4 + 2][nt];
+                c_[i][1] = (acc[i * 4 + 1][nt] - acc[i * 4 + 2][nt]) - acc[i * 4 + 3][nt];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i][nt] = zero4;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const int oy = by * 16 + 2 * ty + dy, ox = bx * 32 + 2 * tx + dx;
+                    const int oy = cur.by * 16 + 2 * ty + dy, ox = cur.bx * 32 + 2 * tx + dx;
                     if (oy < a.H && ox < a.W) {
-                        float v = dy == 0 ? (s_[0][dx] + s_[1][dx]) + s_[2][dx] : (s_[1][dx] - s_[2][dx]) - s_[3][dx];
+                        f32x4 v = dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[3][dx];
                         v += bv;
-                        const size_t oo = ((size_t)(b * a.H + oy) * a.W + ox) * a.Cout + n;
-                        if (a.z) a.z[oo] = v;
-                        if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + av * fminf(v, 0.f);
-                        if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
-                        if (a.res) v += a.res[oo];
-                        if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                        a.y[oo] = v;
+                        const size_t oo = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + n;
+                        if (a.z) *reinterpret_cast<f32x4*>(a.z + oo) = v;
+                        if (a.act & RN_ACT_PRELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
+                        }
+                        if (a.act & RN_ACT_ELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
+                        }
+                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + oo);
+                        if (a.act & RN_ACT_SIGMOID) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                        }
+                        *reinterpret_cast<f32x4*>(a.y + oo) = v;
                     }
                 }
         }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage ^= 1;
+        if (!has_next) break;
+        id += G;
+        cur = nxt;
     }
+#undef WINO_ROW
+#undef WINO_DMA_ONE
 }
 
 bool rn_wino_supported(int Cin, int Cout)
@@ -281,41 +325,51 @@ bool rn_wino_supported(int Cin, int Cout)
     return !off && Cin % 16 == 0 && Cout % 32 == 0;
 }
 
-// x [B,H,W,Cin] -> y [B,H,W,Cout], 3x3 stride 1 SAME; u from rn_pack_weights(RN_PACK_CONV_WINO | RN_PACK_CONVT_S1_WINO)
+bool rn_wino3d_supported(int Cin, int Cout)
+{
+    static const bool off = getenv("RN_NO_WINOGRAD3D") != nullptr;
+    return !off && rn_wino_supported(Cin, Cout);
+}
+
+// x [B,H,W,(D,)Cin] -> y [B,H,W,(D,)Cout], 3x3(x3) stride 1 SAME; u from rn_pack_weights(RN_PACK_CONV_WINO |
+// RN_PACK_CONVT_S1_WINO) with the matching ndim.  D = 1, KD = 1: 2-D.  KD = 3: 3-D (D >= 1).
 int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
-                        float* y, float* preact, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st)
+                        float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act, hipStream_t st)
 {
     if (Cin % 16 != 0 || Cout % 32 != 0)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d (need %%16) Cout=%d (need %%32)", Cin, Cout);
-    const long long per_item = (long long)H * W * Cin * 4;
+    if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1)) return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d", D, KD);
+    const long long per_item = (long long)H * W * D * Cin * 4;
     if (per_item >= 0x80000000LL)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: one batch item of %lld bytes exceeds the 2 GiB buffer window", per_item);
     if (per_item * B >= 0x80000000LL) {
         // 32-bit byte offsets with the upper half reserved for the hardware zero fill: batch chunks that fit the window
         const int chunk = (int)(0x7fffffffLL / per_item);
-        const size_t ostep = (size_t)H * W * Cout;
+        const size_t ostep = (size_t)H * W * D * Cout;
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nbi = B - b0 < chunk ? B - b0 : chunk;
             const int rc = rn_launch_conv_wino(x + (size_t)b0 * (per_item / 4), u, bias, alpha,
                                                residual ? residual + b0 * ostep : nullptr, y + b0 * ostep,
-                                               preact ? preact + b0 * ostep : nullptr, nbi, H, W, Cin, Cout, act, st);
+                                               preact ? preact + b0 * ostep : nullptr, nbi, H, W, D, KD, Cin, Cout, act, st);
             if (rc != RN_OK) return rc;
         }
         return RN_OK;
     }
+    if ((((uintptr_t)x | (uintptr_t)u | (uintptr_t)bias | (uintptr_t)alpha | (uintptr_t)residual | (uintptr_t)y | (uintptr_t)preact) & 15) != 0)
+        return rn_set_error(RN_E_INVALID, "conv_wino: every pointer must be 16-byte aligned (16-B loads and stores)");
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.alpha = alpha; a.res = residual; a.y = y; a.z = preact;
     a.x_bytes = (unsigned)(per_item * B);
-    const long long ub = 16LL * Cin * Cout * 4;
+    const long long ub = 16LL * KD * Cin * Cout * 4;
     if (ub >= 0x80000000LL) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: transformed filter of %lld bytes exceeds 2 GiB", ub);
     a.u_bytes = (unsigned)ub;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.B = B; a.H = H; a.W = W; a.D = D; a.KD = KD; a.Cin = Cin; a.Cout = Cout;
     a.bh = (H + 15) / 16; a.bw = (W + 31) / 32;
-    const long long mbl = (long long)B * a.bh * a.bw;
+    const long long mbl = (long long)B * D * a.bh * a.bw;
     a.nblocks = Cout / 32;
     if (mbl * a.nblocks > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wino: grid too large");
     a.mblocks = (int)mbl;
-    a.nstep = Cin / 16;
+    a.spt = Cin / 16;
     a.act = act;
     static const int probe = getenv("RN_WINO_PROBE") ? atoi(getenv("RN_WINO_PROBE")) : 0;
     const size_t lds = rn_wino_lds_bytes();
@@ -324,6 +378,19 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
               : conv_wino_kernel<0>;
     // per launch: the attribute is per device, and a process may drive several
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mblocks * a.nblocks)), dim3(512), lds, st, a);
+    // persistent grid: one workgroup per CU (147 KiB of LDS each), every one walking its share of the items
+    static int ncu[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!ncu[dev]) {
+        hipDeviceProp_t pr;
+        ncu[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    const long long total = (long long)a.mblocks * a.nblocks;
+    static const int grid_env = getenv("RN_WINO_GRID") ? atoi(getenv("RN_WINO_GRID")) : 0;     // measurement: 0 = one per CU
+    const long long want = grid_env > 0 ? grid_env : ncu[dev];
+    const unsigned grid = (unsigned)(total < want ? total : want);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     return rn_check_launch("conv_wino");
 }

@@ -56,13 +56,15 @@ __global__ void pack_weights_kernel(const PackArgs a)
 }
 
 // Winograd F(2x2,3x3) filter transform for csrc/conv_wino.hip: U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],
-// packed [Cout/32][Cin/16][16 xi][4 kq][32 n][4 r] with channel c = step*16 + kq*4 + r (one contiguous 32 KiB piece per
-// (n-block, 16-channel step)).  RN_PACK_CONV_WINO reads w_tf[3,3,Cin,Cout]; RN_PACK_CONVT_S1_WINO reads
-// w_tf[3,3,Cout,Cin] with the taps flipped (a stride-1 transposed conv = the input gradient of a 3x3 conv).
-__global__ void pack_wino_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
+// packed [Cout/32][KD*Cin/16][16 xi][4 kq][32 n][4 r] with channel c' = step*16 + kq*4 + r (one contiguous 32 KiB piece
+// per (n-block, 16-channel step)).  RN_PACK_CONV_WINO reads w_tf[3,3,(3,)Cin,Cout]; RN_PACK_CONVT_S1_WINO reads
+// w_tf[3,3,(3,)Cout,Cin] with the taps flipped (a stride-1 transposed conv = the input gradient of a 3x3(x3) conv).
+// 3-D filters (KD = 3): the transform runs over the first two filter dims only, the depth tap t2 joins the channel:
+// c' = t2*Cin + c -- the kernel walks the 3*Cin contiguous floats of three depth slices (see conv_wino.hip).
+__global__ void pack_wino_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int KD, int transposed)
 {
-    const size_t total = (size_t)16 * Cin * Cout;
-    const int nstep = Cin / 16;
+    const size_t total = (size_t)16 * KD * Cin * Cout;
+    const int nstep = KD * Cin / 16;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         size_t rem = idx;
         const int r = (int)(rem & 3); rem >>= 2;
@@ -71,15 +73,16 @@ __global__ void pack_wino_kernel(const float* __restrict__ w_tf, float* __restri
         const int xi = (int)(rem & 15); rem >>= 4;
         const int step = (int)(rem % nstep);
         const int nb = (int)(rem / nstep);
-        const int c = step * 16 + kq * 4 + r, co = nb * 32 + n;
+        const int ce = step * 16 + kq * 4 + r, co = nb * 32 + n;
+        const int t2 = ce / Cin, c = ce - t2 * Cin;
         const int i = xi >> 2, j = xi & 3;
         float g[3][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                g[p][q] = transposed ? w_tf[((size_t)((2 - p) * 3 + (2 - q)) * Cout + co) * Cin + c]
-                                     : w_tf[((size_t)(p * 3 + q) * Cin + c) * Cout + co];
+                g[p][q] = transposed ? w_tf[((size_t)(((2 - p) * 3 + (2 - q)) * KD + (KD - 1 - t2)) * Cout + co) * Cin + c]
+                                     : w_tf[((size_t)((p * 3 + q) * KD + t2) * Cin + c) * Cout + co];
         float row[3];                               // (G g)[i][q]
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -94,8 +97,8 @@ static bool is_wino_kind(int kind) { return kind == RN_PACK_CONV_WINO || kind ==
 
 static int wino_pack_check(int ndim, const int* kdims, int Cin, int Cout)
 {
-    if (!kdims || ndim != 2 || kdims[0] != 3 || kdims[1] != 3)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need a 2-D 3x3 filter");
+    if (!kdims || (ndim != 2 && ndim != 3) || kdims[0] != 3 || kdims[1] != 3 || (ndim == 3 && kdims[2] != 3))
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need a 3x3 or 3x3x3 filter");
     if (Cin < 16 || Cout < 32 || Cin % 16 != 0 || Cout % 32 != 0)
         return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", Cin, Cout);
     return RN_OK;
@@ -123,7 +126,7 @@ static int pack_geometry(int kind, int ndim, const int* kdims, int Cin, int Cout
 
 extern "C" size_t rn_packed_weight_floats(int kind, int ndim, const int* kdims, int Cin, int Cout)
 {
-    if (is_wino_kind(kind)) return wino_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)16 * Cin * Cout : 0;
+    if (is_wino_kind(kind)) return wino_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)16 * (ndim == 3 ? 3 : 1) * Cin * Cout : 0;
     PackArgs a;
     if (pack_geometry(kind, ndim, kdims, Cin, Cout, a) != RN_OK) return 0;
     return (size_t)a.nphase * a.Kq * a.Npad * 4;
@@ -136,9 +139,10 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
         const int rcw = wino_pack_check(ndim, kdims, Cin, Cout);
         if (rcw != RN_OK) return rcw;
         if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
-        const size_t tot = (size_t)16 * Cin * Cout;
+        const int KD = ndim == 3 ? 3 : 1;
+        const size_t tot = (size_t)16 * KD * Cin * Cout;
         const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
-        hipLaunchKernelGGL(pack_wino_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
+        hipLaunchKernelGGL(pack_wino_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout, KD,
                            kind == RN_PACK_CONVT_S1_WINO ? 1 : 0);
         return rn_check_launch("pack_wino");
     }

@@ -52,8 +52,8 @@ class PackedWeight:
         # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
         self.wino = None
         wkind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO}.get(kind)
-        if (wkind is not None and ndim == 2 and self.kdims == [3, 3]
-                and lib.rn_conv2d_wino_supported(self.cin, self.cout)):
+        if wkind is not None and ((ndim == 2 and self.kdims == [3, 3] and lib.rn_conv2d_wino_supported(self.cin, self.cout))
+                                  or (ndim == 3 and self.kdims == [3, 3, 3] and lib.rn_conv3d_wino_supported(self.cin, self.cout))):
             nw = lib.rn_packed_weight_floats(wkind, ndim, L.ivec(self.kdims), self.cin, self.cout)
             if nw == 0:
                 raise L.RenderNetHipError("rn_packed_weight_floats (Winograd): %s" % lib.rn_last_error().decode())
@@ -225,6 +225,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     a = (L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
+        if pw.wino is not None and tuple(stride) == (1, 1, 1):
+            return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *a[2:], B, H, W, D, Cin, pw.cout, act, st)
         return lib.rn_conv3d_fwd_train(*a, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d":
         B, H, W, Cin = x.shape
@@ -314,7 +316,10 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
-            if mode == "conv3d":
+            if mode == "conv3d" and unit and dp.wino is not None:
+                rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
+                                            B, H, W, D, pw.cout, Cin, 0, st)
+            elif mode == "conv3d":
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode == "conv2d" and unit and dp.wino is not None:
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter

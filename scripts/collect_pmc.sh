@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerate the counter evidence of the three roofline kernels on the CURRENT build (run on the GPU box):
 #   * the dominant conv  -- Winograd kernel on the res2 shape (scripts/wino_bench.py --shapes 64x1024)
-#   * the 3-D encoder kernel (scripts/layer_bench.py --only res1)
+#   * the 3-D encoder layer (scripts/layer_bench.py --only res1): the direct depth-run kernel (RN_NO_WINOGRAD3D=1) and
+#     the Winograd kernel on the same layer
 #   * the resampler's three launches (scripts/layer_bench.py --only resample)
 # One rocprofv3 --pmc pass per counter set (SQ set | FETCH_SIZE | WRITE_SIZE | TCC hit/miss), --kernel-trace only (no
 # other trace domain beside --pmc).  Summaries land in $OUT (default gpurun_out/pmc); scripts/pmc_to_traffic.py then
@@ -26,11 +27,12 @@ for tag in sq fetch write tcc; do
         sq) C=$SQ ;; fetch) C="FETCH_SIZE" ;; write) C="WRITE_SIZE" ;; tcc) C=$TCC ;;
     esac
     run wino $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --wino-only
-    run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
-    run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5
+    RN_NO_WINOGRAD3D=1 run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    run res1w $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done
-for name in wino res1 resample; do
-    flt=""; [ $name = wino ] && flt=conv_wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = resample ] && flt=resample_
+for name in wino res1 res1w resample; do
+    flt=""; [ $name = wino ] && flt=conv_wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
     : > "$OUT/$name.txt"
     for tag in sq fetch write tcc; do
         f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)
@@ -38,4 +40,4 @@ for name in wino res1 resample; do
     done
 done
 python "$R/scripts/pmc_to_traffic.py" "$OUT" "$OUT/traffic.json"
-echo "wrote $OUT/{wino,res1,resample}.txt and $OUT/traffic.json"
+echo "wrote $OUT/{wino,res1,res1w,resample}.txt and $OUT/traffic.json"

@@ -17,6 +17,7 @@ csv.field_size_limit(1 << 30)
 KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s), algorithmic bytes per launch at B=24)
     "conv_wino_res2": ("wino", ["conv_wino_kernel"], 24 * 64 * 64 * 1024 * 4 * 2 + 16 * 1024 * 1024 * 4),
     "conv3d_drun_res1": ("res1", ["conv3d_k3_drun"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 27 * 32 * 32 * 4),
+    "conv_wino_res1": ("res1w", ["conv_wino_kernel"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 16 * 3 * 32 * 32 * 4),
     "resampler": ("resample", ["resample_prepare", "resample_classify", "resample_main"], 24 * 9437184),
 }
 

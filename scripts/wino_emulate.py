@@ -19,9 +19,14 @@ G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float
 
 def pack_wino(w_tf, transposed=False):
     """TF conv filter [3,3,Cin,Cout] (or, transposed=True, a conv_transpose-style [3,3,Cout,Cin] read with
-    flipped taps) -> U = G g G^T packed [Cout/32][Cin/16][16 xi][4 kq][32 n][4 r], channel c = step*16 + kq*4 + r."""
+    flipped taps) -> U = G g G^T packed [Cout/32][Cin/16][16 xi][4 kq][32 n][4 r], channel c = step*16 + kq*4 + r.
+    3-D filters [3,3,3,Cin,Cout]: the depth tap joins the channel, c' = t2*Cin + c (transform over the first two dims)."""
     w = np.asarray(w_tf, np.float32)
-    if transposed:
+    if w.ndim == 5:
+        if transposed:
+            w = w[::-1, ::-1, ::-1].transpose(0, 1, 2, 4, 3)
+        w = np.ascontiguousarray(w).reshape(3, 3, 3 * w.shape[3], w.shape[4])
+    elif transposed:
         w = w[::-1, ::-1].transpose(0, 1, 3, 2)
     cin, cout = w.shape[2], w.shape[3]
     assert cin % 16 == 0 and cout % 32 == 0
@@ -45,12 +50,20 @@ def block_map(bid, mblocks, nblocks):
 
 
 def conv_wino_emulated(x, u_packed, cout, bias=None):
-    """x [B,H,W,Cin] float32 -> y [B,H,W,Cout]; follows the kernel thread by thread (vectorised over lanes)."""
-    B, H, W, Cin = x.shape
+    """x [B,H,W,Cin] (2-D) or [B,H,W,D,Cin] (3x3x3 conv) float32 -> y [B,H,W,(D,)Cout]; follows the kernel thread by
+    thread (vectorised over lanes)."""
+    three_d = x.ndim == 5
+    if three_d:
+        B, H, W, D, Cin = x.shape
+        KD = 3
+    else:
+        B, H, W, Cin = x.shape
+        D, KD = 1, 1
     xf = np.ascontiguousarray(x, np.float32).reshape(-1)
-    y = np.full((B, H, W, cout), np.nan, np.float32)
+    y = np.full((B, H, W, D, cout), np.nan, np.float32)
     bh, bw = (H + 15) // 16, (W + 31) // 32
-    mblocks, nblocks, nstep = B * bh * bw, cout // 32, Cin // 16
+    spt = Cin // 16
+    mblocks, nblocks, nstep = B * D * bh * bw, cout // 32, KD * spt
     lane = np.arange(64)
     l16, kq = lane & 15, lane >> 4
     seen = set()
@@ -58,10 +71,13 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
         mb, nb = block_map(bid, mblocks, nblocks)
         assert (mb, nb) not in seen
         seen.add((mb, nb))
-        bx, by, b = mb % bw, (mb // bw) % bh, mb // (bw * bh)
+        bx, by, dz, b = mb % bw, (mb // bw) % bh, (mb // (bw * bh)) % D, mb // (bw * bh * D)
         y0, x0 = by * 16 - 1, bx * 32 - 1
+        s_begin = spt if (KD == 3 and dz == 0) else 0
+        s_end = nstep - (spt if (KD == 3 and dz == D - 1) else 0)
+        win_off = (dz - (1 if KD == 3 else 0)) * Cin * 4
         acc = np.zeros((8, 16, 2, 64, 4), np.float32)                     # wave, xi, nt, lane, r
-        for s in range(nstep):
+        for s in range(s_begin, s_end):
             lds = np.zeros((WRAW_B + WU_B) // 4, np.float32)
             for wave in range(8):
                 for i in range(5):                                        # raw patch pieces
@@ -70,7 +86,7 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                     py, px = q // WPW, q % WPW
                     iy, ix = y0 + py, x0 + px
                     ok = (q < WNPIX) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
-                    off = ((b * H + iy) * W + ix) * Cin * 4 + (((lane & 3) ^ ((px >> 1) & 3)) * 16) + s * 64
+                    off = ((b * H + iy) * W + ix) * D * Cin * 4 + win_off + (((lane & 3) ^ ((px >> 1) & 3)) * 16) + s * 64
                     for ln in range(64):
                         dst = (p * 1024 + ln * 16) // 4
                         lds[dst:dst + 4] = xf[off[ln] // 4: off[ln] // 4 + 4] if ok[ln] else 0.0
@@ -93,23 +109,24 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                     for nt in range(2):
                         ad = (uaddr + xi * 2048 + nt * 256) // 4
                         bb = lds[ad[:, None] + np.arange(4)]                                  # [lane, s]
-                        # MFMA 16x16x4 x4: A[row=l16][k=4kq+s], B[k=4kq+s][col=l16]
+                        # MFMA 16x16x4 x4 with the FILTER as the A operand: A[row=l16 (channel)][k=4kq+s],
+                        # B[k=4kq+s][col=l16 (tile)]
                         A = np.zeros((16, 16), np.float32)
                         Bm = np.zeros((16, 16), np.float32)
-                        A[l16[:, None], (4 * kq)[:, None] + np.arange(4)] = vv
-                        Bm[(4 * kq)[:, None] + np.arange(4), l16[:, None]] = bb
-                        D = A @ Bm                                                            # [row, col]
+                        A[l16[:, None], (4 * kq)[:, None] + np.arange(4)] = bb
+                        Bm[(4 * kq)[:, None] + np.arange(4), l16[:, None]] = vv
+                        Dm = A @ Bm                                                           # [row = channel, col = tile]
                         # D -> lane (col = l16, rows 4kq..4kq+3)
-                        acc[wave, xi, nt] += D[(4 * kq)[:, None] + np.arange(4), l16[:, None]]
+                        acc[wave, xi, nt] += Dm[(4 * kq)[:, None] + np.arange(4), l16[:, None]]
         for wave in range(8):
             ty = wave
             for nt in range(2):
-                n = nb * 32 + nt * 16 + l16
                 for r in range(4):
+                    n = nb * 32 + nt * 16 + 4 * kq + r        # a lane holds channels 4kq..4kq+3 of tile tx = l16
                     M = acc[wave, :, nt, :, r].reshape(4, 4, 64)
                     sc = np.stack([M[:, 0] + M[:, 1] + M[:, 2], M[:, 1] - M[:, 2] - M[:, 3]], 1)   # [i][dx][lane]
                     Y = np.stack([sc[0] + sc[1] + sc[2], sc[1] - sc[2] - sc[3]])                   # [dy][dx][lane]
-                    tx = 4 * kq + r
+                    tx = l16
                     for dy in range(2):
                         for dx in range(2):
                             oy, ox = by * 16 + 2 * ty + dy, bx * 32 + 2 * tx + dx
@@ -117,6 +134,6 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                                 continue
                             ok = ox < W
                             val = Y[dy, dx] + (bias[n] if bias is not None else 0.0)
-                            y[b, oy, ox[ok], n[ok]] = val[ok]
+                            y[b, oy, ox[ok], dz, n[ok]] = val[ok]
     assert len(seen) == mblocks * nblocks
-    return y
+    return y if three_d else y[:, :, :, 0]

@@ -328,3 +328,48 @@ def test_winograd_and_conv3d_inputs_over_2gib_batch_chunks():
     _close(y[items[1]:items[1] + 1], OL.conv3d(x[items[1]:items[1] + 1].cpu().numpy(), w, b, (1, 1, 1)), "chunked conv3d vs oracle")
     del x, y
     torch.cuda.empty_cache()
+
+
+# 3x3x3 stride-1 convs through the Winograd kernel (F(2x2,3x3) over H,W; depth taps as 3*Cin contiguous channels)
+WINO3D_CASES = [
+    (2, 8, 8, 4, 32, 32),        # res1
+    (1, 5, 7, 3, 32, 32),        # ragged, D = 3
+    (1, 20, 37, 1, 16, 32),      # e_conv3 widths, a single depth slice (both neighbours are padding)
+    (1, 16, 16, 2, 32, 64),      # D = 2: every slice has one padded neighbour
+    (2, 64, 64, 8, 32, 32),
+]
+
+
+@pytest.mark.parametrize("case", WINO3D_CASES)
+def test_conv3d_winograd(case):
+    from rendernet_amd import ops, _lib as L
+    from scripts.wino_emulate import pack_wino
+    B, H, W, D, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, D, Cin)
+    w = _xavier(rng, (3, 3, 3, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    assert pw.wino is not None
+    want_u = pack_wino(w)
+    assert np.abs(pw.wino.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    y0 = OL.conv3d(x, w, b, (1, 1, 1))
+    _close(ops.conv3d(_dev(x), pw, _dev(b)), y0, "wino3d")
+    res = _rand(rng, *y0.shape)
+    want = OL.prelu(y0, alpha) + torch.from_numpy(res)
+    got = ops.conv3d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+    _close(got, want, "wino3d+prelu+res")
+    pd = ops.pack_conv(_dev(w))
+    pd.wino = None                                          # the depth-run / implicit-GEMM kernels
+    direct = ops.conv3d(_dev(x), pd, _dev(b), _dev(alpha), _dev(res))
+    assert float((got - direct).abs().max()) <= 2e-5 * float(direct.abs().max())
+    dp = pw.dgrad_pack(True)
+    if dp.wino is None:
+        assert not (Cout % 16 == 0 and Cin % 32 == 0)
+        return
+    dz = _dev(_rand(rng, B, H, W, D, Cout))
+    dx_w = torch.empty((B, H, W, D, Cin), device="cuda")
+    L.check(L.lib().rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx_w), None, B, H, W, D, Cout, Cin, 0,
+                                       L.stream_ptr()), "rn_conv3d_wino_fwd (dgrad)")
+    _close(dx_w, OL.conv3d_transpose(dz.cpu().numpy(), w, None, (1, 1, 1)), "wino3d dgrad vs oracle")

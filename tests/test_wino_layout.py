@@ -46,3 +46,22 @@ def test_block_map_groups_an_xcd_round_on_few_slabs():
             assert len(mbs) == 8 and len(nbs) == 4
             patches |= mbs
         assert len(patches) == 8
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 20, 4, 16, 32), (2, 16, 16, 1, 32, 32), (1, 5, 5, 3, 16, 64)])
+def test_emulated_kernel_matches_the_oracle_conv3d(shape):
+    """The 3x3x3 flavour: Winograd over (H,W), the three depth taps as 3*Cin contiguous channels per depth slice, whole
+    steps skipped where a depth tap is SAME padding."""
+    B, H, W, D, Cin, Cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((B, H, W, D, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cin, Cout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = conv_wino_emulated(x, pack_wino(w), Cout, b)
+    want = OL.conv3d(x, w, b, (1, 1, 1)).numpy()
+    assert not np.isnan(got).any()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    wt = (rng.standard_normal((3, 3, 3, Cout, Cin)) * 0.1).astype(np.float32)     # conv3d_transpose layout [k,k,k,Cout,Cin]
+    got = conv_wino_emulated(x, pack_wino(wt, transposed=True), Cout)
+    want = OL.conv3d_transpose(x, wt, None, (1, 1, 1)).numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
