@@ -10,14 +10,16 @@ initialisers), renders every binvox under `model_path` at the demo pose and writ
 `--train` runs the reference's training loop (:193-306): epochs over the image tar (`image_path`, poses parsed from
 the member names) + binvox folder (`model_path`), crop 32 for the first five epochs then 64 (:204-207), BCE (greyscale)
 or MSE loss, Adam(beta1=0.5) with staircase-decayed learning rate, a sample PNG every 600 steps, weights saved as
-`<sample_save>/<trained_model_name>.npz` after every epoch, then the validation pass over `image_path_valid`
-(:257-301).  Under `torch.distributed.run` every rank trains on its shard of each batch and the gradients are
+`<sample_save>/<trained_model_name>.npz` after every epoch and every `checkpoint_secs` (weights + Adam moments +
+global_step + epoch, written atomically; a restart resumes from it like the reference's Supervisor), then the
+validation pass over `image_path_valid` (:257-301, dropout off).  Under `torch.distributed.run` every rank trains on its shard of each batch and the gradients are
 summed with bucketed RCCL all-reduces (rendernet_amd/train.py).
 """
 import glob
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -49,23 +51,32 @@ def train(cfg, argv):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(cfg.get('gpu', 0)) if world == 1 else "0"))
+    bs = int(cfg['batch_size'])
+    if bs % world != 0:
+        # an empty or short shard would leave its rank out of the bucket / loss all-reduces: rank 0 would block for ever
+        raise SystemExit("batch_size %d is not a multiple of the %d ranks: every rank needs the same, non-empty shard of "
+                         "each batch" % (bs, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        import datetime
+        # generous collective timeout: rank 0 validates alone at the end of an epoch while the others wait at a barrier
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(hours=6))
     grey = cfg['is_greyscale'].lower() == "true"
     spec = ShaderSpec(out_ch=1 if grey else 3).check()
     sample_save = cfg['sample_save']
     os.makedirs(sample_save, exist_ok=True)
     wpath = os.path.join(sample_save, cfg['trained_model_name'] + ".npz")
-    weights = dict(np.load(wpath)) if os.path.exists(wpath) else init_shader_weights(spec, seed=1234)
-    tr = Trainer(spec, weights, device="cuda:%d" % local_rank, e_eta=cfg.get('e_eta', 1e-5),
+    tr = Trainer(spec, init_shader_weights(spec, seed=1234), device="cuda:%d" % local_rank, e_eta=cfg.get('e_eta', 1e-5),
                  decay_steps=cfg.get('decay_steps', 100000), keep_prob=cfg.get('keep_prob', 1.0))
-    bs = int(cfg['batch_size'])
+    # resume like the reference's Supervisor (:171-185): weights, Adam moments, global_step and the epoch counter
+    first_epoch = tr.load_checkpoint(dict(np.load(wpath))) if os.path.exists(wpath) else 0
     new_res = spec.new_size
     max_steps = int(argv[argv.index("--max-steps") + 1]) if "--max-steps" in argv else None
+    ckpt_secs = float(cfg.get('checkpoint_secs', 7200))
+    last_ckpt = time.time()
     l1_all = []
-    for epoch in range(int(cfg['max_epochs'])):
+    for epoch in range(first_epoch, int(cfg['max_epochs'])):
         patch = new_res // 4 if epoch < 5 else new_res // 2                           # :204-207
         for images, models, params, names in data_loader(cfg, img_path=cfg['image_path'], model_path=cfg['model_path'],
                                                          flatten=grey, validation_mode=False, img_res=4 * new_res):
@@ -82,8 +93,12 @@ def train(cfg, argv):
                 step = tr.global_step
                 if rank == 0:
                     print("Step {0} Loss {1}".format(step, float(loss.item())))
-                if step % 600 == 0 and rank == 0 and hi > lo:                           # :242-253
-                    pred, (r, c, p, _) = tr.forward(models[sl][lo:hi], params[sl][lo:hi], patch, start.tolist())
+                if rank == 0 and time.time() - last_ckpt >= ckpt_secs:                  # Supervisor(save_model_secs=checkpoint_secs)
+                    tr.save_checkpoint(wpath, epoch)
+                    last_ckpt = time.time()
+                if step % 600 == 0 and rank == 0:                                       # :242-253
+                    with torch.no_grad():
+                        pred, (r, c, p, _) = tr.forward(models[sl][lo:hi], params[sl][lo:hi], patch, start.tolist())
                     i = random.randint(0, hi - lo - 1)
                     tgt = images[sl][lo:hi][i, 4 * r:4 * (r + p), 4 * c:4 * (c + p)]
                     _save_png(os.path.join(sample_save, "{0}_train_target_{1}_patch.png".format(names[sl][lo + i], step)), tgt)
@@ -94,8 +109,10 @@ def train(cfg, argv):
             if max_steps is not None and tr.global_step >= max_steps:
                 break
         if rank == 0:
-            np.savez(wpath, **tr.state_dict())                                          # :257 sess_saver.save
-        # validation (:258-301): full-resolution render, mean absolute error
+            tr.save_checkpoint(wpath, epoch + 1)                                        # :257 sess_saver.save (atomic)
+            last_ckpt = time.time()
+        # validation (:258-301): full-resolution render with is_training False (dropout off), mean absolute error; on
+        # rank 0 while the other ranks wait at the barrier below (a generous timeout: torch's default is 10 min for nccl)
         if rank == 0 and cfg.get('image_path_valid') and os.path.exists(cfg['image_path_valid']):
             l1, cnt = 0.0, 0
             with torch.no_grad():
@@ -103,7 +120,7 @@ def train(cfg, argv):
                                                                  model_path=cfg['model_path'], flatten=grey,
                                                                  validation_mode=True, img_res=4 * new_res):
                     images = images / 255.0
-                    pred, _ = tr.forward(models, params)
+                    pred, _ = tr.forward(models, params, is_training=False)
                     pred = pred.cpu().numpy()
                     if cnt % 600 == 0:
                         _save_png(os.path.join(sample_save, "VALID_{0}_target_{1}.png".format(names[0], epoch)), images[0])
@@ -115,10 +132,11 @@ def train(cfg, argv):
             if cnt:
                 l1_all.append(l1 / cnt)
                 np.savez(os.path.join(sample_save, "L1 All.txt"), l1_all)
+        if world > 1:
+            dist.barrier()                      # nobody starts the next epoch's collectives while rank 0 validates
         if max_steps is not None and tr.global_step >= max_steps:
             break
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -139,7 +157,10 @@ def main(argv=None):
     sample_save = cfg['sample_save']
     os.makedirs(sample_save, exist_ok=True)
     wpath = os.path.join(sample_save, cfg['trained_model_name'] + ".npz")
-    weights = dict(np.load(wpath)) if os.path.exists(wpath) else init_shader_weights(spec, seed=1234)
+    if os.path.exists(wpath):
+        weights = {k: v for k, v in np.load(wpath).items() if not k.startswith("__")}     # drop the optimiser state
+    else:
+        weights = init_shader_weights(spec, seed=1234)
     renderer = Renderer(spec, weights)
 
     files = sorted(glob.glob(os.path.join(cfg['model_path'], "*.binvox")))

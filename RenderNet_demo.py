@@ -52,6 +52,9 @@ def build_parser():
     parser.add_argument('--weights', type=str, default=None,
                         help='.npz of weights keyed by TF variable names (default: seeded random initialisation)')
     parser.add_argument('--batch', type=int, default=24, help='poses rendered per launch with --rotate')
+    parser.add_argument('--gif', type=str, default=None,
+                        help='with --rotate: also write the 72 frames as an animated GIF to this path (the reference ships '
+                             'such turntables under images/*.gif, README.md)')
     return parser
 
 
@@ -104,10 +107,17 @@ def main(argv=None):
     model_name = os.path.basename(voxel_path).split('.binvox')[0]
 
     if args.rotate:
+        # RenderNet_demo.py:130-137: 72 poses, 5 degrees apart, numbered 000..071 -- rendered `--batch` poses per launch
         az = list(np.arange(0.0, 360.0, 5.0))
+        paths = []
         for s in range(0, len(az), args.batch):
-            render(az[s:s + args.batch], args.elevation, args.radius, renderer, voxel, light_dir, args.render_dir, s,
-                   args.light_azimuth, args.light_elevation, model_name)
+            paths += render(az[s:s + args.batch], args.elevation, args.radius, renderer, voxel, light_dir, args.render_dir, s,
+                            args.light_azimuth, args.light_elevation, model_name)
+        if args.gif:
+            from PIL import Image
+            frames = [Image.open(p).convert("P", palette=Image.ADAPTIVE) for p in paths]
+            frames[0].save(args.gif, save_all=True, append_images=frames[1:], duration=60, loop=0)
+            print(args.gif)
     else:
         render([args.azimuth], args.elevation, args.radius, renderer, voxel, light_dir, args.render_dir, 0,
                args.light_azimuth, args.light_elevation, model_name)

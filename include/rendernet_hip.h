@@ -292,6 +292,14 @@ int rn_resample_affine_bwd(const float* vox, const float* m_inv, const float* do
                            int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout, void* stream);
 int rn_pose_to_affine_bwd(const float* pose, const float* dm, float* dpose, int B, int S, int N, void* stream);
 
+/* tf.nn.dropout(x, keep_prob) = x / keep_prob * floor(keep_prob + U[0,1))  (RenderNet_Shader.py:39,43,47,88,103,107-123
+ * with tools/layer_util.py:124-131; README default keep_prob 0.75 for training).  The uniforms come from a counter-based
+ * generator: element e uses word e%4 of Philox4x32-10(counter = (e/4, stream_id), key = seed), u = (word >> 8) * 2^-24.
+ * No mask is stored: calling it again with the same (seed, stream_id) on the output gradient IS the backward pass.
+ * y may alias x.  keep_prob in (0, 1]; pointers 16-byte aligned. */
+int rn_dropout(const float* x, float* y, size_t n, float keep_prob, unsigned long long seed,
+               unsigned long long stream_id, void* stream);
+
 /* Reconstruction loss and d(loss)/d(pred)  (RenderNet_Shader.py:159-163).
  *   mode 0: binary cross-entropy  sum_elems -(t*log(1e-6+p) + (1-t)*log(1e-6+1-p)) / divisor   (divisor = batch)
  *   mode 1: mean squared error    sum_elems (t-p)^2 / divisor                                  (divisor = #elements)

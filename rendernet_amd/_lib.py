@@ -57,6 +57,7 @@ SIGNATURES = {
     "rn_conv3d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
     "rn_resample_affine_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 9 + [_c_vp]),
     "rn_pose_to_affine_bwd": (_c_int, [_c_vp] * 3 + [_c_int] * 3 + [_c_vp]),
+    "rn_dropout": (_c_int, [_c_vp, _c_vp, ctypes.c_size_t, _c_f, ctypes.c_uint64, ctypes.c_uint64, _c_vp]),
     "rn_loss_fwd_bwd": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t, ctypes.c_double, _c_int, _c_vp]),
     "rn_adam_step": (_c_int, [_c_vp] * 4 + [ctypes.c_size_t] + [_c_f] * 5 + [_c_vp]),
     "rn_sgd_step": (_c_int, [_c_vp, _c_vp, ctypes.c_size_t, _c_f, _c_vp]),

@@ -96,11 +96,8 @@ static int launch_direct(const DirectArgs& a, hipStream_t st)
     const size_t lds = (size_t)a.Ktot * CO * sizeof(float);
     if (lds > 160 * 1024) return rn_set_error(RN_E_UNSUPPORTED, "conv_direct: filter %zu B exceeds LDS", lds);
     auto kern = conv_direct_kernel<CO>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const long long nb = (a.M + 255) / 256;
     if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_direct: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);

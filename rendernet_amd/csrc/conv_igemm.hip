@@ -406,11 +406,8 @@ static int launch_glds(IgemmArgs& a, hipStream_t st)
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * BK * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
     auto kern = conv_igemm_glds_kernel<BM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long long nb = (long long)a.mtiles * a.ntiles;
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: bad grid %lld", nb);
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
@@ -426,11 +423,8 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st)
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * (BK + 4) * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
     auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long long nb = (long long)a.mtiles * a.ntiles;
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: bad grid %lld", nb);
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * WM * WN), lds, st, a);

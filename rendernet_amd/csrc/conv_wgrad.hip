@@ -279,11 +279,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st)
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: bad grid %lld", nb);
     const size_t lds = (size_t)2 * BK * (BM + BN) * 4 + (size_t)WG_MAX_CHUNK * 4;
     auto kern = conv_wgrad_kernel<BM, BN, BK, WM, WN, WK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
     return rn_check_launch("conv_wgrad");
 }
@@ -462,12 +459,9 @@ static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, 
     a.nsplit = (a.nitems + a.ipw - 1) / a.ipw;
     const long long nb = (long long)((a.nsplit + 7) / 8) * 72;
     const size_t lds = (size_t)2 * (136 * 32 + 128 * 32) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(conv_wgrad_k3d32_kernel, dim3((unsigned)nb), dim3(256), lds, st, a);
     return rn_check_launch("conv_wgrad_k3d32");
 }
@@ -513,7 +507,7 @@ int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const
         return launch_wgrad_k3d32(A, G, dw, B, I[0], I[1], I[2], a.a_bytes, a.g_bytes, st);
     if (Ca % 4 != 0 || Cg % 4 != 0 || Ca < 8) {
         // narrow path: one thread per (tap, ca)
-        if ((long long)taps * Ca > 1024 || Cg > 16)
+        if ((long long)taps * Ca > 1024 || Cg > 32)
             return rn_set_error(RN_E_UNSUPPORTED, "conv_wgrad: Ca=%d Cg=%d taps=%d has no kernel", Ca, Cg, taps);
         long long nblk = 4096;
         long long kc = (M + nblk - 1) / nblk;
@@ -522,7 +516,8 @@ int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const
         a.kchunk = (int)kc; a.nsplit = (int)nblk; a.mtiles = a.ntiles = 1;
         const int nt = (taps * Ca + 63) / 64 * 64;
         if (Cg <= 8) hipLaunchKernelGGL(conv_wgrad_small_kernel<8>, dim3((unsigned)nblk), dim3(nt), 0, st, a);
-        else hipLaunchKernelGGL(conv_wgrad_small_kernel<16>, dim3((unsigned)nblk), dim3(nt), 0, st, a);
+        else if (Cg <= 16) hipLaunchKernelGGL(conv_wgrad_small_kernel<16>, dim3((unsigned)nblk), dim3(nt), 0, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_small_kernel<32>, dim3((unsigned)nblk), dim3(nt), 0, st, a);   // e_conv11 of the stress net (w10 = 32)
         return rn_check_launch("conv_wgrad_small");
     }
     const bool wide_m = Ca > 32, wide_n = Cg > 32;

@@ -289,6 +289,58 @@ extern "C" int rn_sgd_step(float* param, const float* grad, size_t n, float lr, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// tf.nn.dropout (RenderNet_Shader.py:39,43,47,88,103,107-123; tools/layer_util.py:124-131):
+//     y = x / keep_prob * floor(keep_prob + u),   u ~ U[0,1)
+// The uniform comes from a counter-based generator (Philox4x32-10, Salmon et al. 2011): element e uses word e%4 of
+// philox(counter = (e/4, stream), key = seed), u = (word >> 8) * 2^-24.  Nothing is stored: the backward pass applies
+// the SAME call (same seed and stream) to the gradient and so regenerates the forward mask bit for bit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+        c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k.y, (unsigned)p0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float keep_prob, float inv_keep,
+                               unsigned long long seed, unsigned long long stream)
+{
+    const size_t nq = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), (unsigned)stream, (unsigned)(stream >> 32)),
+                                      make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+        if (q * 4 + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(x + q * 4);
+            float* e = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = e[i] * inv_keep * floorf(keep_prob + (float)(w[i] >> 8) * 5.9604644775390625e-08f);
+            *reinterpret_cast<float4*>(y + q * 4) = v;
+        } else {
+            for (int i = 0; i < 4 && q * 4 + i < n; ++i)
+                y[q * 4 + i] = x[q * 4 + i] * inv_keep * floorf(keep_prob + (float)(w[i] >> 8) * 5.9604644775390625e-08f);
+        }
+    }
+}
+
+extern "C" int rn_dropout(const float* x, float* y, size_t n, float keep_prob, unsigned long long seed,
+                          unsigned long long stream_id, void* stream)
+{
+    if (!x || !y || n < 1) return rn_set_error(RN_E_INVALID, "rn_dropout: bad arguments");
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return rn_set_error(RN_E_INVALID, "rn_dropout: keep_prob %g not in (0, 1]", keep_prob);
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return rn_set_error(RN_E_INVALID, "rn_dropout: pointers must be 16-byte aligned");
+    size_t nb = ((n + 3) / 4 + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob, 1.0f / keep_prob,
+                       seed, stream_id);
+    return rn_check_launch("rn_dropout");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Input gradient of a forward conv by direct gather, for the strided / channel-starved stem
 // (e_conv2: 3^3, stride (1,1,2), 8 -> 16; RenderNet_Shader.py:40-43):
 //     dx[b,i,c] = sum_{t, n : (i + P - t) % S == 0, o = (i+P-t)/S in range} dz[b,o,n] * w[t][c][n]

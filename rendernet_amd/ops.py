@@ -440,6 +440,50 @@ def fully_connected(x, w, bias=None, alpha=None):
     return _FC.apply(x.contiguous().float(), w.contiguous().float(), bias, alpha, anchor)
 
 
+class _Dropout(torch.autograd.Function):
+    """tf.nn.dropout through rn_dropout: the mask is a pure function of (seed, stream id, element index), so the
+    backward regenerates it by running the same call on the gradient -- nothing is saved."""
+
+    @staticmethod
+    def forward(ctx, x, keep_prob, seed, stream_id):
+        _chk_dev(x)
+        y = torch.empty_like(x)
+        L.check(L.lib().rn_dropout(L.ptr(x), L.ptr(y), x.numel(), keep_prob, seed, stream_id, L.stream_ptr()), "rn_dropout")
+        ctx.cfg = (keep_prob, seed, stream_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep_prob, seed, stream_id = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.lib().rn_dropout(L.ptr(dy), L.ptr(dx), dy.numel(), keep_prob, seed, stream_id, L.stream_ptr()), "rn_dropout (bwd)")
+        return dx, None, None, None
+
+
+_DROPOUT_SEED = [0x5EED0FD50, 0]          # process-wide (seed, next stream id): every call draws a fresh stream
+
+
+def seed_dropout(seed):
+    """Re-seed the dropout generator (and restart its stream counter): two runs with the same seed and the same sequence
+    of dropout calls draw the same masks."""
+    _DROPOUT_SEED[0], _DROPOUT_SEED[1] = int(seed) & (2 ** 64 - 1), 0
+
+
+def dropout(x, keep_prob, seed=None, stream_id=None):
+    """tf.nn.dropout(x, keep_prob) (RenderNet_Shader.py:39 ...): x / keep_prob * floor(keep_prob + U[0,1)); the identity
+    at keep_prob >= 1.  Differentiable.  (seed, stream_id) pin the mask; by default every call takes the next stream of
+    the process-wide generator (see seed_dropout)."""
+    if keep_prob >= 1.0:
+        return x
+    if seed is None:
+        seed = _DROPOUT_SEED[0]
+    if stream_id is None:
+        stream_id = _DROPOUT_SEED[1]
+        _DROPOUT_SEED[1] += 1
+    return _Dropout.apply(x.contiguous().float(), float(keep_prob), int(seed), int(stream_id))
+
+
 def prelu(x, alpha):
     """Stand-alone PReLU over the last dim (tools/layer_util.py:27-45)."""
     x = x.contiguous().float()

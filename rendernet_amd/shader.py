@@ -143,12 +143,11 @@ def init_shader_weights(spec, seed=1234, perturb=False):
     return w
 
 
-def _dropout(x, kp, gen=None):
-    """tf.nn.dropout(x, kp) = x/kp * floor(kp + U[0,1)); identity at kp == 1 (inference)."""
-    if kp >= 1.0:
-        return x
-    mask = torch.floor(kp + torch.rand(x.shape, device=x.device, generator=gen))
-    return x * mask / kp
+def _dropout(x, kp):
+    """tf.nn.dropout(x, kp) = x/kp * floor(kp + U[0,1)); identity at kp == 1 (inference).  One HIP launch
+    (rn_dropout, counter-based mask regenerated in the backward pass)."""
+    from . import ops
+    return ops.dropout(x, kp)
 
 
 def RenderNet(models_in, is_training, prob=0.75, reuse=False, spec=None, taps=None):

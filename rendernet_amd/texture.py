@@ -178,12 +178,15 @@ def decoder_texture(z_in, spec=None, taps=None):
     return conv2
 
 
-def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None):
-    """RenderNet_Texture_Face_Normal.py:48-147 (inference: dropout is the identity).  models_in
-    [B,H,W,D,5]; returns (image [B,4H,4W,3], normal [B,4H,4W,3])."""
+def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None, is_training=False):
+    """RenderNet_Texture_Face_Normal.py:48-147.  models_in [B,H,W,D,5]; returns (image [B,4H,4W,3], normal
+    [B,4H,4W,3]).  `is_training` stands for the reference's graph-level placeholder (:161): with it, tf.nn.dropout
+    runs after e_conv1..3, e_conv5 and the first four layers of each head (:55-65, :101, :116-125, :133-142)."""
+    from .shader import _dropout
     s = spec or TextureSpec()
     st = V.get_default_store()
     xav = xavier_initializer
+    kp = LU.keep_prob(prob, is_training)
 
     def tap(name, t):
         if taps is not None:
@@ -197,6 +200,7 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None):
             with st.variable_scope(name):
                 net = LU.conv3d(net, co, kernel_size=[k, k, k], stride=stride, reuse=reuse, pad="SAME", scope=name,
                                 weight_initializer_type=xav(), activation_alpha=a)
+                net = _dropout(net, kp)
             tap("enc" + name[-1], net)
         enc3 = net
         for i in range(1, s.n_res1 + 1):
@@ -217,6 +221,7 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None):
         with st.variable_scope('e_conv5'):
             enc5 = LU.conv2d(enc4_skip, s.w5, kernel_size=[4, 4], stride=[1, 1], scope='e_conv5',
                              weight_initializer_type=xav(), activation_alpha=a5)
+            enc5 = _dropout(enc5, kp)
         tap("enc5", enc5)
         net = enc5
         for i in range(1, s.n_res3 + 1):
@@ -234,11 +239,13 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None):
                 with st.variable_scope(sc[0][0]):
                     net = LU.conv2d(enc5_skip, s.w6, kernel_size=[4, 4], stride=[1, 1], scope=sc[0][1],
                                     weight_initializer_type=xav(), activation_alpha=a)
+                    net = _dropout(net, kp)
                 for (vs, cs), co in zip(sc[1:4], (s.w7, s.w8, s.w9)):
                     a = _alpha(st, vs, co)
                     with st.variable_scope(vs):
                         net = LU.conv2d_transpose(net, co, [4, 4], stride=[2, 2], scope=cs, weight_initializer_type=xav(),
                                                   activation_alpha=a)
+                        net = _dropout(net, kp)
                 vs, cs = sc[4]
                 with st.variable_scope(vs):
                     net = LU.conv2d_transpose(net, 3, [4, 4], stride=[1, 1], scope=cs, weight_initializer_type=xav(),

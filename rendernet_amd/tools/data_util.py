@@ -96,3 +96,54 @@ def data_loader(cfg, img_path, model_path, validation_mode=False, flatten=False,
             yield ims, mods, params, names
         else:
             yield ims[:counter], mods[:counter], params[:counter], names
+
+
+def _read_texture_code(texture_path, ident):
+    """`beta<ident>.mat` (MATLAB file with the 199 Basel-face texture coefficients under 'beta',
+    tools/data_util.py:184-186); a plain `beta<ident>.npy` is accepted as well."""
+    mat = os.path.join(texture_path, "beta%s.mat" % ident)
+    if os.path.exists(mat):
+        import scipy.io
+        return np.reshape(scipy.io.loadmat(mat)['beta'].astype(np.float32), 199)
+    return np.reshape(np.load(os.path.join(texture_path, "beta%s.npy" % ident)).astype(np.float32), 199)
+
+
+def data_loader_image_texture_normal_face(cfg, img_path, model_path, texture_path, normal_path, validation_mode=False,
+                                          img_res=256, add_noise=True):
+    """tools/data_util.py:159-233: (images, normals [n,res,res,3] in 0..255, voxels [n,64,64,64,1], texture codes
+    [n,199], poses [n,3], names) chunks for the face renderer.  Image names look like `<model>ply<id>_..._p<az>_t<el>_r<rad>`;
+    the model file is `<first field>.binvox`, the texture code `beta<id>.mat`, the normal map `<name>.png`."""
+    from PIL import Image
+    chunk = cfg['batch_size'] if validation_mode else cfg['batch_size'] * cfg['batches_chunk']
+
+    def fresh():
+        return (np.zeros((chunk, img_res, img_res, 3), np.float32), np.zeros((chunk, img_res, img_res, 3), np.float32),
+                np.zeros((chunk, 64, 64, 64, 1), np.float32), np.zeros((chunk, 199), np.float32), np.zeros((chunk, 3), np.float32))
+
+    ims, nrms, mods, texs, params = fresh()
+    names, counter = [], 0
+    for item in utils.NpyTarReader(img_path):
+        if not isinstance(item, tuple) or item[0] is None or item[1] is None:
+            continue
+        img, name = item
+        idx = counter
+        ims[idx] = np.reshape(img.astype(np.float32)[:, :, :3], (img_res, img_res, 3))
+        if add_noise:
+            ims[idx] += np.random.uniform(0.0, 1.0, size=ims[idx].shape)
+        first = name.split('_')[0]
+        texs[idx] = _read_texture_code(texture_path, first.split('ly')[1])
+        nrms[idx] = np.asarray(Image.open(os.path.join(normal_path, name + ".png")), np.float32)[:, :, :3]
+        params[idx] = extract_param_from_names(name)[0]
+        with open(os.path.join(model_path, first + ".binvox"), 'rb') as f:
+            mods[idx] = np.reshape(binvox_rw.read_as_3d_array(f).data.astype(np.float32), (64, 64, 64, 1))
+        names.append(name)
+        counter += 1
+        if counter == chunk:
+            yield ims, nrms, mods, texs, params, names
+            (ims, nrms, mods, texs, params), names, counter = fresh(), [], 0
+    if counter > 0:
+        if counter % cfg['batch_size'] != 0:
+            (ims, nrms, mods, texs, params), names = _pad_tail([ims, nrms, mods, texs, params], names, counter, cfg['batch_size'])
+            yield ims, nrms, mods, texs, params, names
+        else:
+            yield ims[:counter], nrms[:counter], mods[:counter], texs[:counter], params[:counter], names

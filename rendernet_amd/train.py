@@ -165,7 +165,43 @@ class _TrainerBase:
         return self.loss_buf[0].clone()
 
     def state_dict(self):
+        """The weights by TF variable name (what `sess_saver.save` keeps for inference)."""
         return self.store.state_dict()
+
+    # -- checkpoint / resume ------------------------------------------------------------------
+    # The reference's tf.train.Supervisor saves the whole graph state -- variables, the Adam slots `m` / `v` and
+    # global_step (RenderNet_Shader.py:171-185, save_model_secs = checkpoint_secs) -- and restores it on restart, so the
+    # learning-rate staircase, Adam's bias correction and the patch-size schedule continue where they stopped.
+    def checkpoint(self, epoch=0):
+        """Everything a restart needs: weights + '__adam_m__' / '__adam_v__' (the flat moment buffers, layout = creation
+        order of the variables, each 16-byte aligned) + '__global_step__' + '__epoch__'."""
+        sd = self.store.state_dict()
+        sd["__adam_m__"] = self.m.cpu().numpy()
+        sd["__adam_v__"] = self.v.cpu().numpy()
+        sd["__global_step__"] = np.int64(self.global_step)
+        sd["__epoch__"] = np.int64(epoch)
+        return sd
+
+    def save_checkpoint(self, path, epoch=0):
+        """Atomic: written next to `path` and renamed over it, so a kill mid-write leaves the previous file intact."""
+        import os
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **self.checkpoint(epoch))
+        os.replace(tmp, path)
+
+    def load_checkpoint(self, sd):
+        """Restore weights and, when present, the optimiser state; returns the epoch to resume at."""
+        extra = {k: sd[k] for k in ("__adam_m__", "__adam_v__", "__global_step__", "__epoch__") if k in sd}
+        with torch.no_grad():
+            for n in self.names:
+                if n in sd:
+                    self.store.vars[n].copy_(torch.as_tensor(np.asarray(sd[n], np.float32)).reshape(self.store.vars[n].shape))
+            if "__adam_m__" in extra and extra["__adam_m__"].size == self.m.numel():
+                self.m.copy_(torch.as_tensor(np.asarray(extra["__adam_m__"], np.float32)))
+                self.v.copy_(torch.as_tensor(np.asarray(extra["__adam_v__"], np.float32)))
+                self.global_step = int(extra.get("__global_step__", 0))
+        self.store.repack_all()
+        return int(extra.get("__epoch__", 0))
 
 
 class Trainer(_TrainerBase):
@@ -177,9 +213,10 @@ class Trainer(_TrainerBase):
         self.mse = self.spec.out_ch != 1                      # RenderNet_Shader.py:159-163
 
     # -- pieces (also used one by one by the parity tests) ----------------------------------
-    def forward(self, voxels, poses, patch_size=None, start_point=None, taps=None, net_in=None):
-        """Training-mode forward: returns (prediction [b,4p,4p,ch], window).  `net_in` [b,p,p,N,C], when
-        given, is an already resampled + cropped grid (voxels/poses are then ignored)."""
+    def forward(self, voxels, poses, patch_size=None, start_point=None, taps=None, net_in=None, is_training=True):
+        """Forward through the trainer's graph: returns (prediction [b,4p,4p,ch], window).  `net_in` [b,p,p,N,C], when
+        given, is an already resampled + cropped grid (voxels/poses are then ignored).  is_training=False is the
+        reference's validation feed (RenderNet_Shader.py:279: dropout off)."""
         s = self.spec
         p = int(patch_size) if patch_size is not None else s.new_size
         if net_in is not None:
@@ -200,7 +237,7 @@ class Trainer(_TrainerBase):
                     net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
                 if taps is not None:
                     taps["net_in"] = net_in
-                pred = RenderNet(net_in, True, prob=self.keep_prob, spec=s, taps=taps)
+                pred = RenderNet(net_in, bool(is_training), prob=self.keep_prob, spec=s, taps=taps)
         finally:
             V._default = old
         return pred, window
@@ -235,7 +272,7 @@ class TextureTrainer(_TrainerBase):
         spec = (spec or TextureSpec()).check()
         super().__init__(spec, weights if weights is not None else init_texture_weights(spec, seed), device, seed, **kw)
 
-    def forward(self, voxels, textures, poses, patch_size=None, start_point=None, taps=None):
+    def forward(self, voxels, textures, poses, patch_size=None, start_point=None, taps=None, is_training=True):
         from .texture import decoder_texture, RenderNetTexture
         s = self.spec
         vox = torch.as_tensor(voxels, dtype=torch.float32).to(self.device)
@@ -255,7 +292,7 @@ class TextureTrainer(_TrainerBase):
                 net_in = torch.cat([geo, tex_rot], dim=4)
                 if taps is not None:
                     taps["net_in"] = net_in
-                img, nrm = RenderNetTexture(net_in, prob=self.keep_prob, spec=s, taps=taps)
+                img, nrm = RenderNetTexture(net_in, prob=self.keep_prob, spec=s, taps=taps, is_training=bool(is_training))
         finally:
             V._default = old
         return img, nrm, window

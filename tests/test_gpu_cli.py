@@ -43,7 +43,65 @@ def test_shader_script_trains_and_checkpoints(tmp_path, capsys):
     assert all(np.isfinite(losses)) and losses[0] > 0
     ck = np.load(os.path.join(cfg["sample_save"], "3d2d_renderer.npz"))
     assert "encoder/res2_4/con1_3X3/weights" in ck.files and ck["encoder/e_conv7/e_conv7/weights"].shape == (4, 4, 128, 256)
-    assert len(ck.files) == 166                                   # every variable of the Phong-shader graph
+    names = [k for k in ck.files if not k.startswith("__")]
+    assert len(names) == 166                                      # every variable of the Phong-shader graph
+    # the checkpoint carries the optimiser state (Adam moments, global_step, epoch) like the reference's Supervisor
+    assert int(ck["__global_step__"]) == 2 and int(ck["__epoch__"]) == 1 and ck["__adam_m__"].shape == ck["__adam_v__"].shape
+    assert float(np.abs(ck["__adam_v__"]).max()) > 0
+    assert not os.path.exists(os.path.join(cfg["sample_save"], "3d2d_renderer.npz.tmp.npz"))
+    # a restart resumes: epoch counter past max_epochs -> no further steps, weights untouched
+    RenderNet_Shader.main([cfgp, "--train", "--max-steps", "5"])
+    assert "Step" not in capsys.readouterr().out
+    # and a world size that does not divide the batch is refused up front (an empty shard would dead-lock the all-reduces)
+    os.environ["WORLD_SIZE"], os.environ["RANK"] = "3", "0"
+    try:
+        with pytest.raises(SystemExit, match="not a multiple"):
+            RenderNet_Shader.main([cfgp, "--train"])
+    finally:
+        del os.environ["WORLD_SIZE"], os.environ["RANK"]
+
+
+def test_texture_script_trains_checkpoints_and_renders(tmp_path, capsys):
+    """`python RenderNet_Texture_Face_Normal.py <config.json> [--train]` on a four-image synthetic face set: the loop of
+    the reference script (:196-334) with its file naming, the resumable checkpoint, then the render mode."""
+    from PIL import Image
+    import RenderNet_Texture_Face_Normal as script
+    from rendernet_amd.tools import utils
+    models, tex, nrm = tmp_path / "models", tmp_path / "beta", tmp_path / "normals"
+    for d in (models, tex, nrm):
+        d.mkdir()
+    rng = np.random.default_rng(1)
+    for ident, src in (("007", "suzanne"), ("012", "teapot")):
+        shutil.copy(os.path.join(ROOT, "binvox", src + ".binvox"), models / ("faceply%s.binvox" % ident))
+        np.save(tex / ("beta%s.npy" % ident), rng.standard_normal(199).astype(np.float32))
+    tarp = str(tmp_path / "train.tar")
+    w = utils.NpyTarWriter(tarp)
+    for name in ("faceply007_p250_t30_r3.3", "faceply012_p10_t100_r3.3", "faceply007_p90_t60_r3.3", "faceply012_p300_t45_r3.3"):
+        buf = io.BytesIO()
+        Image.fromarray((rng.random((512, 512, 3)) * 255).astype(np.uint8)).save(buf, format="PNG")
+        w.add_bytes(buf.getvalue(), name + ".png")
+        Image.fromarray((rng.random((512, 512, 3)) * 255).astype(np.uint8)).save(nrm / (name + ".png"))
+    w.close()
+    cfg = {"image_path": tarp, "image_path_valid": tarp, "normal_path": str(nrm), "texture_path": str(tex),
+           "model_path": str(models), "gpu": 0, "batch_size": 2, "max_epochs": 1, "batches_chunk": 1, "threshold": 0.1,
+           "e_eta": 1e-5, "keep_prob": 0.75, "decay_steps": 100000, "trained_model_name": "3d2d_renderer",
+           "sample_save": str(tmp_path / "out"), "checkpoint_secs": 7200}
+    cfgp = str(tmp_path / "config.json")
+    json.dump(cfg, open(cfgp, "w"))
+    script.main([cfgp, "--train", "--max-steps", "2"])
+    out = capsys.readouterr().out
+    losses = [float(l.split("Loss")[1]) for l in out.splitlines() if l.startswith("Step")]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[0] > 0
+    files = set(os.listdir(cfg["sample_save"]))
+    assert {"config.json", "3d2d_renderer.npz", "L1 All.txt.npz"} <= files
+    assert sum(f.startswith("VALID_faceply") and "_pred_normal_0" in f for f in files) == 1      # :322-327 naming
+    ck = np.load(os.path.join(cfg["sample_save"], "3d2d_renderer.npz"))
+    assert int(ck["__global_step__"]) == 2 and any(k.startswith("texture_encoder/") for k in ck.files)
+    script.main([cfgp])                                            # render mode: one image + one normal map per model
+    files = set(os.listdir(cfg["sample_save"]))
+    assert {"VALID_faceply007_pred.png", "VALID_faceply007_pred_normal.png", "VALID_faceply012_pred.png"} <= files
+    img = np.asarray(Image.open(os.path.join(cfg["sample_save"], "VALID_faceply007_pred.png")))
+    assert img.shape == (512, 512, 3)
 
 
 def test_demo_cli_renders_and_names_files_like_the_reference(tmp_path):
@@ -101,3 +159,28 @@ def test_reconstruct_script_runs_and_writes_the_reference_outputs(tmp_path, caps
     with open(os.path.join(cfg["sample_save"], vox[0]), "rb") as fh:
         assert binvox_rw.read_as_3d_array(fh).data.shape == (64, 64, 64)
     assert np.load(os.path.join(cfg["sample_save"], "2_loss_.txt.npz"))["arr_0"].shape == (5,)
+
+
+def test_demo_rotate_renders_72_numbered_frames_equal_to_single_pose_runs(tmp_path):
+    """`RenderNet_demo.py --rotate True` (RenderNet_demo.py:130-137): 72 files numbered 000..071, azimuth 0..355 in 5
+    degree steps, rendered in batches -- pixel-identical to 72 runs of the single-pose path -- plus the optional GIF."""
+    from PIL import Image
+    import RenderNet_demo
+    vox = os.path.join(ROOT, "binvox", "teapot.binvox")
+    rot = tmp_path / "rot"
+    gif = str(tmp_path / "turn.gif")
+    RenderNet_demo.main(["--voxel_path", vox, "--render_dir", str(rot), "--rotate", "True", "--elevation", "40", "--radius", "3.0",
+                         "--batch", "24", "--gif", gif])
+    files = sorted(os.listdir(rot))
+    assert len(files) == 72
+    for i, f in enumerate(files):
+        assert f == "%03d_teapot_pose_%f_%f_%f_light_%f_%f.png" % (i, 5.0 * i, 40.0, 3.0, 250.0, 60.0)
+    with Image.open(gif) as g:
+        assert g.n_frames == 72 and g.size == (512, 512)
+    for i in (0, 23, 24, 50, 71):                       # both sides of a batch boundary, first and last
+        one = tmp_path / ("one%d" % i)
+        RenderNet_demo.main(["--voxel_path", vox, "--render_dir", str(one), "--azimuth", str(5.0 * i), "--elevation", "40",
+                             "--radius", "3.0"])
+        a = np.asarray(Image.open(rot / files[i]))
+        b = np.asarray(Image.open(one / os.listdir(one)[0]))
+        assert np.array_equal(a, b), "frame %d of the rotation differs from the single-pose render" % i

@@ -1,0 +1,90 @@
+"""tf.nn.dropout on the HIP path (rn_dropout) -- the op behind RenderNet_Shader.py:39,43,47,88,103,107-123 and
+RenderNet_Texture_Face_Normal.py:55-142 (`keep_prob` of tools/layer_util.py:124-131; README default 0.75).  -m gpu.
+TensorFlow's random stream cannot be reproduced; what is pinned: the formula x/kp*floor(kp+u) bit for bit against the
+NumPy Philox restatement (oracle/dropout.py, itself pinned to the published Philox known answers), its statistics,
+and that the backward pass regenerates the forward mask."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dropout as OD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,kp", [(4096 * 7 + 3, 0.75), (100003, 0.5), (16, 0.9)])
+def test_dropout_matches_the_oracle_bit_for_bit(n, kp):
+    from rendernet_amd import ops
+    x = torch.randn(n, device="cuda")
+    y = ops.dropout(x, kp, seed=0x1234567890ABCDEF, stream_id=5 + (1 << 33))
+    want = OD.dropout(x.cpu().numpy(), kp, 0x1234567890ABCDEF, 5 + (1 << 33))
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_dropout_statistics_and_backward_mask():
+    from rendernet_amd import ops
+    kp = 0.75
+    x = torch.rand((8, 64, 64, 32), device="cuda") + 0.5
+    x.requires_grad_(True)
+    ops.seed_dropout(99)
+    y = ops.dropout(x, kp)
+    kept = (y != 0)
+    rate = float(kept.float().mean())
+    assert abs(rate - kp) < 4 * np.sqrt(kp * (1 - kp) / x.numel()) + 1e-4            # keep rate = keep_prob
+    assert torch.allclose(y[kept], (x / kp)[kept])                                      # survivors scaled by 1/kp
+    assert abs(float(y.mean()) / float(x.mean()) - 1.0) < 5e-3                          # E[y] = x
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad != 0, kept) and torch.allclose(x.grad[kept], (g / kp)[kept])   # same mask forward / backward
+    z = ops.dropout(x.detach(), kp)                                                     # next call: a fresh stream
+    assert float(((z != 0) != kept).float().mean()) > 0.2
+    ops.seed_dropout(99)
+    assert torch.equal(ops.dropout(x.detach(), kp), y.detach())                         # re-seeding replays the masks
+    assert ops.dropout(x, 1.0) is x                                                     # keep_prob 1: identity (inference)
+
+
+def test_training_step_with_dropout_runs_and_eval_is_deterministic():
+    """keep_prob < 1 through the whole training graph (nine dropout sites, RenderNet_Shader.py:39-123): finite loss and
+    gradients; is_training=False (the reference's validation feed) switches every site off."""
+    from rendernet_amd.shader import tiny_spec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    spec = tiny_spec(1)
+    tr = Trainer(spec, init_shader_weights(spec, seed=3, perturb=True), keep_prob=0.75)
+    rng = np.random.default_rng(0)
+    vox = (rng.random((2, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    poses = np.array([[1.0, 0.6, 1.0], [4.0, 0.4, 0.9]], np.float32)
+    tgt = rng.random((2, 128, 128, 1)).astype(np.float32)
+    a, _ = tr.forward(vox, poses, is_training=False)
+    b, _ = tr.forward(vox, poses, is_training=False)
+    assert torch.equal(a, b)
+    c, _ = tr.forward(vox, poses, is_training=True)
+    d, _ = tr.forward(vox, poses, is_training=True)
+    assert not torch.equal(c, d)
+    loss = tr.step(vox, poses, tgt, patch_size=16, start_point=(3, 5))
+    assert np.isfinite(float(loss.item())) and bool(torch.isfinite(tr.grad).all()) and float(tr.grad.abs().max()) > 0
+
+
+def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+    """Trainer.save_checkpoint / load_checkpoint carry weights, Adam moments and global_step: two steps + restart + one
+    step equals three uninterrupted steps."""
+    from rendernet_amd.shader import tiny_spec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    spec = tiny_spec(1)
+    w = init_shader_weights(spec, seed=3, perturb=True)
+    rng = np.random.default_rng(0)
+    vox = (rng.random((2, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    poses = np.array([[1.0, 0.6, 1.0], [4.0, 0.4, 0.9]], np.float32)
+    tgt = rng.random((2, 128, 128, 1)).astype(np.float32)
+    kw = dict(e_eta=1e-3, decay_steps=2)
+    ref = Trainer(spec, w, **kw)
+    for i in range(3):
+        ref.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
+    a = Trainer(spec, w, **kw)
+    for i in range(2):
+        a.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
+    path = str(tmp_path / "ck.npz")
+    a.save_checkpoint(path, epoch=7)
+    b = Trainer(spec, init_shader_weights(spec, seed=99), **kw)
+    assert b.load_checkpoint(dict(np.load(path))) == 7 and b.global_step == 2
+    b.step(vox, poses, tgt, patch_size=16, start_point=(2, 4))
+    assert torch.equal(b.param, ref.param) and torch.equal(b.m, ref.m) and torch.equal(b.v, ref.v)

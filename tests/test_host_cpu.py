@@ -262,3 +262,56 @@ def test_create_tar_feeds_the_tar_reader(tmp_path):
     assert set(got) == set(imgs)
     for n in imgs:
         assert got[n].dtype == np.float32 and np.array_equal(got[n], imgs[n].astype(np.float32))
+
+
+def test_philox_known_answers_and_dropout_oracle_statistics():
+    """oracle/dropout.py: Philox4x32-10 against the known-answer vectors published with Random123 (kat_vectors:
+    counter / key all zero, all ones, and the digits of pi), then tf.nn.dropout's formula on its uniforms."""
+    from oracle import dropout as OD
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = OD.philox4x32_10([ctr[0]], [ctr[1]], [ctr[2]], [ctr[3]], key[0], key[1])
+        assert tuple(int(v[0]) for v in got) == want
+    u = OD.uniforms(200003, seed=7, stream=3)
+    assert u.dtype == np.float32 and 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    x = np.ones(200003, np.float32)
+    y = OD.dropout(x, 0.75, 7, 3)
+    assert set(np.unique(y)) == {np.float32(0.0), np.float32(1.0) / np.float32(0.75)}
+    assert abs((y != 0).mean() - 0.75) < 5e-3 and abs(y.mean() - 1.0) < 5e-3
+    assert np.array_equal(OD.dropout(x, 1.0, 7, 3), x)
+
+
+def test_texture_face_loader_parses_names_and_pads(tmp_path):
+    """data_loader_image_texture_normal_face (tools/data_util.py:159-233): pose / model / texture ids from the member
+    names, normal maps from PNGs, a short tail repeated up to one batch."""
+    import io
+    import shutil
+    from PIL import Image
+    from rendernet_amd.tools import utils
+    from rendernet_amd.tools.data_util import data_loader_image_texture_normal_face
+    models, tex, nrm = tmp_path / "m", tmp_path / "t", tmp_path / "n"
+    for d in (models, tex, nrm):
+        d.mkdir()
+    shutil.copy(os.path.join(BINVOX_DIR, "chair.binvox"), models / "faceply003.binvox")
+    code = np.arange(199, dtype=np.float32)
+    np.save(tex / "beta003.npy", code)
+    tarp = str(tmp_path / "faces.tar")
+    w = utils.NpyTarWriter(tarp)
+    names = ["faceply003_p250_t30_r3.3", "faceply003_p10_t100_r2.5", "faceply003_p90_t60_r4.0"]
+    rng = np.random.default_rng(0)
+    for nme in names:
+        buf = io.BytesIO()
+        Image.fromarray((rng.random((32, 32, 3)) * 255).astype(np.uint8)).save(buf, format="PNG")
+        w.add_bytes(buf.getvalue(), nme + ".png")
+        Image.fromarray(np.full((32, 32, 3), 77, np.uint8)).save(nrm / (nme + ".png"))
+    w.close()
+    cfg = {"batch_size": 2, "batches_chunk": 1}
+    chunks = list(data_loader_image_texture_normal_face(cfg, tarp, str(models), str(tex), str(nrm), img_res=32, add_noise=False))
+    assert [len(c[5]) for c in chunks] == [2, 2]                               # 3 samples -> a full batch + a padded tail
+    ims, nrms, mods, texs, params, nm = chunks[0]
+    assert ims.shape == (2, 32, 32, 3) and nrms.shape == (2, 32, 32, 3) and mods.shape == (2, 64, 64, 64, 1)
+    assert np.array_equal(texs[0], code) and float(nrms.max()) == 77.0 and mods.sum() > 0
+    assert np.allclose(params[0], [250 * np.pi / 180, 60 * np.pi / 180, 1.0]) and np.allclose(params[1][2], 3.3 / 2.5)
+    assert list(chunks[1][5]) == [names[2], names[2]]
