@@ -3,6 +3,8 @@ RenderNet_Texture_Face_Normal.py:55-142 (`keep_prob` of tools/layer_util.py:124-
 TensorFlow's random stream cannot be reproduced; what is pinned: the formula x/kp*floor(kp+u) bit for bit against the
 NumPy Philox restatement (oracle/dropout.py, itself pinned to the published Philox known answers), its statistics,
 and that the backward pass regenerates the forward mask."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -32,7 +34,7 @@ def test_dropout_statistics_and_backward_mask():
     rate = float(kept.float().mean())
     assert abs(rate - kp) < 4 * np.sqrt(kp * (1 - kp) / x.numel()) + 1e-4            # keep rate = keep_prob
     assert torch.allclose(y[kept], (x / kp)[kept])                                      # survivors scaled by 1/kp
-    assert abs(float(y.mean()) / float(x.mean()) - 1.0) < 5e-3                          # E[y] = x
+    assert abs(float(y.detach().mean()) / float(x.detach().mean()) - 1.0) < 5e-3                          # E[y] = x
     g = torch.randn_like(y)
     y.backward(g)
     assert torch.equal(x.grad != 0, kept) and torch.allclose(x.grad[kept], (g / kp)[kept])   # same mask forward / backward
@@ -64,9 +66,11 @@ def test_training_step_with_dropout_runs_and_eval_is_deterministic():
     assert np.isfinite(float(loss.item())) and bool(torch.isfinite(tr.grad).all()) and float(tr.grad.abs().max()) > 0
 
 
-def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     """Trainer.save_checkpoint / load_checkpoint carry weights, Adam moments and global_step: two steps + restart + one
-    step equals three uninterrupted steps."""
+    step lands where three uninterrupted steps land (to within the run-to-run spread of the fp32-atomic filter
+    gradients), while a weights-only restart -- Adam at t = 1 with zero moments, the learning-rate staircase back at step
+    0 -- does not."""
     from rendernet_amd.shader import tiny_spec, init_shader_weights
     from rendernet_amd.train import Trainer
     spec = tiny_spec(1)
@@ -76,15 +80,26 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     poses = np.array([[1.0, 0.6, 1.0], [4.0, 0.4, 0.9]], np.float32)
     tgt = rng.random((2, 128, 128, 1)).astype(np.float32)
     kw = dict(e_eta=1e-3, decay_steps=2)
-    ref = Trainer(spec, w, **kw)
-    for i in range(3):
-        ref.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
-    a = Trainer(spec, w, **kw)
-    for i in range(2):
-        a.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
+
+    def run(tr, steps):
+        for i in steps:
+            tr.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
+        return tr
+
+    ref = run(Trainer(spec, w, **kw), range(3))
+    ref2 = run(Trainer(spec, w, **kw), range(3))
+    spread = float((ref2.param - ref.param).abs().max())            # wgrad accumulates with atomics: order varies
+    a = run(Trainer(spec, w, **kw), range(2))
     path = str(tmp_path / "ck.npz")
     a.save_checkpoint(path, epoch=7)
+    assert not os.path.exists(path + ".tmp.npz")
     b = Trainer(spec, init_shader_weights(spec, seed=99), **kw)
     assert b.load_checkpoint(dict(np.load(path))) == 7 and b.global_step == 2
-    b.step(vox, poses, tgt, patch_size=16, start_point=(2, 4))
-    assert torch.equal(b.param, ref.param) and torch.equal(b.m, ref.m) and torch.equal(b.v, ref.v)
+    assert torch.equal(b.param, a.param) and torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
+    run(b, [2])
+    resumed = float((b.param - ref.param).abs().max())
+    c = Trainer(spec, {k: v for k, v in a.state_dict().items()}, **kw)     # weights only: the round-1 checkpoint
+    run(c, [2])
+    cold = float((c.param - ref.param).abs().max())
+    assert b.global_step == 3 and resumed <= max(20 * spread, 5e-5), (resumed, spread)     # lr = 1e-3: a step is ~1e-3
+    assert cold > 10 * (resumed + 1e-7), (cold, resumed)
