@@ -49,7 +49,7 @@ extern "C" {
 
 #define RN_PACK_CONV_WINO       3  /* TF conv filter [3,3,Cin,Cout] (ndim 2) or [3,3,3,Cin,Cout] (ndim 3) -> Winograd
                                      F(2x2,3x3) transformed U = G g G^T over the first two filter dims (16 planes,
-                                     16*Cin*Cout floats, x3 for 3-D; Cin % 16 == 0, Cout % 32 == 0) for
+                                     16*Cin*Cout floats, x3 for 3-D; Cin % 16 == 0, Cout % 16 == 0) for
                                      rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
 #define RN_PACK_CONVT_S1_WINO   4  /* TF conv_transpose filter [3,3,(3,)Cout,Cin], stride 1, taps flipped, same
                                      transform: the input gradient of a stride-1 3x3(x3) conv through
@@ -152,7 +152,8 @@ int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, 
  * in fp32.  w_wino comes from rn_pack_weights(RN_PACK_CONV_WINO); packed with RN_PACK_CONVT_S1_WINO from the layer's
  * own TF filter it computes the layer's input gradient (dz [B,H,W,Cout_fwd] -> dx [B,H,W,Cin_fwd]).  preact may be
  * NULL (see rn_conv2d_fwd_train).  rn_conv2d_wino_supported: 1 when this library takes (Cin, Cout) on that path
- * (Cin % 16 == 0, Cout % 32 == 0, and the environment does not set RN_NO_WINOGRAD), else 0 -- use rn_conv2d_fwd. */
+ * (Cin % 16 == 0, Cout % 16 == 0, and the environment does not set RN_NO_WINOGRAD), else 0 -- use rn_conv2d_fwd.
+ * Every pointer must be 16-byte aligned. */
 /* rn_conv3d_wino_fwd: the same for the 3x3x3, stride-1 convs of the 3-D encoder -- conv3d in res_block_3d and
  * res1_skip (tools/layer_util.py:60-73; RenderNet_Shader.py:44-64): Winograd F(2x2,3x3) over (H,W), direct over the
  * three depth taps (in channels-last [B,H,W,D,C] the three depth neighbours of a voxel are 3*C contiguous floats, so

@@ -12,7 +12,7 @@
 // One fused kernel, no transformed tensors in HBM:
 //   * filters are pre-transformed once by rn_pack_weights (RN_PACK_CONV_WINO): U[xi][c][n], 16 "xi"
 //     planes, stored [Cout/32][Cin/16][16 xi][4][32][4] so that every (n-block, 16-channel step) is one
-//     contiguous 32 KiB piece that goes global -> LDS with buffer_load ... lds;
+//     contiguous 32 KiB piece that goes global -> LDS with buffer_load ... lds (Cout % 32 != 0: 16-wide n-blocks);
 //   * a workgroup (512 threads = 8 waves, two per SIMD, 128 accumulator registers each) owns a block of
 //     16x8 tiles (32x16 outputs) x 32 output channels x all 16 xi.  Its RAW 34x18-pixel input patch goes
 //     global -> LDS, 16 channels per stage (SAME padding from the buffer bounds check);
@@ -80,6 +80,7 @@ struct WinoBlock {
 // work item `id` (0 <= id < mblocks*nblocks) -> block.  Enumeration e: groups of 8 m-blocks, n-major inside a group, so
 // that the 32 workgroups of one XCD (id % 8; one workgroup per CU, persistent, round r works on id = r*G + blockIdx)
 // stream 4 filter slabs and 8 patches between them, and the 8 XCDs of a round of 256 read the same 8 patches.
+template <int NT>
 __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, int lane, WinoBlock& k)
 {
     const int T = a.mblocks * a.nblocks;
@@ -113,8 +114,8 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
         const unsigned o = (unsigned)((k.b * a.H + iy) * a.W + ix) * pix_bytes + win_off;
         k.roff[i] = ok ? o + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16) : WOOB;
     }
-    // filter DMA: the 32 KiB piece of (nb, step) is lane-linear; wave w moves KiB 4w .. 4w+3
-    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt)) * 32768u + (unsigned)wave * 4096u + (unsigned)lane * 16u;
+    // filter DMA: the 16*NT KiB piece of (nb, step) is lane-linear; wave w moves KiB 2NT*w .. 2NT*w + 2NT-1
+    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt)) * (16384u * NT) + (unsigned)wave * (2048u * NT) + (unsigned)lane * 16u;
 }
 
 // PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
@@ -125,7 +126,9 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
 // straight across item boundaries: during the LAST step of an item the first step of the NEXT item is fetched into the
 // free LDS stage, so the epilogue (output transform + stores) and the next item's cold start overlap its latency --
 // with 6 K steps per item (the 3-D encoder layers) prologue + epilogue used to cost as much as the steps themselves.
-template <int PROBE>
+// NT = 16-channel n-tiles per wave: 2 (32 output channels per workgroup; Cout % 32 == 0) or 1 (Cout % 16 == 0 only: the
+// 16-wide 3-D encoder of the texture net).  The filter pack's n-block is 16*NT wide (misc_kernels.hip: pack_wino_kernel).
+template <int PROBE, int NT>
 __global__ __launch_bounds__(512, 1)
 void conv_wino_kernel(const WinoArgs a)
 {
@@ -148,17 +151,19 @@ void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
     for (int hj = 0; hj < 2; ++hj)
         raddr0[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
-    const unsigned uaddr0 = (unsigned)(2 * WRAW_B + kq * 512 + l16 * 16);
+    const unsigned uaddr0 = (unsigned)(2 * WRAW_B + kq * (256 * NT) + l16 * 16);
 
-    f32x4 acc[16][2];
+    constexpr int NDMA = 5 + 2 * NT;               // DMA instructions per wave and step: 5 raw-patch + 2NT filter pieces
+    constexpr unsigned USTEP = 16384u * NT;        // filter bytes per step and n-block
+    f32x4 acc[16][NT];
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][nt][r] = 0.f;
 
-    // DMA number idx_ (0..8) of this wave into stage st_: 0..4 = raw-patch pieces (per-lane offsets ro_[]), 5..8 = filter
+    // DMA number idx_ (0..NDMA-1) of this wave into stage st_: 0..4 = raw-patch pieces (per-lane offsets ro_[]), 5.. = filter
     // pieces (per-lane offset uo_, step offset us_ in an SGPR).  When nothing follows, the offsets are out of range: the
     // hardware then writes zeros into the stage nobody reads -- no branches in the loop.
 #define WINO_DMA_ONE(st_, idx_)                                                                           \
@@ -167,7 +172,7 @@ void conv_wino_kernel(const WinoArgs a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (st_) * WRAW_B + (wave + 8 * (idx_)) * 1024), \
                                                      16, ro_[(idx_) < 5 ? (idx_) : 0], 0, 0, 0);          \
         } else {                                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (st_) * WU_B + (wave * 4 + (idx_) - 5) * 1024), \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (st_) * WU_B + (wave * 2 * NT + (idx_) - 5) * 1024), \
                                                      16, uo_, us_ + (unsigned)((idx_) - 5) * 1024u, 0, 0); \
         }                                                                                                 \
     }
@@ -193,22 +198,22 @@ void conv_wino_kernel(const WinoArgs a)
     WinoBlock cur, nxt;
     int id = blockIdx.x;
     if (id >= T) return;
-    wino_block(a, id, wave, lane, cur);
+    wino_block<NT>(a, id, wave, lane, cur);
     int stage = 0;
     {   // the first step of the first item
         unsigned ro_[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) ro_[i] = cur.roff[i] + (unsigned)cur.s_begin * 64u;
-        const unsigned uo_ = cur.uoff, us_ = (unsigned)cur.s_begin * 32768u;
+        const unsigned uo_ = cur.uoff, us_ = (unsigned)cur.s_begin * USTEP;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) WINO_DMA_ONE(0, i);
+        for (int i = 0; i < NDMA; ++i) WINO_DMA_ONE(0, i);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (;;) {
         const bool has_next = id + G < T;
-        if (has_next) wino_block(a, id + G, wave, lane, nxt);
+        if (has_next) wino_block<NT>(a, id + G, wave, lane, nxt);
         for (int s = cur.s_begin; s < cur.s_end; ++s) {
             // what the other stage receives during this step: the item's next step, or the next item's first, or nothing
             const bool last = s + 1 == cur.s_end;
@@ -218,11 +223,11 @@ void conv_wino_kernel(const WinoArgs a)
             for (int i = 0; i < 5; ++i)
                 ro_[i] = !fetch ? WOOB : last ? nxt.roff[i] + (unsigned)nxt.s_begin * 64u : cur.roff[i] + (unsigned)(s + 1) * 64u;
             const unsigned uo_ = !fetch ? WOOB : last ? nxt.uoff : cur.uoff;
-            const unsigned us_ = !fetch ? 0u : last ? (unsigned)nxt.s_begin * 32768u : (unsigned)(s + 1) * 32768u;
+            const unsigned us_ = !fetch ? 0u : last ? (unsigned)nxt.s_begin * USTEP : (unsigned)(s + 1) * USTEP;
             const int st1 = stage ^ 1;
             if ((PROBE & 10) == 8) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) WINO_DMA_ONE(st1, i);
+                for (int i = 0; i < NDMA; ++i) WINO_DMA_ONE(st1, i);
             }
             // one 16-channel step on `stage`; the nine DMAs are issued one at a time behind the MFMA groups of xi 0..8
             // (all at the top of the step: 7.64 ms instead of 7.10 on res2 -- they stall the step's head)
@@ -242,16 +247,19 @@ void conv_wino_kernel(const WinoArgs a)
                 WINO_ROW(i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const f32x4 b0_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048);
-                    const f32x4 b1_ = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * 2048 + 256);
+                    f32x4 b_[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        b_[nt] = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * (1024 * NT) + nt * 256);
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_) {
                         // A operand = filter fragment, B operand = transformed-input fragment: the accumulator then holds
                         // FOUR CONSECUTIVE CHANNELS of one tile per lane (rows = channels), which the epilogue stores as 16 B
-                        acc[i * 4 + jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0_[s_], v_[jj][s_], acc[i * 4 + jj][0], 0, 0, 0);
-                        acc[i * 4 + jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1_[s_], v_[jj][s_], acc[i * 4 + jj][1], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i * 4 + jj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_[nt][s_], v_[jj][s_], acc[i * 4 + jj][nt], 0, 0, 0);
                     }
-                    if (!(PROBE & 10) && i * 4 + jj < 9) WINO_DMA_ONE(st1, i * 4 + jj);
+                    if (!(PROBE & 10) && i * 4 + jj < NDMA) WINO_DMA_ONE(st1, i * 4 + jj);
                 }
             }
             if (!last) {
@@ -267,8 +275,8 @@ void conv_wino_kernel(const WinoArgs a)
         // and workgroup.  Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = acc[4i+j].
         const int ty = wave, tx = l16;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = cur.nb * 32 + nt * 16 + 4 * kq;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = cur.nb * (16 * NT) + nt * 16 + 4 * kq;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
             const f32x4 av = a.alpha ? *reinterpret_cast<const f32x4*>(a.alpha + n) : zero4;
@@ -322,7 +330,7 @@ void conv_wino_kernel(const WinoArgs a)
 bool rn_wino_supported(int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD") != nullptr;
-    return !off && Cin % 16 == 0 && Cout % 32 == 0;
+    return !off && Cin % 16 == 0 && Cout % 16 == 0;
 }
 
 bool rn_wino3d_supported(int Cin, int Cout)
@@ -336,8 +344,8 @@ bool rn_wino3d_supported(int Cin, int Cout)
 int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act, hipStream_t st)
 {
-    if (Cin % 16 != 0 || Cout % 32 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d (need %%16) Cout=%d (need %%32)", Cin, Cout);
+    if (Cin % 16 != 0 || Cout % 16 != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (both must be multiples of 16)", Cin, Cout);
     if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1)) return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d", D, KD);
     const long long per_item = (long long)H * W * D * Cin * 4;
     if (per_item >= 0x80000000LL)
@@ -366,16 +374,18 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     a.B = B; a.H = H; a.W = W; a.D = D; a.KD = KD; a.Cin = Cin; a.Cout = Cout;
     a.bh = (H + 15) / 16; a.bw = (W + 31) / 32;
     const long long mbl = (long long)B * D * a.bh * a.bw;
-    a.nblocks = Cout / 32;
+    const int NTv = Cout % 32 == 0 ? 2 : 1;         // 16-channel n-tiles per wave (the filter pack follows the same rule)
+    a.nblocks = Cout / (16 * NTv);
     if (mbl * a.nblocks > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wino: grid too large");
     a.mblocks = (int)mbl;
     a.spt = Cin / 16;
     a.act = act;
     static const int probe = getenv("RN_WINO_PROBE") ? atoi(getenv("RN_WINO_PROBE")) : 0;
     const size_t lds = rn_wino_lds_bytes();
-    auto kern = probe == 1 ? conv_wino_kernel<1> : probe == 2 ? conv_wino_kernel<2> : probe == 3 ? conv_wino_kernel<3>
-              : probe == 4 ? conv_wino_kernel<4> : probe == 8 ? conv_wino_kernel<8> : probe == 12 ? conv_wino_kernel<12>
-              : conv_wino_kernel<0>;
+    auto kern = NTv == 1 ? conv_wino_kernel<0, 1>
+              : probe == 1 ? conv_wino_kernel<1, 2> : probe == 2 ? conv_wino_kernel<2, 2> : probe == 3 ? conv_wino_kernel<3, 2>
+              : probe == 4 ? conv_wino_kernel<4, 2> : probe == 8 ? conv_wino_kernel<8, 2> : probe == 12 ? conv_wino_kernel<12, 2>
+              : conv_wino_kernel<0, 2>;
     // per launch: the attribute is per device, and a process may drive several
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // persistent grid: one workgroup per CU (147 KiB of LDS each), every one walking its share of the items

@@ -56,8 +56,9 @@ __global__ void pack_weights_kernel(const PackArgs a)
 }
 
 // Winograd F(2x2,3x3) filter transform for csrc/conv_wino.hip: U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],
-// packed [Cout/32][KD*Cin/16][16 xi][4 kq][32 n][4 r] with channel c' = step*16 + kq*4 + r (one contiguous 32 KiB piece
-// per (n-block, 16-channel step)).  RN_PACK_CONV_WINO reads w_tf[3,3,(3,)Cin,Cout]; RN_PACK_CONVT_S1_WINO reads
+// packed [Cout/NB][KD*Cin/16][16 xi][4 kq][NB n][4 r] with channel c' = step*16 + kq*4 + r (one contiguous piece per
+// (n-block, 16-channel step)); the n-block width NB is 32 when Cout % 32 == 0 and 16 otherwise -- the rule the kernel's
+// launcher uses to pick one or two 16-channel MFMA tiles per wave.  RN_PACK_CONV_WINO reads w_tf[3,3,(3,)Cin,Cout]; RN_PACK_CONVT_S1_WINO reads
 // w_tf[3,3,(3,)Cout,Cin] with the taps flipped (a stride-1 transposed conv = the input gradient of a 3x3(x3) conv).
 // 3-D filters (KD = 3): the transform runs over the first two filter dims only, the depth tap t2 joins the channel:
 // c' = t2*Cin + c -- the kernel walks the 3*Cin contiguous floats of three depth slices (see conv_wino.hip).
@@ -66,14 +67,15 @@ __global__ void pack_wino_kernel(const float* __restrict__ w_tf, float* __restri
     const size_t total = (size_t)16 * KD * Cin * Cout;
     const int nstep = KD * Cin / 16;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int NB = Cout % 32 == 0 ? 32 : 16;
         size_t rem = idx;
         const int r = (int)(rem & 3); rem >>= 2;
-        const int n = (int)(rem & 31); rem >>= 5;
+        const int n = (int)(rem % NB); rem /= NB;
         const int kq = (int)(rem & 3); rem >>= 2;
         const int xi = (int)(rem & 15); rem >>= 4;
         const int step = (int)(rem % nstep);
         const int nb = (int)(rem / nstep);
-        const int ce = step * 16 + kq * 4 + r, co = nb * 32 + n;
+        const int ce = step * 16 + kq * 4 + r, co = nb * NB + n;
         const int t2 = ce / Cin, c = ce - t2 * Cin;
         const int i = xi >> 2, j = xi & 3;
         float g[3][3];
@@ -99,8 +101,8 @@ static int wino_pack_check(int ndim, const int* kdims, int Cin, int Cout)
 {
     if (!kdims || (ndim != 2 && ndim != 3) || kdims[0] != 3 || kdims[1] != 3 || (ndim == 3 && kdims[2] != 3))
         return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need a 3x3 or 3x3x3 filter");
-    if (Cin < 16 || Cout < 32 || Cin % 16 != 0 || Cout % 32 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", Cin, Cout);
+    if (Cin < 16 || Cout < 16 || Cin % 16 != 0 || Cout % 16 != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the Winograd packs need Cin and Cout to be multiples of 16 (got %d, %d)", Cin, Cout);
     return RN_OK;
 }
 

@@ -29,9 +29,10 @@ def pack_wino(w_tf, transposed=False):
     elif transposed:
         w = w[::-1, ::-1].transpose(0, 1, 3, 2)
     cin, cout = w.shape[2], w.shape[3]
-    assert cin % 16 == 0 and cout % 32 == 0
+    assert cin % 16 == 0 and cout % 16 == 0
+    NB = 32 if cout % 32 == 0 else 16                                      # n-block width (one or two MFMA n-tiles per wave)
     u = np.einsum("ip,pqcn,jq->ijcn", G, w, G).astype(np.float32)          # [4,4,Cin,Cout]
-    u = u.reshape(16, cin // 16, 4, 4, cout // 32, 32)                    # xi, step, kq, r, nb, n
+    u = u.reshape(16, cin // 16, 4, 4, cout // NB, NB)                    # xi, step, kq, r, nb, n
     return np.ascontiguousarray(u.transpose(4, 1, 0, 2, 5, 3)).reshape(-1)
 
 
@@ -63,7 +64,9 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
     y = np.full((B, H, W, D, cout), np.nan, np.float32)
     bh, bw = (H + 15) // 16, (W + 31) // 32
     spt = Cin // 16
-    mblocks, nblocks, nstep = B * D * bh * bw, cout // 32, KD * spt
+    NT = 2 if cout % 32 == 0 else 1
+    USTEP = 16384 * NT
+    mblocks, nblocks, nstep = B * D * bh * bw, cout // (16 * NT), KD * spt
     lane = np.arange(64)
     l16, kq = lane & 15, lane >> 4
     seen = set()
@@ -90,13 +93,13 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                     for ln in range(64):
                         dst = (p * 1024 + ln * 16) // 4
                         lds[dst:dst + 4] = xf[off[ln] // 4: off[ln] // 4 + 4] if ok[ln] else 0.0
-                for i in range(4):                                        # filter pieces
-                    g = (nb * nstep + s) * 32768 + wave * 4096 + i * 1024
-                    dst = (WRAW_B + (wave * 4 + i) * 1024) // 4
+                for i in range(2 * NT):                                   # filter pieces
+                    g = (nb * nstep + s) * USTEP + wave * 2048 * NT + i * 1024
+                    dst = (WRAW_B + (wave * 2 * NT + i) * 1024) // 4
                     lds[dst:dst + 256] = u_packed[g // 4: g // 4 + 256]
             for wave in range(8):
                 raddr = [(2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4) for hj in range(2)]
-                uaddr = WRAW_B + kq * 512 + l16 * 16
+                uaddr = WRAW_B + kq * 256 * NT + l16 * 16
                 d = np.zeros((4, 4, 64, 4), np.float32)
                 for ai in range(4):
                     for bi in range(4):
@@ -106,8 +109,8 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                 v = np.stack([t[:, 0] - t[:, 2], t[:, 1] + t[:, 2], t[:, 2] - t[:, 1], t[:, 1] - t[:, 3]], 1)  # [i][j]
                 for xi in range(16):
                     vv = v[xi // 4, xi % 4]                                                   # [lane, s]
-                    for nt in range(2):
-                        ad = (uaddr + xi * 2048 + nt * 256) // 4
+                    for nt in range(NT):
+                        ad = (uaddr + xi * 1024 * NT + nt * 256) // 4
                         bb = lds[ad[:, None] + np.arange(4)]                                  # [lane, s]
                         # MFMA 16x16x4 x4 with the FILTER as the A operand: A[row=l16 (channel)][k=4kq+s],
                         # B[k=4kq+s][col=l16 (tile)]
@@ -120,9 +123,9 @@ def conv_wino_emulated(x, u_packed, cout, bias=None):
                         acc[wave, xi, nt] += Dm[(4 * kq)[:, None] + np.arange(4), l16[:, None]]
         for wave in range(8):
             ty = wave
-            for nt in range(2):
+            for nt in range(NT):
                 for r in range(4):
-                    n = nb * 32 + nt * 16 + 4 * kq + r        # a lane holds channels 4kq..4kq+3 of tile tx = l16
+                    n = nb * 16 * NT + nt * 16 + 4 * kq + r        # a lane holds channels 4kq..4kq+3 of tile tx = l16
                     M = acc[wave, :, nt, :, r].reshape(4, 4, 64)
                     sc = np.stack([M[:, 0] + M[:, 1] + M[:, 2], M[:, 1] - M[:, 2] - M[:, 3]], 1)   # [i][dx][lane]
                     Y = np.stack([sc[0] + sc[1] + sc[2], sc[1] - sc[2] - sc[3]])                   # [dy][dx][lane]

@@ -48,7 +48,7 @@ def test_block_map_groups_an_xcd_round_on_few_slabs():
         assert len(patches) == 8
 
 
-@pytest.mark.parametrize("shape", [(1, 9, 20, 4, 16, 32), (2, 16, 16, 1, 32, 32), (1, 5, 5, 3, 16, 64)])
+@pytest.mark.parametrize("shape", [(1, 9, 20, 4, 16, 32), (2, 16, 16, 1, 32, 32), (1, 5, 5, 3, 16, 64), (1, 6, 33, 2, 16, 16), (1, 4, 4, 3, 32, 48)])
 def test_emulated_kernel_matches_the_oracle_conv3d(shape):
     """The 3x3x3 flavour: Winograd over (H,W), the three depth taps as 3*Cin contiguous channels per depth slice, whole
     steps skipped where a depth tap is SAME padding."""
