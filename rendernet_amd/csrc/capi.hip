@@ -40,6 +40,9 @@ static int dispatch(const RnConvProblem& p, hipStream_t st)
 {
     static const bool no_drun = getenv("RN_NO_DRUN") != nullptr;
     if (!no_drun && rn_drun_supported(p)) return rn_launch_conv3d_drun(p, st);
+    if (rn_igemm_supported(p) && p.Cout >= 8) return rn_launch_conv_igemm(p, st);
+    const int rc = rn_launch_conv_tiled(p, st);          // LDS-tiled kernels of the stem / tail shapes
+    if (rc != RN_E_UNSUPPORTED) return rc;
     if (rn_igemm_supported(p)) return rn_launch_conv_igemm(p, st);
     return rn_launch_conv_direct(p, st);
 }

@@ -1,0 +1,150 @@
+// LDS-tiled direct (VALU) convolution for the channel-starved stem and tail of the path, which are memory-bound and
+// hopeless MFMA shapes:  e_conv1 (5^3 stride 2, Cin 1 | 5 -> 8; RenderNet_Shader.py:36-39,
+// RenderNet_Texture_Face_Normal.py:52-55), e_conv2 (3^3 stride (1,1,2), 8 -> 16; :40-43) and e_conv11 (4x4 stride-1
+// transposed conv = flipped conv, 16 -> 1 | 3, + sigmoid; :125-131).
+//
+// The generic direct kernel (conv_direct.hip) reads every tap of every output straight from L1/L2: 125 x Cin scattered
+// loads per output (e_conv1: 0.83 ms for 402 MB of traffic, 5.0 ms with the texture net's 5 input channels).  Here a
+// workgroup stages the input box of its T0 x T1 x T2 output tile in LDS with coalesced row loads (zero-filled where SAME
+// padding applies) and the filter beside it; every thread then owns ONE output position and all CO channels.
+// A tile whose input box is entirely zero -- 98 % of the 128^3 resampled grid is -- skips the arithmetic: its outputs
+// are the constant act(bias).
+#include "rn_common.h"
+
+struct TiledArgs2 {
+    const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y; float* z;
+    int B, I0, I1, I2, O0, O1, O2, Cout, Npad;
+    int P0, P1, P2;
+    int nt0, nt1, nt2;          // tiles per dim
+    int act;
+};
+
+template <int K0, int K1, int K2, int S0, int S1, int S2, int CIN, int CO, int T0, int T1, int T2>
+__global__ __launch_bounds__(T0 * T1 * T2)
+void conv_tiled_kernel(const TiledArgs2 a)
+{
+    constexpr int NTH = T0 * T1 * T2;
+    constexpr int IT0 = (T0 - 1) * S0 + K0, IT1 = (T1 - 1) * S1 + K1, IT2 = (T2 - 1) * S2 + K2;
+    constexpr int ROWE = IT2 * CIN;                       // floats in one (r0, r1) row of the box in global memory
+    // LDS pitches chosen so that the lanes of a wave (t2 fastest, then t1) read distinct banks: a position takes PP floats
+    // (S2*PP*t2 mod 32 distinct for 16 lanes), a row an odd number of floats, and rows of a stride-2 conv are skewed by one
+    // float per output row
+    constexpr int PP = (CIN % 2 == 0) ? CIN + 1 : CIN;
+    constexpr int SKEW = (S1 % 2 == 0) ? 1 : 0;
+    constexpr int ROW = (IT2 * PP + SKEW * (IT1 / 2 + 1)) | 1;
+    constexpr int KTOT = K0 * K1 * K2 * CIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);           // [KTOT][CO]
+    float* xt = wl + KTOT * CO;                           // [IT0][IT1][ROW]
+
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int bt2 = blk % a.nt2; blk /= a.nt2;
+    const int bt1 = blk % a.nt1; blk /= a.nt1;
+    const int bt0 = blk % a.nt0; const int b = blk / a.nt0;
+    const int in0 = bt0 * T0 * S0 - a.P0, in1 = bt1 * T1 * S1 - a.P1, in2 = bt2 * T2 * S2 - a.P2;
+
+    for (int i = tid; i < KTOT * CO; i += NTH) {
+        const int k = i / CO, n = i % CO;
+        wl[i] = (n < a.Cout) ? a.w[((size_t)(k >> 2) * a.Npad + n) * 4 + (k & 3)] : 0.f;
+    }
+    // input box: rows of ROWE contiguous floats (depth x channel) in global memory
+    bool any = false;
+    for (int i = tid; i < IT0 * IT1 * ROWE; i += NTH) {
+        const int e = i % ROWE, r = i / ROWE;
+        const int r1 = r % IT1, r0 = r / IT1;
+        const int i0 = in0 + r0, i1 = in1 + r1, i2 = in2 + e / CIN;
+        float v = 0.f;
+        if ((unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 && (unsigned)i2 < (unsigned)a.I2)
+            v = a.x[((((size_t)b * a.I0 + i0) * a.I1 + i1) * a.I2 + in2) * CIN + e];
+        any = any || v != 0.f;
+        xt[r * ROW + SKEW * (r1 >> 1) + (e / CIN) * PP + e % CIN] = v;
+    }
+    const bool work = __syncthreads_or(any ? 1 : 0) != 0;
+
+    const int t2 = tid % T2, t1 = (tid / T2) % T1, t0 = tid / (T2 * T1);
+    const int o0 = bt0 * T0 + t0, o1 = bt1 * T1 + t1, o2 = bt2 * T2 + t2;
+    float acc[CO];
+#pragma unroll
+    for (int n = 0; n < CO; ++n) acc[n] = 0.f;
+    if (work) {
+        for (int k0 = 0; k0 < K0; ++k0)
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const int r1 = t1 * S1 + k1;
+                const float* xr = xt + ((t0 * S0 + k0) * IT1 + r1) * ROW + SKEW * (r1 >> 1) + t2 * S2 * PP;
+                const float* wr = wl + (size_t)((k0 * K1 + k1) * K2) * CIN * CO;
+#pragma unroll
+                for (int k2 = 0; k2 < K2; ++k2)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) {
+                        const float xv = xr[k2 * PP + c];
+#pragma unroll
+                        for (int n = 0; n < CO; ++n) acc[n] = fmaf(xv, wr[(k2 * CIN + c) * CO + n], acc[n]);
+                    }
+            }
+    }
+    if (o0 >= a.O0 || o1 >= a.O1 || o2 >= a.O2) return;
+    const size_t oo = ((((size_t)b * a.O0 + o0) * a.O1 + o1) * a.O2 + o2) * a.Cout;
+#pragma unroll
+    for (int n = 0; n < CO; ++n) {
+        if (n < a.Cout) {
+            float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
+            if (a.z) a.z[oo + n] = v;
+            if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+            if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
+            if (a.res) v += a.res[oo + n];
+            if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+            a.y[oo + n] = v;
+        }
+    }
+}
+
+template <int K0, int K1, int K2, int S0, int S1, int S2, int CIN, int CO, int T0, int T1, int T2>
+static int launch_tiled(const RnConvProblem& p, hipStream_t st)
+{
+    constexpr int IT0 = (T0 - 1) * S0 + K0, IT1 = (T1 - 1) * S1 + K1, IT2 = (T2 - 1) * S2 + K2;
+    TiledArgs2 a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
+    a.B = p.B; a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2];
+    a.Cout = p.Cout; a.Npad = p.Npad; a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = p.P[2];
+    a.nt0 = (p.O[0] + T0 - 1) / T0; a.nt1 = (p.O[1] + T1 - 1) / T1; a.nt2 = (p.O[2] + T2 - 1) / T2;
+    a.act = p.act;
+    const long long nb = (long long)p.B * a.nt0 * a.nt1 * a.nt2;
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_tiled: bad grid %lld", nb);
+    constexpr int PP = (CIN % 2 == 0) ? CIN + 1 : CIN;
+    constexpr int ROW = (IT2 * PP + ((S1 % 2 == 0) ? IT1 / 2 + 1 : 0)) | 1;
+    const size_t lds = ((size_t)K0 * K1 * K2 * CIN * CO + (size_t)IT0 * IT1 * ROW + 16) * sizeof(float);
+    auto kern = conv_tiled_kernel<K0, K1, K2, S0, S1, S2, CIN, CO, T0, T1, T2>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(T0 * T1 * T2), lds, st, a);
+    return rn_check_launch("conv_tiled");
+}
+
+static bool is_plain(const RnConvProblem& p)
+{
+    // contiguous channels-last output covering the whole grid (no sub-pixel phase addressing)
+    return p.out_off == 0 && p.os[2] == p.Cout && p.os[1] == (long long)p.O[2] * p.Cout &&
+           p.os[0] == (long long)p.O[1] * p.O[2] * p.Cout && p.os_b == (long long)p.O[0] * p.O[1] * p.O[2] * p.Cout;
+}
+
+// returns RN_E_UNSUPPORTED (without setting an error) when no instantiation matches: the caller falls back
+int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
+{
+    static const bool off = getenv("RN_NO_TILED") != nullptr;
+    if (off || !is_plain(p)) return RN_E_UNSUPPORTED;
+    const bool k555s2 = p.K[0] == 5 && p.K[1] == 5 && p.K[2] == 5 && p.S[0] == 2 && p.S[1] == 2 && p.S[2] == 2;
+    if (k555s2 && p.Cout == 8 && p.Cin == 1) return launch_tiled<5, 5, 5, 2, 2, 2, 1, 8, 4, 4, 16>(p, st);
+    // the texture net's 5-channel stem: 625 taps x 8 channels per output make it LDS-instruction-bound on the broadcast
+    // filter reads (2 ds_read_b128 per input value); tile 4x8x16 (512 threads): 4.9 ms, 4x4x16: 5.5, 2x4x16: 6.7, the generic
+    // direct kernel: 5.0 ms.  Next step if it matters: several outputs per thread sharing each filter read.
+    if (k555s2 && p.Cout == 8 && p.Cin == 5) return launch_tiled<5, 5, 5, 2, 2, 2, 5, 8, 4, 8, 16>(p, st);
+    // (e_conv2 -- 3^3 stride (1,1,2), 8 -> 16 -- measured 0.98 ms tiled vs 0.79 ms with the generic direct kernel: its 8-float
+    //  channel runs already coalesce, and 16 accumulators x 216 taps leave the tile's 4 waves per CU latency-bound.  Not routed here.)
+    static const bool tiled_e2 = getenv("RN_TILED_ECONV2") != nullptr;
+    if (tiled_e2 && p.K[0] == 3 && p.K[1] == 3 && p.K[2] == 3 && p.S[0] == 1 && p.S[1] == 1 && p.S[2] == 2 && p.Cin == 8 && p.Cout == 16)
+        return launch_tiled<3, 3, 3, 1, 1, 2, 8, 16, 4, 4, 16>(p, st);
+    const bool k44 = p.K[0] == 4 && p.K[1] == 4 && p.K[2] == 1 && p.S[0] == 1 && p.S[1] == 1 && p.S[2] == 1 && p.I[2] == 1;
+    if (k44 && p.Cin == 16 && p.Cout == 1) return launch_tiled<4, 4, 1, 1, 1, 1, 16, 1, 16, 16, 1>(p, st);
+    if (k44 && p.Cin == 16 && p.Cout == 3) return launch_tiled<4, 4, 1, 1, 1, 1, 16, 3, 16, 16, 1>(p, st);
+    return RN_E_UNSUPPORTED;
+}

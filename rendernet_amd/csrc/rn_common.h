@@ -33,6 +33,7 @@ int rn_check_launch(const char* what);
 // launchers implemented in the kernel translation units
 int rn_launch_conv_igemm(const RnConvProblem& p, hipStream_t st);     // conv_igemm.hip  (MFMA)
 int rn_launch_conv_direct(const RnConvProblem& p, hipStream_t st);    // conv_direct.hip (VALU)
+int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st);     // conv_tiled.hip  (VALU, LDS-tiled stem / tail shapes; RN_E_UNSUPPORTED = no match)
 bool rn_igemm_supported(const RnConvProblem& p);
 int rn_launch_conv3d_drun(const RnConvProblem& p, hipStream_t st);     // conv3d_drun.hip (MFMA, 3^3 s1, N=32)
 bool rn_drun_supported(const RnConvProblem& p);

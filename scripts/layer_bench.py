@@ -88,6 +88,9 @@ def main():
                   % ("resample-dense", msd, B * 9437184 / (msd * 1e-3) / 1e9), flush=True)
 
     conv_case("e_conv1", "conv3d", (B, 128, 128, 128, 1), (5, 5, 5, 1, 8), (2, 2, 2), 1)
+    if args.only and "tex" in args.only:          # texture net (RenderNet_Texture_Face_Normal.py): 5 input channels, 16-wide trunk
+        conv_case("tex_e_conv1", "conv3d", (B, 128, 128, 128, 5), (5, 5, 5, 5, 8), (2, 2, 2), 1)
+        conv_case("tex_res1", "conv3d", (B, 64, 64, 32, 16), (3, 3, 3, 16, 16), (1, 1, 1), 21)
     conv_case("e_conv2", "conv3d", (B, 64, 64, 64, 8), (3, 3, 3, 8, 16), (1, 1, 2), 1)
     conv_case("e_conv3", "conv3d", (B, 64, 64, 32, 16), (3, 3, 3, 16, 32), (1, 1, 1), 1)
     conv_case("res1", "conv3d", (B, 64, 64, 32, 32), (3, 3, 3, 32, 32), (1, 1, 1), 21)
