@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 140            /* 0.1.4: + Winograd F(2x2,3x3) path for the stride-1 3x3 2-D convs */
+#define RN_VERSION 150            /* 0.1.5: + Winograd paths (3x3, 3x3x3, 4x4 filters), dropout */
 
 /* error codes */
 #define RN_OK              0
@@ -54,6 +54,12 @@ extern "C" {
 #define RN_PACK_CONVT_S1_WINO   4  /* TF conv_transpose filter [3,3,(3,)Cout,Cin], stride 1, taps flipped, same
                                      transform: the input gradient of a stride-1 3x3(x3) conv through
                                      rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
+
+#define RN_PACK_CONV_WINO4      5  /* TF conv filter [4,4,Cin,Cout] as four 2x2 sub-filters, each Winograd F(2x2,2x2)
+                                     transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 32 == 0) for
+                                     rn_conv2d_wino4_fwd                                                          */
+#define RN_PACK_CONVT_S1_WINO4  6  /* TF conv_transpose filter [4,4,Cout,Cin], stride 1, taps flipped, same transform:
+                                     rn_conv2d_wino4_fwd with transposed = 1                                     */
 
 int rn_version(void);
 const char* rn_last_error(void);
@@ -160,6 +166,15 @@ int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, 
  * every output depth slice is a 2-D conv with 3*C input channels): 27 -> 12 multiplies per output and channel pair. */
 int rn_conv2d_wino_supported(int Cin, int Cout);
 int rn_conv3d_wino_supported(int Cin, int Cout);
+/* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
+ * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the
+ * flipped conv with padding (2,1)), and their input gradients (a conv's is the transposed form of the same filter and vice
+ * versa).  The 4x4 filter is the sum of four 2x2 sub-filters applied to the input shifted by (0|2, 0|2) pixels; each is a
+ * Winograd F(2x2,2x2): 36 multiplies per 2x2 outputs and channel pair instead of 64, in fp32.  Cin % 16 == 0, Cout % 32 == 0. */
+int rn_conv2d_wino4_supported(int Cin, int Cout);
+int rn_conv2d_wino4_fwd(const float* x, const float* w_wino4, const float* bias, const float* alpha,
+                        const float* residual, float* y, float* preact,
+                        int B, int H, int W, int Cin, int Cout, int transposed, int act, void* stream);
 int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
                        const float* residual, float* y, float* preact,
                        int B, int H, int W, int D, int Cin, int Cout, int act, void* stream);

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RN_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libre
 RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID, RN_ACT_ELU = 0, 1, 2, 4
 RN_PHONG_NP_BLACK, RN_PHONG_NP_WHITE, RN_PHONG_TF_BLACK, RN_PHONG_TF_WHITE, RN_PHONG_NO_MASK = 0, 1, 2, 3, 4
 RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2, RN_PACK_CONV_WINO, RN_PACK_CONVT_S1_WINO = 0, 1, 2, 3, 4
+RN_PACK_CONV_WINO4, RN_PACK_CONVT_S1_WINO4 = 5, 6
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -34,6 +35,8 @@ SIGNATURES = {
     "rn_projection_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
+    "rn_conv2d_wino4_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino4_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_conv3d_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv3d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),

@@ -100,7 +100,21 @@ extern "C" int rn_conv2d_wino_fwd(const float* x, const float* w_wino, const flo
     if (!x || !w_wino || !y) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: null pointer");
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_fwd: PReLU needs alpha");
-    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, 1, 1, Cin, Cout, act, (hipStream_t)stream);
+    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, 1, 1, Cin, Cout, act, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int rn_conv2d_wino4_supported(int Cin, int Cout) { return rn_wino4_supported(Cin, Cout) ? 1 : 0; }
+
+extern "C" int rn_conv2d_wino4_fwd(const float* x, const float* w_wino4, const float* bias, const float* alpha,
+                                   const float* residual, float* y, float* preact,
+                                   int B, int H, int W, int Cin, int Cout, int transposed, int act, void* stream)
+{
+    if (!x || !w_wino4 || !y) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino4_fwd: null pointer");
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino4_fwd: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino4_fwd: PReLU needs alpha");
+    // TF SAME for k = 4, s = 1: pad_before 1; the stride-1 transposed conv is the flipped conv with pad_before 4-1-1 = 2
+    return rn_launch_conv_wino(x, w_wino4, bias, alpha, residual, y, preact, B, H, W, 1, 1, Cin, Cout, act, 1, transposed ? 2 : 1,
+                               (hipStream_t)stream);
 }
 
 extern "C" int rn_conv3d_wino_supported(int Cin, int Cout) { return rn_wino3d_supported(Cin, Cout) ? 1 : 0; }
@@ -112,7 +126,7 @@ extern "C" int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const flo
     if (!x || !w_wino || !y) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: null pointer");
     if (B < 1 || H < 1 || W < 1 || D < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv3d_wino_fwd: PReLU needs alpha");
-    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, D, 3, Cin, Cout, act, (hipStream_t)stream);
+    return rn_launch_conv_wino(x, w_wino, bias, alpha, residual, y, preact, B, H, W, D, 3, Cin, Cout, act, 0, 1, (hipStream_t)stream);
 }
 
 // Transposed conv, TF SAME with output = in*s (input-gradient of the SAME forward conv):

@@ -120,6 +120,109 @@ static int launch_tiled(const RnConvProblem& p, hipStream_t st)
     return rn_check_launch("conv_tiled");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The 5-channel stem of the texture net (e_conv1: 5^3 stride 2, 5 -> 8; RenderNet_Texture_Face_Normal.py:52-55).  Its
+// input box does not fit LDS at a useful tile size (5 channels x a (2T+3)^3 halo), and with one output per thread the
+// 625 taps x 8 channels are bound by the broadcast filter reads (two ds_read_b128 per input value: 4.9-5.5 ms).  Here a
+// thread owns OPT consecutive outputs along the depth axis: per (k0, k1) filter row it loads its window of
+// ((OPT-1)*S2 + K2) positions x CIN floats -- contiguous in channels-last memory -- ONCE into registers, and every filter
+// value read from LDS feeds OPT outputs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int K0, int K1, int K2, int S0, int S1, int S2, int CIN, int CO, int OPT>
+__global__ __launch_bounds__(256)
+void conv_rows_kernel(const TiledArgs2 a)
+{
+    constexpr int KTOT = K0 * K1 * K2 * CIN;
+    constexpr int WIN = ((OPT - 1) * S2 + K2) * CIN;       // floats in a thread's row window
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);           // [KTOT][CO]
+    for (int i = threadIdx.x; i < KTOT * CO; i += 256) {
+        const int k = i / CO, n = i % CO;
+        wl[i] = (n < a.Cout) ? a.w[((size_t)(k >> 2) * a.Npad + n) * 4 + (k & 3)] : 0.f;
+    }
+    __syncthreads();
+    const int nq = (a.O2 + OPT - 1) / OPT;                // output groups along depth
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= (long long)a.B * a.O0 * a.O1 * nq) return;
+    long long t = m;
+    const int q = (int)(t % nq); t /= nq;
+    const int o1 = (int)(t % a.O1); t /= a.O1;
+    const int o0 = (int)(t % a.O0); const int b = (int)(t / a.O0);
+    const int i2base = q * OPT * S2 - a.P2;
+
+    float acc[OPT][CO];
+#pragma unroll
+    for (int j = 0; j < OPT; ++j)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[j][n] = 0.f;
+    for (int k0 = 0; k0 < K0; ++k0) {
+        const int i0 = o0 * S0 - a.P0 + k0;
+        if ((unsigned)i0 >= (unsigned)a.I0) continue;
+        for (int k1 = 0; k1 < K1; ++k1) {
+            const int i1 = o1 * S1 - a.P1 + k1;
+            if ((unsigned)i1 >= (unsigned)a.I1) continue;
+            const float* xr = a.x + (((size_t)b * a.I0 + i0) * a.I1 + i1) * a.I2 * CIN;
+            float xw[WIN];
+#pragma unroll
+            for (int e = 0; e < WIN; ++e) {
+                const int i2 = i2base + e / CIN;
+                xw[e] = ((unsigned)i2 < (unsigned)a.I2) ? xr[(long long)i2base * CIN + e] : 0.f;
+            }
+            const float* wr = wl + (size_t)((k0 * K1 + k1) * K2) * CIN * CO;
+#pragma unroll
+            for (int k2 = 0; k2 < K2; ++k2)
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    float wv[CO];
+#pragma unroll
+                    for (int n = 0; n < CO; ++n) wv[n] = wr[(k2 * CIN + c) * CO + n];
+#pragma unroll
+                    for (int j = 0; j < OPT; ++j) {
+                        const float xv = xw[(j * S2 + k2) * CIN + c];
+#pragma unroll
+                        for (int n = 0; n < CO; ++n) acc[j][n] = fmaf(xv, wv[n], acc[j][n]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < OPT; ++j) {
+        const int o2 = q * OPT + j;
+        if (o2 >= a.O2) break;
+        const size_t oo = ((((size_t)b * a.O0 + o0) * a.O1 + o1) * a.O2 + o2) * a.Cout;
+#pragma unroll
+        for (int n = 0; n < CO; ++n) {
+            if (n < a.Cout) {
+                float v = acc[j][n] + (a.bias ? a.bias[n] : 0.f);
+                if (a.z) a.z[oo + n] = v;
+                if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+                if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
+                if (a.res) v += a.res[oo + n];
+                if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                a.y[oo + n] = v;
+            }
+        }
+    }
+}
+
+template <int K0, int K1, int K2, int S0, int S1, int S2, int CIN, int CO, int OPT>
+static int launch_rows(const RnConvProblem& p, hipStream_t st)
+{
+    TiledArgs2 a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
+    a.B = p.B; a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2];
+    a.Cout = p.Cout; a.Npad = p.Npad; a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = p.P[2];
+    a.nt0 = a.nt1 = a.nt2 = 0; a.act = p.act;
+    const long long threads = (long long)p.B * p.O[0] * p.O[1] * ((p.O[2] + OPT - 1) / OPT);
+    const long long nb = (threads + 255) / 256;
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_rows: bad grid %lld", nb);
+    const size_t lds = (size_t)K0 * K1 * K2 * CIN * CO * sizeof(float);
+    auto kern = conv_rows_kernel<K0, K1, K2, S0, S1, S2, CIN, CO, OPT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch("conv_rows");
+}
+
 static bool is_plain(const RnConvProblem& p)
 {
     // contiguous channels-last output covering the whole grid (no sub-pixel phase addressing)
@@ -134,10 +237,9 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     if (off || !is_plain(p)) return RN_E_UNSUPPORTED;
     const bool k555s2 = p.K[0] == 5 && p.K[1] == 5 && p.K[2] == 5 && p.S[0] == 2 && p.S[1] == 2 && p.S[2] == 2;
     if (k555s2 && p.Cout == 8 && p.Cin == 1) return launch_tiled<5, 5, 5, 2, 2, 2, 1, 8, 4, 4, 16>(p, st);
-    // the texture net's 5-channel stem: 625 taps x 8 channels per output make it LDS-instruction-bound on the broadcast
-    // filter reads (2 ds_read_b128 per input value); tile 4x8x16 (512 threads): 4.9 ms, 4x4x16: 5.5, 2x4x16: 6.7, the generic
-    // direct kernel: 5.0 ms.  Next step if it matters: several outputs per thread sharing each filter read.
-    if (k555s2 && p.Cout == 8 && p.Cin == 5) return launch_tiled<5, 5, 5, 2, 2, 2, 5, 8, 4, 8, 16>(p, st);
+    // the texture net's 5-channel stem (LDS-tiled with one output per thread: 5.5 ms at tile 4x4x16; the generic direct
+    // kernel: 5.0 ms): four outputs per thread along the depth axis, row windows in registers
+    if (k555s2 && p.Cout == 8 && p.Cin == 5) return launch_rows<5, 5, 5, 2, 2, 2, 5, 8, 4>(p, st);
     // (e_conv2 -- 3^3 stride (1,1,2), 8 -> 16 -- measured 0.98 ms tiled vs 0.79 ms with the generic direct kernel: its 8-float
     //  channel runs already coalesce, and 16 accumulators x 216 taps leave the tile's 4 waves per CU latency-bound.  Not routed here.)
     static const bool tiled_e2 = getenv("RN_TILED_ECONV2") != nullptr;

@@ -35,7 +35,8 @@ struct WinoArgs {
     int KD;                     // depth taps (1 or 3)
     int bh, bw;                 // 16x8-tile blocks per image along H (16 rows each) and W (32 columns each)
     int mblocks, nblocks;       // B*D*bh*bw, Cout/32
-    int spt;                    // 16-channel steps per depth tap = Cin/16; the K loop has KD*spt steps
+    int spt;                    // 16-channel steps per depth tap = Cin/16; the K loop has KD*spt steps (x4 sub-filters for 4x4)
+    int pad;                    // pad_lo of the conv: 1 (3x3, 4x4 SAME) or 2 (4x4 flipped conv of a stride-1 transposed conv)
     int act;
 };
 
@@ -44,11 +45,16 @@ constexpr int WPW = 34, WPH = 18;         // patch: 32+2 columns, 16+2 rows
 constexpr int WNPIX = WPW * WPH;          // 612
 constexpr int WRAW_PIECES = 40;           // 1 KiB DMA pieces of 16 pixels x 64 B (612 -> 640 pixel slots: 5 per wave)
 constexpr int WRAW_B = WRAW_PIECES * 1024;   // bytes per raw stage (40 960)
-constexpr int WU_B = 16 * 4 * 32 * 16;    // bytes per U stage (32 768)
 constexpr unsigned WOOB = 0x80000000u;
+// MODE 0: F(2x2,3x3), 16 xi planes, 4x4 input tiles.  MODE 1: a 4x4 filter as four 2x2 sub-filters, each F(2x2,2x2): 9 xi
+// planes, 3x3 input tiles, the sub-filters are four consecutive K steps that read the patch shifted by (2a, 2b) pixels.
+constexpr int wino_nxi(int mode) { return mode ? 9 : 16; }
+constexpr int wino_upieces(int mode, int nt) { return wino_nxi(mode) * nt; }          // 1-KiB filter pieces per step
+constexpr int wino_upw(int mode, int nt) { return (wino_upieces(mode, nt) + 7) / 8; }   // ... per wave
+constexpr int wino_ustage(int mode, int nt) { return wino_upw(mode, nt) * 8 * 1024; }    // bytes per filter stage
 }
 
-size_t rn_wino_lds_bytes() { return (size_t)2 * WRAW_B + 2 * WU_B; }
+static size_t wino_lds_bytes(int mode, int nt) { return (size_t)2 * WRAW_B + 2 * (size_t)wino_ustage(mode, nt); }
 
 __device__ __forceinline__ f32x4 pk_add(f32x4 x, f32x4 y)
 {
@@ -73,16 +79,20 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 x, f32x4 y)
 struct WinoBlock {
     int by, bx, dz, b, nb;      // 16x8-tile block (rows by*16.., columns bx*32..), depth slice, batch item, n-block
     int s_begin, s_end;         // K steps [s_begin, s_end) of 16 channels
-    unsigned roff[5];           // raw-patch DMA: per-lane byte offset of piece wave + 8 i at step 0 (WOOB = zero fill)
-    unsigned uoff;              // filter DMA: per-lane byte offset of this wave's first KiB at step 0
+    unsigned roff[5];           // raw-patch DMA: per-lane byte offset of piece wave + 8 i at channel step 0.  MODE 0: WOOB
+                                // where SAME padding applies (zero fill).  MODE 1: the offset for sub-filter 0, unmasked --
+                                // sub-filter (a, b) adds the constant (2a*W + 2b)*pix_bytes and tests its bit of vmask
+    unsigned vmask;             // MODE 1: bit sub*5 + i = piece i's pixel is inside the image for sub-filter `sub`
+    unsigned uoff;              // filter DMA: per-lane byte offset of piece `wave` at step 0
 };
 
 // work item `id` (0 <= id < mblocks*nblocks) -> block.  Enumeration e: groups of 8 m-blocks, n-major inside a group, so
 // that the 32 workgroups of one XCD (id % 8; one workgroup per CU, persistent, round r works on id = r*G + blockIdx)
 // stream 4 filter slabs and 8 patches between them, and the 8 XCDs of a round of 256 read the same 8 patches.
-template <int NT>
+template <int NT, int MODE>
 __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, int lane, WinoBlock& k)
 {
+    constexpr int NSUB = MODE ? 4 : 1;
     const int T = a.mblocks * a.nblocks;
     int e = id;
     if (id < (T & ~255)) { const int s = id >> 3; e = (s >> 5) * 256 + (id & 7) * 32 + (s & 31); }
@@ -97,25 +107,35 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
     // channels-last [B,H,W,D,C] the conv IS a 2-D conv with 3*Cin channels per depth slice.  A depth tap outside the
     // volume (SAME padding) is a run of `spt` whole steps of zeros: those steps are skipped.
     k.s_begin = (a.KD == 3 && k.dz == 0) ? a.spt : 0;
-    k.s_end = a.KD * a.spt - ((a.KD == 3 && k.dz == a.D - 1) ? a.spt : 0);
+    k.s_end = a.KD * a.spt * NSUB - ((a.KD == 3 && k.dz == a.D - 1) ? a.spt : 0);
     const unsigned pix_bytes = (unsigned)a.D * (unsigned)a.Cin * 4u;
     const unsigned win_off = (unsigned)((k.dz - (a.KD == 3 ? 1 : 0)) * a.Cin * 4);   // may wrap below 0: only used with s >= s_begin
-    const int y0 = k.by * 16 - 1, x0 = k.bx * 32 - 1;
     // raw-patch DMA: piece p = wave + 8 i (i < 5) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane fetches
     // LOGICAL chunk (lane%4) ^ swz(px) into physical slot lane%4, swz(px) = (px>>1)&3 (two lanes of a ds_read_b128
     // group at most share a 16-B slot)
+    k.vmask = 0u;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int p = wave + 8 * i;
         const int q = p * 16 + (lane >> 2);
         const int py = q / WPW, px = q - py * WPW;
-        const int iy = y0 + py, ix = x0 + px;
-        const bool ok = q < WNPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const unsigned o = (unsigned)((k.b * a.H + iy) * a.W + ix) * pix_bytes + win_off;
-        k.roff[i] = ok ? o + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16) : WOOB;
+        const int iy = k.by * 16 - a.pad + py, ix = k.bx * 32 - a.pad + px;
+        const unsigned o = (unsigned)((k.b * a.H + iy) * a.W + ix) * pix_bytes + win_off + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16);
+        if (MODE == 0) {
+            const bool ok = q < WNPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            k.roff[i] = ok ? o : WOOB;
+        } else {
+            k.roff[i] = o;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const bool ok = q < WNPIX && (unsigned)(iy + 2 * (sub >> 1)) < (unsigned)a.H && (unsigned)(ix + 2 * (sub & 1)) < (unsigned)a.W;
+                k.vmask |= ok ? (1u << (sub * 5 + i)) : 0u;
+            }
+        }
     }
-    // filter DMA: the 16*NT KiB piece of (nb, step) is lane-linear; wave w moves KiB 2NT*w .. 2NT*w + 2NT-1
-    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt)) * (16384u * NT) + (unsigned)wave * (2048u * NT) + (unsigned)lane * 16u;
+    // filter DMA: the piece of (nb, step) is lane-linear, 1 KiB per instruction; wave w moves pieces w, w + 8, ...
+    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt * NSUB)) * (1024u * wino_upieces(MODE, NT)) + (unsigned)wave * 1024u +
+             (unsigned)lane * 16u;
 }
 
 // PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
@@ -128,7 +148,7 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
 // with 6 K steps per item (the 3-D encoder layers) prologue + epilogue used to cost as much as the steps themselves.
 // NT = 16-channel n-tiles per wave: 2 (32 output channels per workgroup; Cout % 32 == 0) or 1 (Cout % 16 == 0 only: the
 // 16-wide 3-D encoder of the texture net).  The filter pack's n-block is 16*NT wide (misc_kernels.hip: pack_wino_kernel).
-template <int PROBE, int NT>
+template <int PROBE, int NT, int MODE>
 __global__ __launch_bounds__(512, 1)
 void conv_wino_kernel(const WinoArgs a)
 {
@@ -153,11 +173,13 @@ void conv_wino_kernel(const WinoArgs a)
         raddr0[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
     const unsigned uaddr0 = (unsigned)(2 * WRAW_B + kq * (256 * NT) + l16 * 16);
 
-    constexpr int NDMA = 5 + 2 * NT;               // DMA instructions per wave and step: 5 raw-patch + 2NT filter pieces
-    constexpr unsigned USTEP = 16384u * NT;        // filter bytes per step and n-block
-    f32x4 acc[16][NT];
+    constexpr int NXI = wino_nxi(MODE), TP = MODE ? 3 : 4, NSUB = MODE ? 4 : 1;
+    constexpr int UPW = wino_upw(MODE, NT), UPIECES = wino_upieces(MODE, NT), WU_B = wino_ustage(MODE, NT);
+    constexpr int NDMA = 5 + UPW;                  // DMA instructions per wave and step: 5 raw-patch + UPW filter pieces
+    constexpr unsigned USTEP = 1024u * UPIECES;    // filter bytes per step and n-block
+    f32x4 acc[NXI][NT];
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int t = 0; t < NXI; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -172,38 +194,46 @@ void conv_wino_kernel(const WinoArgs a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(smem + (st_) * WRAW_B + (wave + 8 * (idx_)) * 1024), \
                                                      16, ro_[(idx_) < 5 ? (idx_) : 0], 0, 0, 0);          \
         } else {                                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (st_) * WU_B + (wave * 2 * NT + (idx_) - 5) * 1024), \
-                                                     16, uo_, us_ + (unsigned)((idx_) - 5) * 1024u, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(smem + 2 * WRAW_B + (st_) * WU_B + (wave + 8 * ((idx_) - 5)) * 1024), \
+                                                     16, (UPIECES % 8 != 0 && wave + 8 * ((idx_) - 5) >= UPIECES) ? WOOB : uo_, \
+                                                     us_ + (unsigned)((idx_) - 5) * 8192u, 0, 0);          \
         }                                                                                                 \
     }
-    // 4x4 input transform of one xi row: t = (B^T d)[i][*], v = t B
+    // input transform of one xi row i: t = (B^T d)[i][*], v = t B.  MODE 0: B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];
+    // MODE 1 (F(2,2)): B^T = [[1,-1,0],[0,1,0],[0,1,-1]]
 #define WINO_ROW(i)                                                                                       \
-            f32x4 t_[4], v_[4];                                                                           \
+            f32x4 t_[TP], v_[TP];                                                                         \
             if (PROBE & 1) {                                                                              \
-                _Pragma("unroll") for (int bi = 0; bi < 4; ++bi) v_[bi] = d_[i][bi];                      \
+                _Pragma("unroll") for (int bi = 0; bi < TP; ++bi) v_[bi] = d_[i][bi];                     \
+            } else if (MODE == 1) {                                                                       \
+                _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                                          \
+                    t_[bi] = i == 0 ? pk_sub(d_[0][bi], d_[1][bi]) : i == 1 ? d_[1][bi] : pk_sub(d_[1][bi], d_[2][bi]); \
+                v_[0] = pk_sub(t_[0], t_[1]); v_[1] = t_[1]; v_[2] = pk_sub(t_[1], t_[2]);                \
+                asm volatile("s_nop 1" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]));                          \
             } else if (!(PROBE & 4)) {                                                                    \
                 _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                          \
                     t_[bi] = i == 0 ? pk_sub(d_[0][bi], d_[2][bi]) : i == 1 ? pk_add(d_[1][bi], d_[2][bi]) \
-                           : i == 2 ? pk_sub(d_[2][bi], d_[1][bi]) : pk_sub(d_[1][bi], d_[3][bi]);        \
+                           : i == 2 ? pk_sub(d_[2][bi], d_[1][bi]) : pk_sub(d_[1][bi], d_[TP - 1][bi]);   \
                 v_[0] = pk_sub(t_[0], t_[2]); v_[1] = pk_add(t_[1], t_[2]); v_[2] = pk_sub(t_[2], t_[1]); \
-                v_[3] = pk_sub(t_[1], t_[3]);                                                             \
-                asm volatile("s_nop 1" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[3]));             \
+                v_[TP - 1] = pk_sub(t_[1], t_[TP - 1]);                                                   \
+                asm volatile("s_nop 1" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[TP - 1]));        \
             } else {                                                                                      \
                 _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                          \
                     t_[bi] = i == 0 ? d_[0][bi] - d_[2][bi] : i == 1 ? d_[1][bi] + d_[2][bi]              \
-                           : i == 2 ? d_[2][bi] - d_[1][bi] : d_[1][bi] - d_[3][bi];                      \
-                v_[0] = t_[0] - t_[2]; v_[1] = t_[1] + t_[2]; v_[2] = t_[2] - t_[1]; v_[3] = t_[1] - t_[3]; \
+                           : i == 2 ? d_[2][bi] - d_[1][bi] : d_[1][bi] - d_[TP - 1][bi];                 \
+                v_[0] = t_[0] - t_[2]; v_[1] = t_[1] + t_[2]; v_[2] = t_[2] - t_[1]; v_[TP - 1] = t_[1] - t_[TP - 1]; \
             }
 
     WinoBlock cur, nxt;
     int id = blockIdx.x;
     if (id >= T) return;
-    wino_block<NT>(a, id, wave, lane, cur);
+    wino_block<NT, MODE>(a, id, wave, lane, cur);
     int stage = 0;
     {   // the first step of the first item
         unsigned ro_[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) ro_[i] = cur.roff[i] + (unsigned)cur.s_begin * 64u;
+        for (int i = 0; i < 5; ++i)
+            ro_[i] = (MODE == 0 || ((cur.vmask >> i) & 1u)) ? cur.roff[i] + (unsigned)(cur.s_begin / NSUB) * 64u : WOOB;
         const unsigned uo_ = cur.uoff, us_ = (unsigned)cur.s_begin * USTEP;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) WINO_DMA_ONE(0, i);
@@ -213,21 +243,30 @@ void conv_wino_kernel(const WinoArgs a)
 
     for (;;) {
         const bool has_next = id + G < T;
-        if (has_next) wino_block<NT>(a, id + G, wave, lane, nxt);
+        if (has_next) wino_block<NT, MODE>(a, id + G, wave, lane, nxt);
         for (int s = cur.s_begin; s < cur.s_end; ++s) {
             // what the other stage receives during this step: the item's next step, or the next item's first, or nothing
             const bool last = s + 1 == cur.s_end;
             const bool fetch = !last || has_next;
             unsigned ro_[5];
+            const int sn = s + 1;                 // the item's next step: sub-filter sn % NSUB of channel step sn / NSUB
+            // MODE 1: sub-filter sn & 3 = (a, b) reads the patch shifted by (2a, 2b) pixels
+            const unsigned sd_ = MODE == 0 ? 0u : (unsigned)((((sn >> 1) & 1) * 2 * a.W + (sn & 1) * 2) * a.Cin * 4);
+            const unsigned vm_ = MODE == 0 ? ~0u : last ? nxt.vmask : cur.vmask >> ((sn & 3) * 5);
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
-                ro_[i] = !fetch ? WOOB : last ? nxt.roff[i] + (unsigned)nxt.s_begin * 64u : cur.roff[i] + (unsigned)(s + 1) * 64u;
+            for (int i = 0; i < 5; ++i) {
+                const unsigned o_ = last ? nxt.roff[i] + (unsigned)(nxt.s_begin / NSUB) * 64u : cur.roff[i] + sd_ + (unsigned)(sn / NSUB) * 64u;
+                ro_[i] = (!fetch || !((vm_ >> i) & 1u)) ? WOOB : o_;
+            }
             const unsigned uo_ = !fetch ? WOOB : last ? nxt.uoff : cur.uoff;
-            const unsigned us_ = !fetch ? 0u : last ? (unsigned)nxt.s_begin * USTEP : (unsigned)(s + 1) * USTEP;
+            const unsigned us_ = !fetch ? 0u : last ? (unsigned)nxt.s_begin * USTEP : (unsigned)sn * USTEP;
             const int st1 = stage ^ 1;
             if ((PROBE & 10) == 8) {
 #pragma unroll
                 for (int i = 0; i < NDMA; ++i) WINO_DMA_ONE(st1, i);
+            } else if (!(PROBE & 10)) {
+#pragma unroll
+                for (int i = NXI; i < NDMA; ++i) WINO_DMA_ONE(st1, i);      // more DMAs than xi groups to hide them behind
             }
             // one 16-channel step on `stage`; the nine DMAs are issued one at a time behind the MFMA groups of xi 0..8
             // (all at the top of the step: 7.64 ms instead of 7.10 on res2 -- they stall the step's head)
@@ -236,30 +275,30 @@ void conv_wino_kernel(const WinoArgs a)
             unsigned ua_ = uaddr0 + (unsigned)stage * WU_B;
             asm volatile("" : "+v"(ua_));     // opaque: ONE base register + 16-bit immediates for the 32 filter-fragment reads
             const char* ub_ = smem + ua_;
-            f32x4 d_[4][4];
+            f32x4 d_[TP][TP];
 #pragma unroll
-            for (int ai = 0; ai < 4; ++ai)
+            for (int ai = 0; ai < TP; ++ai)
 #pragma unroll
-                for (int bi = 0; bi < 4; ++bi)
+                for (int bi = 0; bi < TP; ++bi)
                     d_[ai][bi] = *reinterpret_cast<const f32x4*>(((bi >> 1) ? rb1_ : rb0_) + (ai * WPW + bi) * 64);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TP; ++i) {
                 WINO_ROW(i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
+                for (int jj = 0; jj < TP; ++jj) {
                     f32x4 b_[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        b_[nt] = *reinterpret_cast<const f32x4*>(ub_ + (i * 4 + jj) * (1024 * NT) + nt * 256);
+                        b_[nt] = *reinterpret_cast<const f32x4*>(ub_ + (i * TP + jj) * (1024 * NT) + nt * 256);
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_) {
                         // A operand = filter fragment, B operand = transformed-input fragment: the accumulator then holds
                         // FOUR CONSECUTIVE CHANNELS of one tile per lane (rows = channels), which the epilogue stores as 16 B
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[i * 4 + jj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_[nt][s_], v_[jj][s_], acc[i * 4 + jj][nt], 0, 0, 0);
+                            acc[i * TP + jj][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_[nt][s_], v_[jj][s_], acc[i * TP + jj][nt], 0, 0, 0);
                     }
-                    if (!(PROBE & 10) && i * 4 + jj < NDMA) WINO_DMA_ONE(st1, i * 4 + jj);
+                    if (!(PROBE & 10) && i * TP + jj < NDMA) WINO_DMA_ONE(st1, i * TP + jj);
                 }
             }
             if (!last) {
@@ -280,21 +319,27 @@ void conv_wino_kernel(const WinoArgs a)
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
             const f32x4 av = a.alpha ? *reinterpret_cast<const f32x4*>(a.alpha + n) : zero4;
-            f32x4 c_[4][2];                      // column transform of every xi row: M[i][*] A
+            f32x4 c_[TP][2];                     // column transform of every xi row: M[i][*] A
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                c_[i][0] = (acc[i * 4 + 0][nt] + acc[i * 4 + 1][nt]) + acc[i * 4 + 2][nt];
-                c_[i][1] = (acc[i * 4 + 1][nt] - acc[i * 4 + 2][nt]) - acc[i * 4 + 3][nt];
+            for (int i = 0; i < TP; ++i) {
+                if (MODE == 1) {                 // F(2,2): A^T = [[1,1,0],[0,1,-1]]
+                    c_[i][0] = acc[i * 3 + 0][nt] + acc[i * 3 + 1][nt];
+                    c_[i][1] = acc[i * 3 + 1][nt] - acc[i * 3 + 2][nt];
+                } else {
+                    c_[i][0] = (acc[i * TP + 0][nt] + acc[i * TP + 1][nt]) + acc[i * TP + 2][nt];
+                    c_[i][1] = (acc[i * TP + 1][nt] - acc[i * TP + 2][nt]) - acc[i * TP + TP - 1][nt];
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i][nt] = zero4;
+            for (int i = 0; i < NXI; ++i) acc[i][nt] = zero4;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int oy = cur.by * 16 + 2 * ty + dy, ox = cur.bx * 32 + 2 * tx + dx;
                     if (oy < a.H && ox < a.W) {
-                        f32x4 v = dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[3][dx];
+                        f32x4 v = MODE == 1 ? (dy == 0 ? c_[0][dx] + c_[1][dx] : c_[1][dx] - c_[2][dx])
+                                            : (dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[TP - 1][dx]);
                         v += bv;
                         const size_t oo = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + n;
                         if (a.z) *reinterpret_cast<f32x4*>(a.z + oo) = v;
@@ -339,14 +384,38 @@ bool rn_wino3d_supported(int Cin, int Cout)
     return !off && rn_wino_supported(Cin, Cout);
 }
 
-// x [B,H,W,(D,)Cin] -> y [B,H,W,(D,)Cout], 3x3(x3) stride 1 SAME; u from rn_pack_weights(RN_PACK_CONV_WINO |
-// RN_PACK_CONVT_S1_WINO) with the matching ndim.  D = 1, KD = 1: 2-D.  KD = 3: 3-D (D >= 1).
-int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
-                        float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act, hipStream_t st)
+bool rn_wino4_supported(int Cin, int Cout)
 {
-    if (Cin % 16 != 0 || Cout % 16 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (both must be multiples of 16)", Cin, Cout);
-    if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1)) return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d", D, KD);
+    static const bool off = getenv("RN_NO_WINOGRAD4") != nullptr;
+    return !off && rn_wino_supported(Cin, Cout) && Cout % 32 == 0;
+}
+
+// 16-channel n-tiles per wave; rn_pack_weights follows the same rule (misc_kernels.hip)
+int rn_wino_ntiles(int mode, int Cout) { return mode ? (Cout % 64 == 0 ? 4 : 2) : (Cout % 32 == 0 ? 2 : 1); }
+
+template <int PROBE, int NT, int MODE>
+static void wino_launch(const WinoArgs& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = wino_lds_bytes(MODE, NT);
+    auto kern = conv_wino_kernel<PROBE, NT, MODE>;
+    // per launch: the attribute is per device, and a process may drive several
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+}
+
+// x [B,H,W,(D,)Cin] -> y [B,H,W,(D,)Cout], stride 1.
+//   mode 0: 3x3(x3) SAME conv, u from rn_pack_weights(RN_PACK_CONV_WINO | RN_PACK_CONVT_S1_WINO) with the matching ndim;
+//           D = 1, KD = 1: 2-D.  KD = 3: 3-D (D >= 1).
+//   mode 1: 4x4 2-D conv with pad_lo = pad (1: SAME conv; 2: the flipped conv of a stride-1 transposed conv), u from
+//           rn_pack_weights(RN_PACK_CONV_WINO4 | RN_PACK_CONVT_S1_WINO4).
+int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
+                        float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
+                        int mode, int pad, hipStream_t st)
+{
+    if (Cin % 16 != 0 || Cout % 16 != 0 || (mode && Cout % 32 != 0))
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (multiples of 16; 4x4 filters: Cout %% 32 == 0)", Cin, Cout);
+    if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1) || (mode && KD != 1) || (mode != 0 && mode != 1))
+        return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d mode=%d", D, KD, mode);
     const long long per_item = (long long)H * W * D * Cin * 4;
     if (per_item >= 0x80000000LL)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: one batch item of %lld bytes exceeds the 2 GiB buffer window", per_item);
@@ -358,7 +427,7 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
             const int nbi = B - b0 < chunk ? B - b0 : chunk;
             const int rc = rn_launch_conv_wino(x + (size_t)b0 * (per_item / 4), u, bias, alpha,
                                                residual ? residual + b0 * ostep : nullptr, y + b0 * ostep,
-                                               preact ? preact + b0 * ostep : nullptr, nbi, H, W, D, KD, Cin, Cout, act, st);
+                                               preact ? preact + b0 * ostep : nullptr, nbi, H, W, D, KD, Cin, Cout, act, mode, pad, st);
             if (rc != RN_OK) return rc;
         }
         return RN_OK;
@@ -368,27 +437,21 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.alpha = alpha; a.res = residual; a.y = y; a.z = preact;
     a.x_bytes = (unsigned)(per_item * B);
-    const long long ub = 16LL * KD * Cin * Cout * 4;
+    const long long ub = (mode ? 36LL : 16LL * KD) * Cin * Cout * 4;
     if (ub >= 0x80000000LL) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: transformed filter of %lld bytes exceeds 2 GiB", ub);
     a.u_bytes = (unsigned)ub;
     a.B = B; a.H = H; a.W = W; a.D = D; a.KD = KD; a.Cin = Cin; a.Cout = Cout;
     a.bh = (H + 15) / 16; a.bw = (W + 31) / 32;
     const long long mbl = (long long)B * D * a.bh * a.bw;
-    const int NTv = Cout % 32 == 0 ? 2 : 1;         // 16-channel n-tiles per wave (the filter pack follows the same rule)
+    const int NTv = rn_wino_ntiles(mode, Cout);
     a.nblocks = Cout / (16 * NTv);
     if (mbl * a.nblocks > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wino: grid too large");
     a.mblocks = (int)mbl;
     a.spt = Cin / 16;
+    a.pad = pad;
     a.act = act;
     static const int probe = getenv("RN_WINO_PROBE") ? atoi(getenv("RN_WINO_PROBE")) : 0;
-    const size_t lds = rn_wino_lds_bytes();
-    auto kern = NTv == 1 ? conv_wino_kernel<0, 1>
-              : probe == 1 ? conv_wino_kernel<1, 2> : probe == 2 ? conv_wino_kernel<2, 2> : probe == 3 ? conv_wino_kernel<3, 2>
-              : probe == 4 ? conv_wino_kernel<4, 2> : probe == 8 ? conv_wino_kernel<8, 2> : probe == 12 ? conv_wino_kernel<12, 2>
-              : conv_wino_kernel<0, 2>;
-    // per launch: the attribute is per device, and a process may drive several
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // persistent grid: one workgroup per CU (147 KiB of LDS each), every one walking its share of the items
+    // persistent grid: one workgroup per CU (144-160 KiB of LDS each), every one walking its share of the items
     static int ncu[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -401,6 +464,19 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     static const int grid_env = getenv("RN_WINO_GRID") ? atoi(getenv("RN_WINO_GRID")) : 0;     // measurement: 0 = one per CU
     const long long want = grid_env > 0 ? grid_env : ncu[dev];
     const unsigned grid = (unsigned)(total < want ? total : want);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    if (mode == 1) {
+        if (NTv == 4) wino_launch<0, 4, 1>(a, grid, st); else wino_launch<0, 2, 1>(a, grid, st);
+    } else if (NTv == 1) {
+        wino_launch<0, 1, 0>(a, grid, st);
+    } else {
+        switch (probe) {
+            case 1: wino_launch<1, 2, 0>(a, grid, st); break;
+            case 2: wino_launch<2, 2, 0>(a, grid, st); break;
+            case 3: wino_launch<3, 2, 0>(a, grid, st); break;
+            case 4: wino_launch<4, 2, 0>(a, grid, st); break;
+            case 8: wino_launch<8, 2, 0>(a, grid, st); break;
+            default: wino_launch<0, 2, 0>(a, grid, st);
+        }
+    }
     return rn_check_launch("conv_wino");
 }

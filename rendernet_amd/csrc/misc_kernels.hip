@@ -95,7 +95,52 @@ __global__ void pack_wino_kernel(const float* __restrict__ w_tf, float* __restri
     }
 }
 
+// 4x4 filters for the same kernel (MODE 1): the filter is the sum of FOUR 2x2 sub-filters h_ab = g[2a:2a+2, 2b:2b+2], each
+// transformed with F(2x2,2x2): U_ab = G2 h_ab G2^T, G2 = [[1,0],[1,1],[0,1]] (9 planes; 36 multiplies per 2x2 outputs and
+// channel pair instead of 64).  Packed [Cout/NB][(Cin/16)*4][9 xi][4 kq][NB n][4 r]: K step s = cstep*4 + (2a+b), channel
+// c = cstep*16 + kq*4 + r; NB = 64 when Cout % 64 == 0, else 32 (rn_wino_ntiles).  RN_PACK_CONV_WINO4 reads
+// w_tf[4,4,Cin,Cout]; RN_PACK_CONVT_S1_WINO4 reads w_tf[4,4,Cout,Cin] with the taps flipped.
+__global__ void pack_wino4_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int NB, int transposed)
+{
+    const size_t total = (size_t)36 * Cin * Cout;
+    const int nstep = Cin / 16 * 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t rem = idx;
+        const int r = (int)(rem & 3); rem >>= 2;
+        const int n = (int)(rem % NB); rem /= NB;
+        const int kq = (int)(rem & 3); rem >>= 2;
+        const int xi = (int)(rem % 9); rem /= 9;
+        const int step = (int)(rem % nstep);
+        const int nb = (int)(rem / nstep);
+        const int sub = step & 3, c = (step >> 2) * 16 + kq * 4 + r, co = nb * NB + n;
+        const int a = sub >> 1, b = sub & 1, i = xi / 3, j = xi % 3;
+        float h[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int t0 = 2 * a + p, t1 = 2 * b + q;
+                h[p][q] = transposed ? w_tf[((size_t)((3 - t0) * 4 + (3 - t1)) * Cout + co) * Cin + c]
+                                     : w_tf[((size_t)(t0 * 4 + t1) * Cin + c) * Cout + co];
+            }
+        float row[2];                               // (G2 h)[i][q]
+#pragma unroll
+        for (int q = 0; q < 2; ++q) row[q] = i == 0 ? h[0][q] : i == 1 ? h[0][q] + h[1][q] : h[1][q];
+        u[idx] = j == 0 ? row[0] : j == 1 ? row[0] + row[1] : row[1];
+    }
+}
+
 static bool is_wino_kind(int kind) { return kind == RN_PACK_CONV_WINO || kind == RN_PACK_CONVT_S1_WINO; }
+static bool is_wino4_kind(int kind) { return kind == RN_PACK_CONV_WINO4 || kind == RN_PACK_CONVT_S1_WINO4; }
+
+static int wino4_pack_check(int ndim, const int* kdims, int Cin, int Cout)
+{
+    if (!kdims || ndim != 2 || kdims[0] != 4 || kdims[1] != 4)
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the 4x4 Winograd packs need a 2-D 4x4 filter");
+    if (Cin < 16 || Cout < 32 || Cin % 16 != 0 || Cout % 32 != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the 4x4 Winograd packs need Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", Cin, Cout);
+    return RN_OK;
+}
 
 static int wino_pack_check(int ndim, const int* kdims, int Cin, int Cout)
 {
@@ -129,6 +174,7 @@ static int pack_geometry(int kind, int ndim, const int* kdims, int Cin, int Cout
 extern "C" size_t rn_packed_weight_floats(int kind, int ndim, const int* kdims, int Cin, int Cout)
 {
     if (is_wino_kind(kind)) return wino_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)16 * (ndim == 3 ? 3 : 1) * Cin * Cout : 0;
+    if (is_wino4_kind(kind)) return wino4_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)36 * Cin * Cout : 0;
     PackArgs a;
     if (pack_geometry(kind, ndim, kdims, Cin, Cout, a) != RN_OK) return 0;
     return (size_t)a.nphase * a.Kq * a.Npad * 4;
@@ -147,6 +193,16 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
         hipLaunchKernelGGL(pack_wino_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout, KD,
                            kind == RN_PACK_CONVT_S1_WINO ? 1 : 0);
         return rn_check_launch("pack_wino");
+    }
+    if (is_wino4_kind(kind)) {
+        const int rcw = wino4_pack_check(ndim, kdims, Cin, Cout);
+        if (rcw != RN_OK) return rcw;
+        if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
+        const size_t tot = (size_t)36 * Cin * Cout;
+        const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
+        hipLaunchKernelGGL(pack_wino4_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
+                           16 * rn_wino_ntiles(1, Cout), kind == RN_PACK_CONVT_S1_WINO4 ? 1 : 0);
+        return rn_check_launch("pack_wino4");
     }
     PackArgs a;
     int rc = pack_geometry(kind, ndim, kdims, Cin, Cout, a);

@@ -40,8 +40,11 @@ bool rn_drun_supported(const RnConvProblem& p);
 
 bool rn_wino_supported(int Cin, int Cout);                                                                 // conv_wino.hip
 bool rn_wino3d_supported(int Cin, int Cout);
+bool rn_wino4_supported(int Cin, int Cout);
+int rn_wino_ntiles(int mode, int Cout);
 int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
-                        float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act, hipStream_t st);
+                        float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
+                        int mode, int pad, hipStream_t st);
 
 int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const int* I, int Ca,
                          const int* O, int Cg, const int* K, const int* S, const int* P, hipStream_t st);   // conv_wgrad.hip

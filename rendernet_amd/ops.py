@@ -59,6 +59,15 @@ class PackedWeight:
                 raise L.RenderNetHipError("rn_packed_weight_floats (Winograd): %s" % lib.rn_last_error().decode())
             self.wino_kind = wkind
             self.wino = torch.empty(nw, dtype=torch.float32, device=w_tf.device)
+        # 4x4 stride-1 filters (e_conv5, e_conv6; e_conv7_1 as a transposed conv): four 2x2 sub-filters, each F(2x2,2x2)
+        self.wino4 = None
+        w4kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO4, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO4}.get(kind)
+        if w4kind is not None and ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_wino4_supported(self.cin, self.cout):
+            nw = lib.rn_packed_weight_floats(w4kind, ndim, L.ivec(self.kdims), self.cin, self.cout)
+            if nw == 0:
+                raise L.RenderNetHipError("rn_packed_weight_floats (Winograd 4x4): %s" % lib.rn_last_error().decode())
+            self.wino4_kind = w4kind
+            self.wino4 = torch.empty(nw, dtype=torch.float32, device=w_tf.device)
         self.repack()
 
     def repack(self):
@@ -68,6 +77,9 @@ class PackedWeight:
         if self.wino is not None:
             L.check(L.lib().rn_pack_weights(self.wino_kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
                                             L.ptr(self.w_tf), L.ptr(self.wino), L.stream_ptr()), "rn_pack_weights (Winograd)")
+        if self.wino4 is not None:
+            L.check(L.lib().rn_pack_weights(self.wino4_kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
+                                            L.ptr(self.w_tf), L.ptr(self.wino4), L.stream_ptr()), "rn_pack_weights (Winograd 4x4)")
         if self._dgrad is not None:
             self._dgrad.repack()
 
@@ -232,9 +244,13 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
         B, H, W, Cin = x.shape
         if pw.wino is not None and tuple(stride) == (1, 1):
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *a[2:], B, H, W, Cin, pw.cout, act, st)
+        if pw.wino4 is not None and tuple(stride) == (1, 1):
+            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *a[2:], B, H, W, Cin, pw.cout, 0, act, st)
         return lib.rn_conv2d_fwd_train(*a, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d_transpose":
         B, H, W, Cin = x.shape
+        if pw.wino4 is not None and int(stride[0]) == 1:
+            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *a[2:], B, H, W, Cin, pw.cout, 1, act, st)
         return lib.rn_conv2d_transpose_fwd_train(*a, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
     if mode == "conv3d_transpose":
         B, H, W, D, Cin = x.shape
@@ -325,6 +341,14 @@ class _Conv(torch.autograd.Function):
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
                 rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
                                             B, H, W, pw.cout, Cin, 0, st)
+            elif mode == "conv2d" and unit and dp.wino4 is not None:
+                # stride-1 4x4: the input gradient is the stride-1 transposed conv of the same filter
+                rc = lib.rn_conv2d_wino4_fwd(L.ptr(dz), L.ptr(dp.wino4), None, None, None, L.ptr(dx), None,
+                                             B, H, W, pw.cout, Cin, 1, 0, st)
+            elif mode == "conv2d_transpose" and unit and dp.wino4 is not None:
+                # ... and a stride-1 transposed conv's is the plain conv of the same filter
+                rc = lib.rn_conv2d_wino4_fwd(L.ptr(dz), L.ptr(dp.wino4), None, None, None, L.ptr(dx), None,
+                                             B, H, W, pw.cout, Cin, 0, 0, st)
             elif mode == "conv2d":
                 rc = lib.rn_conv2d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode == "conv2d_transpose":

@@ -372,3 +372,53 @@ def test_conv3d_winograd(case):
     L.check(L.lib().rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx_w), None, B, H, W, D, Cout, Cin, 0,
                                        L.stream_ptr()), "rn_conv3d_wino_fwd (dgrad)")
     _close(dx_w, OL.conv3d_transpose(dz.cpu().numpy(), w, None, (1, 1, 1)), "wino3d dgrad vs oracle")
+
+
+# 4x4 stride-1 filters through the Winograd kernel (four 2x2 sub-filters, F(2x2,2x2) each): e_conv5 / e_conv6 as convs
+# (SAME padding (1,2)), e_conv7_1 as a stride-1 transposed conv (the flipped conv, padding (2,1)), and their input gradients.
+WINO4_CASES = [
+    (2, 16, 16, 256, 128),      # e_conv5-like, Cout % 64 == 0 (four n-tiles per wave)
+    (1, 9, 11, 64, 32),         # ragged, two n-tiles
+    (1, 37, 70, 16, 96),
+    (3, 64, 64, 32, 64),
+    (1, 16, 16, 1024, 512),
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv2d_winograd_4x4(case):
+    from rendernet_amd import ops, _lib as L
+    from scripts.wino_emulate import pack_wino4
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (4, 4, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    assert pw.wino4 is not None
+    want_u = pack_wino4(w)
+    assert np.abs(pw.wino4.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    y0 = OL.conv2d(x, w, b, (1, 1))
+    _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "wino4")
+    res = _rand(rng, *y0.shape)
+    got = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+    _close(got, OL.prelu(y0, alpha) + torch.from_numpy(res), "wino4+prelu+res")
+    pd = ops.pack_conv(_dev(w))
+    pd.wino4 = None
+    direct = ops.conv2d(_dev(x), pd, _dev(b), _dev(alpha), _dev(res))
+    assert float((got - direct).abs().max()) <= 2e-5 * float(direct.abs().max())
+    # the transposed form: conv2d_transpose 4x4 stride 1 with a [4,4,Cout_T,Cin_T] filter (e_conv7_1), PReLU epilogue
+    wt = _xavier(rng, (4, 4, Cout, Cin))
+    pt = ops.pack_conv_transpose(_dev(wt), 1)
+    assert pt.wino4 is not None
+    want_t = OL.prelu(OL.conv2d_transpose(x, wt, b, (1, 1)), alpha)
+    _close(ops.conv2d_transpose(_dev(x), pt, _dev(b), _dev(alpha)), want_t, "wino4 transposed")
+    # input gradients: a conv's is the transposed form of its own filter, and vice versa
+    dz = _dev(_rand(rng, B, H, W, Cout))
+    dp = pw.dgrad_pack(True)
+    if dp.wino4 is not None:                                        # needs Cin % 32 == 0 (it is the output width there)
+        dx = torch.empty((B, H, W, Cin), device="cuda")
+        L.check(L.lib().rn_conv2d_wino4_fwd(L.ptr(dz), L.ptr(dp.wino4), None, None, None, L.ptr(dx), None, B, H, W, Cout, Cin, 1, 0,
+                                            L.stream_ptr()), "rn_conv2d_wino4_fwd (dgrad)")
+        _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino4 dgrad vs oracle")

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import layers as OL
-from scripts.wino_emulate import block_map, conv_wino_emulated, pack_wino
+from scripts.wino_emulate import block_map, conv_wino4_emulated, conv_wino_emulated, pack_wino, pack_wino4
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 37, 32, 64), (1, 16, 16, 16, 32), (1, 5, 33, 16, 32)])
@@ -64,4 +64,22 @@ def test_emulated_kernel_matches_the_oracle_conv3d(shape):
     wt = (rng.standard_normal((3, 3, 3, Cout, Cin)) * 0.1).astype(np.float32)     # conv3d_transpose layout [k,k,k,Cout,Cin]
     got = conv_wino_emulated(x, pack_wino(wt, transposed=True), Cout)
     want = OL.conv3d_transpose(x, wt, None, (1, 1, 1)).numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 37, 32, 64), (2, 9, 5, 16, 32)])
+def test_emulated_4x4_variant_matches_the_oracle(shape):
+    """MODE 1 of the kernel: a 4x4 filter as four 2x2 sub-filters (consecutive K steps reading the patch shifted by (2a, 2b)
+    pixels), each a Winograd F(2x2,2x2); SAME conv (pad 1,2) and the stride-1 transposed conv (flipped, pad 2,1)."""
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, Cin, Cout)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = conv_wino4_emulated(x, pack_wino4(w), Cout, 1, b)
+    want = OL.conv2d(x, w, b, (1, 1)).numpy()
+    assert not np.isnan(got).any() and np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    wt = (rng.standard_normal((4, 4, Cout, Cin)) * 0.1).astype(np.float32)
+    got = conv_wino4_emulated(x, pack_wino4(wt, True), Cout, 2)
+    want = OL.conv2d_transpose(x, wt, None, (1, 1)).numpy()
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
