@@ -56,7 +56,7 @@ extern "C" {
                                      rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
 
 #define RN_PACK_CONV_WINO4      5  /* TF conv filter [4,4,Cin,Cout] as four 2x2 sub-filters, each Winograd F(2x2,2x2)
-                                     transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 32 == 0) for
+                                     transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 16 == 0) for
                                      rn_conv2d_wino4_fwd                                                          */
 #define RN_PACK_CONVT_S1_WINO4  6  /* TF conv_transpose filter [4,4,Cout,Cin], stride 1, taps flipped, same transform:
                                      rn_conv2d_wino4_fwd with transposed = 1                                     */
@@ -170,7 +170,7 @@ int rn_conv3d_wino_supported(int Cin, int Cout);
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the
  * flipped conv with padding (2,1)), and their input gradients (a conv's is the transposed form of the same filter and vice
  * versa).  The 4x4 filter is the sum of four 2x2 sub-filters applied to the input shifted by (0|2, 0|2) pixels; each is a
- * Winograd F(2x2,2x2): 36 multiplies per 2x2 outputs and channel pair instead of 64, in fp32.  Cin % 16 == 0, Cout % 32 == 0. */
+ * Winograd F(2x2,2x2): 36 multiplies per 2x2 outputs and channel pair instead of 64, in fp32.  Cin % 16 == 0, Cout % 16 == 0. */
 int rn_conv2d_wino4_supported(int Cin, int Cout);
 int rn_conv2d_wino4_fwd(const float* x, const float* w_wino4, const float* bias, const float* alpha,
                         const float* residual, float* y, float* preact,

@@ -387,11 +387,11 @@ bool rn_wino3d_supported(int Cin, int Cout)
 bool rn_wino4_supported(int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD4") != nullptr;
-    return !off && rn_wino_supported(Cin, Cout) && Cout % 32 == 0;
+    return !off && rn_wino_supported(Cin, Cout);
 }
 
 // 16-channel n-tiles per wave; rn_pack_weights follows the same rule (misc_kernels.hip)
-int rn_wino_ntiles(int mode, int Cout) { return mode ? (Cout % 64 == 0 ? 4 : 2) : (Cout % 32 == 0 ? 2 : 1); }
+int rn_wino_ntiles(int mode, int Cout) { return mode ? (Cout % 64 == 0 ? 4 : Cout % 32 == 0 ? 2 : 1) : (Cout % 32 == 0 ? 2 : 1); }
 
 template <int PROBE, int NT, int MODE>
 static void wino_launch(const WinoArgs& a, unsigned grid, hipStream_t st)
@@ -412,8 +412,8 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
                         int mode, int pad, hipStream_t st)
 {
-    if (Cin % 16 != 0 || Cout % 16 != 0 || (mode && Cout % 32 != 0))
-        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (multiples of 16; 4x4 filters: Cout %% 32 == 0)", Cin, Cout);
+    if (Cin % 16 != 0 || Cout % 16 != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (both must be multiples of 16)", Cin, Cout);
     if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1) || (mode && KD != 1) || (mode != 0 && mode != 1))
         return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d mode=%d", D, KD, mode);
     const long long per_item = (long long)H * W * D * Cin * 4;
@@ -465,7 +465,9 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     const long long want = grid_env > 0 ? grid_env : ncu[dev];
     const unsigned grid = (unsigned)(total < want ? total : want);
     if (mode == 1) {
-        if (NTv == 4) wino_launch<0, 4, 1>(a, grid, st); else wino_launch<0, 2, 1>(a, grid, st);
+        if (NTv == 4) wino_launch<0, 4, 1>(a, grid, st);
+        else if (NTv == 2) wino_launch<0, 2, 1>(a, grid, st);
+        else wino_launch<0, 1, 1>(a, grid, st);
     } else if (NTv == 1) {
         wino_launch<0, 1, 0>(a, grid, st);
     } else {

@@ -137,8 +137,8 @@ static int wino4_pack_check(int ndim, const int* kdims, int Cin, int Cout)
 {
     if (!kdims || ndim != 2 || kdims[0] != 4 || kdims[1] != 4)
         return rn_set_error(RN_E_UNSUPPORTED, "pack: the 4x4 Winograd packs need a 2-D 4x4 filter");
-    if (Cin < 16 || Cout < 32 || Cin % 16 != 0 || Cout % 32 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the 4x4 Winograd packs need Cin %% 16 == 0 and Cout %% 32 == 0 (got %d, %d)", Cin, Cout);
+    if (Cin < 16 || Cout < 16 || Cin % 16 != 0 || Cout % 16 != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the 4x4 Winograd packs need Cin and Cout to be multiples of 16 (got %d, %d)", Cin, Cout);
     return RN_OK;
 }
 

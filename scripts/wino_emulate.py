@@ -48,8 +48,8 @@ def pack_wino4(w_tf, transposed=False):
     if transposed:
         w = w[::-1, ::-1].transpose(0, 1, 3, 2)
     cin, cout = w.shape[2], w.shape[3]
-    assert w.shape[:2] == (4, 4) and cin % 16 == 0 and cout % 32 == 0
-    NB = 64 if cout % 64 == 0 else 32
+    assert w.shape[:2] == (4, 4) and cin % 16 == 0 and cout % 16 == 0
+    NB = 64 if cout % 64 == 0 else 32 if cout % 32 == 0 else 16
     subs = []
     for a in range(2):
         for b in range(2):
@@ -68,7 +68,7 @@ def conv_wino4_emulated(x, u_packed, cout, pad_lo=1, bias=None):
     xf = np.ascontiguousarray(x, np.float32).reshape(-1)
     y = np.full((B, H, W, cout), np.nan, np.float32)
     bh, bw = (H + 15) // 16, (W + 31) // 32
-    NT = 4 if cout % 64 == 0 else 2
+    NT = 4 if cout % 64 == 0 else 2 if cout % 32 == 0 else 1
     NPIECE = 9 * NT                                                        # 1-KiB filter pieces per step: 9 xi x (4 kq x 16NT n x 16 B = NT KiB)
     UPW = -(-NPIECE // 8)                                                  # per wave (piece p = wave + 8 i; p >= NPIECE: nothing)
     USTEP = NPIECE * 1024

@@ -382,6 +382,7 @@ WINO4_CASES = [
     (1, 37, 70, 16, 96),
     (3, 64, 64, 32, 64),
     (1, 16, 16, 1024, 512),
+    (1, 40, 40, 32, 16),        # e_conv10's widths: one n-tile per wave
 ]
 
 

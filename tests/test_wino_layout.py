@@ -67,7 +67,7 @@ def test_emulated_kernel_matches_the_oracle_conv3d(shape):
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("shape", [(1, 20, 37, 32, 64), (2, 9, 5, 16, 32)])
+@pytest.mark.parametrize("shape", [(1, 20, 37, 32, 64), (2, 9, 5, 16, 32), (1, 7, 40, 32, 16)])
 def test_emulated_4x4_variant_matches_the_oracle(shape):
     """MODE 1 of the kernel: a 4x4 filter as four 2x2 sub-filters (consecutive K steps reading the patch shifted by (2a, 2b)
     pixels), each a Winograd F(2x2,2x2); SAME conv (pad 1,2) and the stride-1 transposed conv (flipped, pad 2,1)."""
