@@ -97,6 +97,15 @@ int rn_resample_affine_fwd(const float* vox, const float* m_inv, float* out,
                            int h0, int w0, int ph, int pw, int image_layout,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two sources resampled with ONE pose into ONE channel-concatenated output: the face renderer's
+ * `tf.concat([tf_rotation_resampling(geometry), tf_rotation_resampling(texture)], axis=4)`
+ * (RenderNet_Texture_Face_Normal.py:165-178; Reconstruct_RenderNet_Face.py:360-366).  vox_a [B,S,S,S,Ca],
+ * vox_b [B,S,S,S,Cb] -> out [B,ph,pw,N,Ca+Cb] (image layout / window as above).  `affine` != 0: the second-to-last
+ * pointer argument is M_inv [B,3,4] instead of the pose.  Bit-identical, channel by channel, to two rn_resample_* calls. */
+int rn_resample_concat_fwd(const float* vox_a, int Ca, const float* vox_b, int Cb, const float* pose_or_m_inv,
+                           int affine, float* out, int B, int S, int N, int h0, int w0, int ph, int pw,
+                           int image_layout, void* stream);
+
 /* pose [B,3] -> M_inv [B,3,4] (closed form of :526-602, evaluated in double). */
 int rn_pose_to_affine(const float* pose, float* m_inv, int B, int S, int N, void* stream);
 
@@ -307,6 +316,11 @@ int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B,
 int rn_resample_affine_bwd(const float* vox, const float* m_inv, const float* dout, float* dvox, float* dm,
                            int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout, void* stream);
 int rn_pose_to_affine_bwd(const float* pose, const float* dm, float* dpose, int B, int S, int N, void* stream);
+/* rn_resample_affine_bwd for one source of rn_resample_concat_fwd: dout holds dout_channels per sample and this source's C
+ * channels start at dout_offset.  One call per source; dm accumulates over them. */
+int rn_resample_affine_bwd_strided(const float* vox, const float* m_inv, const float* dout, int dout_channels,
+                                   int dout_offset, float* dvox, float* dm, int B, int S, int N, int C,
+                                   int h0, int w0, int ph, int pw, int image_layout, void* stream);
 
 /* tf.nn.dropout(x, keep_prob) = x / keep_prob * floor(keep_prob + U[0,1))  (RenderNet_Shader.py:39,43,47,88,103,107-123
  * with tools/layer_util.py:124-131; README default keep_prob 0.75 for training).  The uniforms come from a counter-based

@@ -25,6 +25,8 @@ SIGNATURES = {
     "rn_resample_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
     "rn_resample_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp, ctypes.c_size_t, _c_vp]),
     "rn_resample_affine_fwd": (_c_int, [_c_vp, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp, ctypes.c_size_t, _c_vp]),
+    "rn_resample_concat_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_vp] + [_c_int] * 8 + [_c_vp]),
+    "rn_resample_affine_bwd_strided": (_c_int, [_c_vp] * 3 + [_c_int, _c_int, _c_vp, _c_vp] + [_c_int] * 9 + [_c_vp]),
     "rn_pose_to_affine": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "rn_packed_weight_floats": (ctypes.c_size_t, [_c_int, _c_int, _ip, _c_int, _c_int]),
     "rn_pack_weights": (_c_int, [_c_int, _c_int, _ip, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),

@@ -195,6 +195,136 @@ void resample_kernel(const ResampleArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two sources, one pose, one output: the face renderer resamples the geometry grid and the decoded texture volume with
+// the SAME view parameters and concatenates them along the channel axis (RenderNet_Texture_Face_Normal.py:165-178;
+// Reconstruct_RenderNet_Face.py:360-366: tf_rotation_resampling x2 + tf.concat).  Here the coordinates, clamped taps and
+// weights of a sample are computed once and both volumes are gathered with them; the Ca + Cb channels of a sample are
+// written contiguously -- the concatenated tensor is produced directly, no [B,N^3,1] / [B,N^3,4] intermediates and no
+// concat copy (1 GB at batch 24).  Per channel the arithmetic is that of sample_point: bit-identical to the separate calls.
+// ------------------------------------------------------------------------------------------------------------------
+struct ConcatArgs {
+    const float* va; const float* vb_; const float* mat; float* out;
+    int B, S, N, Ca, Cb;
+    int h0, w0, ph, pw, image_layout;
+};
+
+// FAST14: Ca = 1, Cb = 4 (geometry + 4-channel texture volume, the face renderer): the texture taps are 16-byte loads and
+// a thread's 4 samples x 5 channels leave as five 16-byte stores.
+template <bool FROM_POSE, bool FAST14>
+__global__ __launch_bounds__(256)
+void resample_concat_kernel(const ConcatArgs a)
+{
+    __shared__ float msh[12];
+    const int N = a.N, Ct = a.Ca + a.Cb;
+    const int kthreads = N / 4, lines_per_block = 256 / kthreads;
+    const long long nlines = (long long)a.B * a.ph * a.pw;
+    const long long line0 = (long long)blockIdx.x * lines_per_block;
+    const int b = (int)(line0 / ((long long)a.ph * a.pw));
+    if (threadIdx.x == 0) {
+        if (FROM_POSE) pose_to_affine_dev(a.mat + 3 * b, a.S, N, msh);
+        else for (int q = 0; q < 12; ++q) msh[q] = a.mat[12 * b + q];
+    }
+    __syncthreads();
+    const long long line = line0 + threadIdx.x / kthreads;
+    if (line >= nlines) return;
+    const int k0 = (threadIdx.x % kthreads) * 4;
+    const int ij = (int)(line - (long long)b * a.ph * a.pw);
+    const int i = ij / a.pw + a.h0, j = ij % a.pw + a.w0;
+    const float gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
+    const float gz = a.image_layout ? (float)j : (float)i;
+    const size_t S3 = (size_t)a.S * a.S * a.S;
+    const float* pa = a.va + (size_t)b * S3 * a.Ca;
+    const float* pb = a.vb_ + (size_t)b * S3 * a.Cb;
+    float* op = a.out + ((size_t)line * N + k0) * Ct;
+    float r20[20];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float gx = (float)(k0 + q);
+        const float x = coord(msh[0], msh[1], msh[2], msh[3], gx, gy, gz);
+        const float y = coord(msh[4], msh[5], msh[6], msh[7], gx, gy, gz);
+        const float z = coord(msh[8], msh[9], msh[10], msh[11], gx, gy, gz);
+        const int mx = a.S - 1;
+        int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+        int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+        x0 = min(max(x0, 0), mx); x1 = min(max(x1, 0), mx);
+        y0 = min(max(y0, 0), mx); y1 = min(max(y1, 0), mx);
+        z0 = min(max(z0, 0), mx); z1 = min(max(z1, 0), mx);
+        const float ax = __fsub_rn((float)x1, x), bx = __fsub_rn(x, (float)x0);
+        const float ay = __fsub_rn((float)y1, y), by = __fsub_rn(y, (float)y0);
+        const float az = __fsub_rn((float)z1, z), bz = __fsub_rn(z, (float)z0);
+        const float w8[8] = {__fmul_rn(__fmul_rn(ax, ay), az), __fmul_rn(__fmul_rn(ax, by), az),
+                             __fmul_rn(__fmul_rn(bx, ay), az), __fmul_rn(__fmul_rn(bx, by), az),
+                             __fmul_rn(__fmul_rn(ax, ay), bz), __fmul_rn(__fmul_rn(ax, by), bz),
+                             __fmul_rn(__fmul_rn(bx, ay), bz), __fmul_rn(__fmul_rn(bx, by), bz)};
+        const int S2 = a.S * a.S;
+        const int i8[8] = {z0 * S2 + y0 * a.S + x0, z0 * S2 + y1 * a.S + x0, z0 * S2 + y0 * a.S + x1, z0 * S2 + y1 * a.S + x1,
+                           z1 * S2 + y0 * a.S + x0, z1 * S2 + y1 * a.S + x0, z1 * S2 + y0 * a.S + x1, z1 * S2 + y1 * a.S + x1};
+        // a sample outside the source along an axis has coinciding clamped taps and cancelling weights, but the add_n order
+        // leaves rounding residues: the arithmetic is done as written in every case
+        if (FAST14) {
+            float ta[8];
+            float4 tb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ta[e] = pa[i8[e]];
+                tb[e] = *reinterpret_cast<const float4*>(pb + (size_t)i8[e] * 4);
+            }
+            float v0 = __fmul_rn(w8[0], ta[0]), v1 = __fmul_rn(w8[0], tb[0].x), v2 = __fmul_rn(w8[0], tb[0].y);
+            float v3 = __fmul_rn(w8[0], tb[0].z), v4 = __fmul_rn(w8[0], tb[0].w);
+#pragma unroll
+            for (int e = 1; e < 8; ++e) {
+                v0 = __fadd_rn(v0, __fmul_rn(w8[e], ta[e]));
+                v1 = __fadd_rn(v1, __fmul_rn(w8[e], tb[e].x));
+                v2 = __fadd_rn(v2, __fmul_rn(w8[e], tb[e].y));
+                v3 = __fadd_rn(v3, __fmul_rn(w8[e], tb[e].z));
+                v4 = __fadd_rn(v4, __fmul_rn(w8[e], tb[e].w));
+            }
+            r20[q * 5 + 0] = v0; r20[q * 5 + 1] = v1; r20[q * 5 + 2] = v2; r20[q * 5 + 3] = v3; r20[q * 5 + 4] = v4;
+            continue;
+        }
+        for (int c = 0; c < Ct; ++c) {
+            const float* src = c < a.Ca ? pa + c : pb + (c - a.Ca);
+            const int cs = c < a.Ca ? a.Ca : a.Cb;
+            float v = __fmul_rn(w8[0], src[(size_t)i8[0] * cs]);
+#pragma unroll
+            for (int e = 1; e < 8; ++e) v = __fadd_rn(v, __fmul_rn(w8[e], src[(size_t)i8[e] * cs]));
+            op[(size_t)q * Ct + c] = v;
+        }
+    }
+    if (FAST14) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            reinterpret_cast<float4*>(op)[q] = make_float4(r20[4 * q], r20[4 * q + 1], r20[4 * q + 2], r20[4 * q + 3]);
+    }
+}
+
+extern "C" int rn_resample_concat_fwd(const float* vox_a, int Ca, const float* vox_b, int Cb, const float* pose_or_m_inv,
+                                      int affine, float* out, int B, int S, int N, int h0, int w0, int ph, int pw,
+                                      int image_layout, void* stream)
+{
+    if (!vox_a || !vox_b || !pose_or_m_inv || !out) return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: null pointer");
+    if (B <= 0 || S < 2 || N < 4 || Ca < 1 || Cb < 1) return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: bad dims");
+    if (N % 4 != 0 || N / 4 > 256 || 256 % (N / 4) != 0)
+        return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: N=%d must be a power of two in [4,1024]", N);
+    if (h0 < 0 || w0 < 0 || ph < 1 || pw < 1 || h0 + ph > N || w0 + pw > N)
+        return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: crop window out of range");
+    if (!image_layout && (h0 || w0 || ph != N || pw != N))
+        return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: crop needs image_layout=1");
+    const int lpb = 256 / (N / 4);
+    if (((long long)ph * pw) % lpb != 0)
+        return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: ph*pw=%d must be a multiple of %d", ph * pw, lpb);
+    const long long nb = (long long)B * ph * pw / lpb;
+    if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: grid too large");
+    ConcatArgs a{vox_a, vox_b, pose_or_m_inv, out, B, S, N, Ca, Cb, h0, w0, ph, pw, image_layout};
+    const bool fast = Ca == 1 && Cb == 4 && (((uintptr_t)vox_b | (uintptr_t)out) & 15) == 0;
+    if (affine && fast) hipLaunchKernelGGL((resample_concat_kernel<false, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+    else if (affine) hipLaunchKernelGGL((resample_concat_kernel<false, false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+    else if (fast) hipLaunchKernelGGL((resample_concat_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((resample_concat_kernel<true, false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+    return rn_check_launch("rn_resample_concat_fwd");
+}
+
 template <bool FROM_POSE>
 static int launch_resample(const ResampleArgs& a, hipStream_t st)
 {

@@ -26,6 +26,7 @@ struct ResampleBwdArgs {
     float* dm;             // [B,12] accumulated, or null
     int B, S, N, C;
     int h0, w0, ph, pw, image_layout;
+    int dcs, dco;          // dout holds dcs channels per sample; this source's C channels start at channel dco
 };
 
 __device__ __forceinline__ float coord_b(float m0, float m1, float m2, float m3, float x, float y, float z)
@@ -66,7 +67,7 @@ void resample_bwd_kernel(const ResampleBwdArgs a)
             const float ax = (float)x1 - x, bx = x - (float)x0;
             const float ay = (float)y1 - y, by = y - (float)y0;
             const float az = (float)z1 - z, bz = z - (float)z0;
-            const float* dp = a.dout + ((size_t)b * per_item + e) * a.C;
+            const float* dp = a.dout + ((size_t)b * per_item + e) * a.dcs + a.dco;
             const size_t S = a.S;
             const size_t base = (size_t)b * S * S * S;
             const size_t ia = base + ((size_t)z0 * S + y0) * S + x0, ib = base + ((size_t)z0 * S + y1) * S + x0;
@@ -148,9 +149,29 @@ __global__ void pose_to_affine_bwd_kernel(const float* __restrict__ pose, const 
     dpose[3 * b + 2] += (float)g[2];
 }
 
+static int resample_bwd_impl(const float* vox, const float* m_inv, const float* dout, int dcs, int dco, float* dvox, float* dm,
+                             int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout, void* stream);
+
 extern "C" int rn_resample_affine_bwd(const float* vox, const float* m_inv, const float* dout, float* dvox, float* dm,
                                       int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout,
                                       void* stream)
+{
+    return resample_bwd_impl(vox, m_inv, dout, C, 0, dvox, dm, B, S, N, C, h0, w0, ph, pw, image_layout, stream);
+}
+
+// The same for ONE source of rn_resample_concat_fwd: dout holds dout_channels per sample, this source's C channels start
+// at channel dout_offset (call once per source; dm accumulates over the calls).
+extern "C" int rn_resample_affine_bwd_strided(const float* vox, const float* m_inv, const float* dout, int dout_channels,
+                                              int dout_offset, float* dvox, float* dm, int B, int S, int N, int C,
+                                              int h0, int w0, int ph, int pw, int image_layout, void* stream)
+{
+    if (dout_channels < 1 || dout_offset < 0 || dout_offset + C > dout_channels)
+        return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd_strided: channels [%d, %d) outside %d", dout_offset, dout_offset + C, dout_channels);
+    return resample_bwd_impl(vox, m_inv, dout, dout_channels, dout_offset, dvox, dm, B, S, N, C, h0, w0, ph, pw, image_layout, stream);
+}
+
+static int resample_bwd_impl(const float* vox, const float* m_inv, const float* dout, int dcs, int dco, float* dvox, float* dm,
+                             int B, int S, int N, int C, int h0, int w0, int ph, int pw, int image_layout, void* stream)
 {
     if (!m_inv || !dout || (!dvox && !dm)) return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd: null pointer");
     if (dm && !vox) return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd: the matrix gradient needs vox");
@@ -159,7 +180,7 @@ extern "C" int rn_resample_affine_bwd(const float* vox, const float* m_inv, cons
         return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd: crop window out of range");
     if (!image_layout && (h0 || w0 || ph != N || pw != N))
         return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd: crop needs image_layout=1");
-    ResampleBwdArgs a{vox, m_inv, dout, dvox, dm, B, S, N, C, h0, w0, ph, pw, image_layout};
+    ResampleBwdArgs a{vox, m_inv, dout, dvox, dm, B, S, N, C, h0, w0, ph, pw, image_layout, dcs, dco};
     const long long per_item = (long long)ph * pw * N;
     const long long nb = (per_item + 255) / 256 * B;
     if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "rn_resample_affine_bwd: grid too large");

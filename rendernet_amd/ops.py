@@ -178,6 +178,67 @@ def resample(vox, pose, new_size=128, window=None, image_layout=True, affine=Fal
     return _Resample.apply(vox, pose, int(new_size), tuple(int(v) for v in window), image_layout, affine)
 
 
+class _ResampleConcat(torch.autograd.Function):
+    """Two volumes, one pose, one channel-concatenated output (rn_resample_concat_fwd); backward: one
+    rn_resample_affine_bwd_strided per source that needs a gradient, the matrix gradient accumulated over both."""
+
+    @staticmethod
+    def forward(ctx, vox_a, vox_b, pose, N, window, image_layout, affine):
+        _chk_dev(vox_a, vox_b, pose)
+        B, S, Ca, Cb = vox_a.shape[0], vox_a.shape[1], vox_a.shape[4], vox_b.shape[4]
+        h0, w0, ph, pw = window
+        out = torch.empty((B, ph, pw, N, Ca + Cb), dtype=torch.float32, device=vox_a.device)
+        ev = LAUNCH_HOOK("resample", (B, S, S, S, Ca + Cb), None) if LAUNCH_HOOK is not None else None
+        if ev is not None:
+            ev[0].record()
+        L.check(L.lib().rn_resample_concat_fwd(L.ptr(vox_a), Ca, L.ptr(vox_b), Cb, L.ptr(pose), 1 if affine else 0, L.ptr(out),
+                                               B, S, N, h0, w0, ph, pw, 1 if image_layout else 0, L.stream_ptr()),
+                "rn_resample_concat_fwd")
+        if ev is not None:
+            ev[1].record()
+        ctx.save_for_backward(vox_a, vox_b, pose)
+        ctx.cfg = (N, window, image_layout, affine)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vox_a, vox_b, pose = ctx.saved_tensors
+        N, (h0, w0, ph, pw), image_layout, affine = ctx.cfg
+        B, S, Ca, Cb = vox_a.shape[0], vox_a.shape[1], vox_a.shape[4], vox_b.shape[4]
+        lib, st = L.lib(), L.stream_ptr()
+        dout = dout.contiguous()
+        m = (pose if affine else pose_to_affine(pose, S, N).reshape(B, 12)).contiguous()
+        want_pose = ctx.needs_input_grad[2]
+        dm = torch.zeros((B, 12), dtype=torch.float32, device=vox_a.device) if want_pose else None
+        grads = []
+        for vox, C, off, want in ((vox_a, Ca, 0, ctx.needs_input_grad[0]), (vox_b, Cb, Ca, ctx.needs_input_grad[1])):
+            dv = torch.zeros_like(vox) if want else None
+            if want or want_pose:
+                L.check(lib.rn_resample_affine_bwd_strided(L.ptr(vox), L.ptr(m), L.ptr(dout), Ca + Cb, off, L.ptr(dv), L.ptr(dm),
+                                                           B, S, N, C, h0, w0, ph, pw, 1 if image_layout else 0, st),
+                        "rn_resample_affine_bwd_strided")
+            grads.append(dv)
+        dpose = None
+        if want_pose:
+            if affine:
+                dpose = dm.reshape(pose.shape)
+            else:
+                dpose = torch.zeros_like(pose)
+                L.check(lib.rn_pose_to_affine_bwd(L.ptr(pose), L.ptr(dm), L.ptr(dpose), B, S, N, st), "rn_pose_to_affine_bwd")
+        return grads[0], grads[1], dpose, None, None, None, None
+
+
+def resample_concat(vox_a, vox_b, pose, new_size=128, window=None, image_layout=True, affine=False):
+    """vox_a [B,S,S,S,Ca], vox_b [B,S,S,S,Cb], one pose [B,3] (or M_inv, affine=True) -> [B,ph,pw,N,Ca+Cb]: what
+    `concat([resample(vox_a), resample(vox_b)], -1)` computes, in one pass and without the intermediates."""
+    vox_a, vox_b, pose = vox_a.contiguous().float(), vox_b.contiguous().float(), pose.contiguous().float()
+    if vox_a.shape[:4] != vox_b.shape[:4]:
+        raise L.RenderNetHipError("resample_concat: grids %s and %s differ" % (tuple(vox_a.shape), tuple(vox_b.shape)))
+    if window is None:
+        window = (0, 0, new_size, new_size)
+    return _ResampleConcat.apply(vox_a, vox_b, pose, int(new_size), tuple(int(v) for v in window), image_layout, affine)
+
+
 def pose_to_affine(pose, size=64, new_size=128):
     pose = pose.contiguous().float()
     _chk_dev(pose)

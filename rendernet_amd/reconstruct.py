@@ -29,7 +29,7 @@ from .texture import TextureSpec, texture_variable_shapes, init_texture_weights,
 from .tools import layer_util as LU
 from .tools import Phong_shading as Phong
 from .tools.model_util import load_weights  # noqa: F401  (tools/model_util.py:26-39)
-from .tools.resampling_voxel_grid import rotation_resampling_to_image
+from .tools.resampling_voxel_grid import rotation_resampling_concat_to_image, rotation_resampling_to_image  # noqa: F401
 from .variables import random_normal_initializer
 
 
@@ -206,9 +206,8 @@ class Reconstructor:
             with ops.training(self.ctx):
                 shape = decoder_3d_pretrained(lat["vector"], self.dec_spec, taps)                                  # :356
                 tex = decoder_texture(lat["texture"], ts, taps)                                                    # :357
-                geo = rotation_resampling_to_image(shape, lat["param"], size=ts.size, new_size=ts.new_size)       # :360-361
-                tex_rot = rotation_resampling_to_image(tex, lat["param"], size=ts.size, new_size=ts.new_size)     # :363-364
-                net_in = torch.cat([geo, tex_rot], dim=4)                                                          # :366
+                # :360-361 + :363-364 + :366 -- both resamplers and the concat in one pass
+                net_in = rotation_resampling_concat_to_image(shape, tex, lat["param"], size=ts.size, new_size=ts.new_size)
                 img, nrm = RenderNetTexture(net_in, prob=1.0, spec=ts, taps=taps)                                  # :367
                 light_dir = Phong.tf_generate_light_pos(lat["light"], self.elevation, self.B)                      # :358
                 compos = Phong.tf_phong_composite(nrm, light_dir, self.light_col, self.ambient, self.k_diffuse,

@@ -15,7 +15,7 @@ import torch
 from . import variables as V
 from .tools import layer_util as LU
 from .tools.layer_util import res_block_2d, res_block_3d, projection_unit
-from .tools.resampling_voxel_grid import rotation_resampling_to_image
+from .tools.resampling_voxel_grid import rotation_resampling_concat_to_image, rotation_resampling_to_image  # noqa: F401
 from .variables import xavier_initializer, constant_initializer, random_normal_initializer
 
 
@@ -275,10 +275,9 @@ class TextureRenderer:
         old = V._default
         V.set_default_store(self.store)
         try:
-            geo = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size)            # :165-166
             tex_vol = decoder_texture(tex, s, taps)                                                     # :169
-            tex_rot = rotation_resampling_to_image(tex_vol, pose, size=s.size, new_size=s.new_size)   # :171-172
-            net_in = torch.cat([geo, tex_rot], dim=4)                                                   # :178
+            # :165-166 + :171-172 + :178 -- both resamplers and the concat in one pass
+            net_in = rotation_resampling_concat_to_image(vox, tex_vol, pose, size=s.size, new_size=s.new_size)
             if taps is not None:
                 taps["net_in"] = net_in
             return RenderNetTexture(net_in, spec=s, taps=taps)

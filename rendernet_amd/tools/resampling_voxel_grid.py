@@ -28,6 +28,15 @@ def rotation_resampling_to_image(voxel_array, view_params, size=64, new_size=128
     return ops.resample(voxel_array, view_params, new_size, window, image_layout=True)
 
 
+def rotation_resampling_concat_to_image(voxel_a, voxel_b, view_params, size=64, new_size=128, window=None):
+    """`tf.concat([transform(tf_rotation_resampling(a, p)), transform(tf_rotation_resampling(b, p))], axis=4)` of the face
+    renderer (RenderNet_Texture_Face_Normal.py:165-178; Reconstruct_RenderNet_Face.py:360-366) in one pass: both volumes
+    are sampled with the same coordinates and the concatenated tensor is written directly."""
+    if voxel_a.shape[1] != size or voxel_b.shape[1] != size:
+        raise ValueError("voxel grids are %d^3 / %d^3 but size=%d" % (voxel_a.shape[1], voxel_b.shape[1], size))
+    return ops.resample_concat(voxel_a, voxel_b, view_params, new_size, window, image_layout=True)
+
+
 def tf_resampling_affine(voxel_array, m_inv, new_size=128, image_layout=False, window=None):
     """tf_resampling (:564-614) given the already inverted matrices total_M[:, 0:3, :] (:601-602)."""
     return ops.resample(voxel_array, m_inv.reshape(m_inv.shape[0], 12), new_size, window,

@@ -25,7 +25,7 @@ from . import _lib as L
 from . import ops
 from . import variables as V
 from .shader import RenderNet, ShaderSpec, init_shader_weights
-from .tools.resampling_voxel_grid import rotation_resampling_to_image
+from .tools.resampling_voxel_grid import rotation_resampling_concat_to_image, rotation_resampling_to_image
 
 
 def exponential_decay(lr0, step, decay_steps, rate=0.96, staircase=True):
@@ -286,10 +286,8 @@ class TextureTrainer(_TrainerBase):
         V.set_default_store(self.store)
         try:
             with ops.training(self.ctx):
-                geo = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
                 tex_vol = decoder_texture(tex, s, taps)
-                tex_rot = rotation_resampling_to_image(tex_vol, pose, size=s.size, new_size=s.new_size, window=window)
-                net_in = torch.cat([geo, tex_rot], dim=4)
+                net_in = rotation_resampling_concat_to_image(vox, tex_vol, pose, size=s.size, new_size=s.new_size, window=window)
                 if taps is not None:
                     taps["net_in"] = net_in
                 img, nrm = RenderNetTexture(net_in, prob=self.keep_prob, spec=s, taps=taps, is_training=bool(is_training))
