@@ -78,6 +78,9 @@ class RenderNetHipError(RuntimeError):
     pass
 
 
+_F32 = [None]          # torch.float32, filled in by lib() (torch is imported lazily)
+
+
 def lib():
     """Load (once) and return the ctypes library.  Raises if it is not built."""
     global _lib
@@ -86,7 +89,8 @@ def lib():
             raise RenderNetHipError(
                 "librendernet_hip.so not found at %s -- build it with `python -m rendernet_amd.build` "
                 "(there is no CPU fallback for the render path)" % LIB_PATH)
-        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime torch ships, not a second copy
+        import torch  # first: the library must bind to the HIP runtime torch ships, not a second copy
+        _F32[0] = torch.float32
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
@@ -112,7 +116,9 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise RenderNetHipError("expected a CUDA/HIP tensor, got device %s" % t.device)
-    if t.dtype.__str__() != "torch.float32" or not t.is_contiguous():
+    if _F32[0] is None:
+        lib()
+    if t.dtype is not _F32[0] or not t.is_contiguous():
         raise RenderNetHipError("expected a contiguous float32 tensor")
     return ctypes.c_void_p(t.data_ptr())
 

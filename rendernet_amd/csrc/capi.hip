@@ -24,6 +24,21 @@ int rn_check_launch(const char* what)
     return RN_OK;
 }
 
+int rn_ensure_dynamic_lds(const void* kernel, size_t bytes)
+{
+    struct Slot { const void* k; int dev; size_t bytes; };
+    static thread_local Slot cache[64];
+    static thread_local int used = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < used; ++i)
+        if (cache[i].k == kernel && cache[i].dev == dev && cache[i].bytes >= bytes) return RN_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return rn_set_error(RN_E_LAUNCH, "hipFuncSetAttribute(%zu B of LDS): %s", bytes, hipGetErrorString(e)); }
+    if (used < 64) cache[used++] = Slot{kernel, dev, bytes};
+    return RN_OK;
+}
+
 extern "C" int rn_version(void) { return RN_VERSION; }
 extern "C" const char* rn_last_error(void) { return g_err; }
 

@@ -96,8 +96,7 @@ static int launch_direct(const DirectArgs& a, hipStream_t st)
     const size_t lds = (size_t)a.Ktot * CO * sizeof(float);
     if (lds > 160 * 1024) return rn_set_error(RN_E_UNSUPPORTED, "conv_direct: filter %zu B exceeds LDS", lds);
     auto kern = conv_direct_kernel<CO>;
-    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(160 * 1024)); if (rc_ != RN_OK) return rc_; }
     const long long nb = (a.M + 255) / 256;
     if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_direct: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);

@@ -406,8 +406,7 @@ static int launch_glds(IgemmArgs& a, hipStream_t st)
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * BK * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
     auto kern = conv_igemm_glds_kernel<BM>;
-    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     const long long nb = (long long)a.mtiles * a.ntiles;
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: bad grid %lld", nb);
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
@@ -423,8 +422,7 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st)
     a.nk = a.K0 * a.K1 * a.K2 * a.ctiles;
     const size_t lds = (size_t)2 * BM * (BK + 4) * 4 + (size_t)2 * BK * BN * 4 + (size_t)BM * (16 + 8);
     auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
-    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     const long long nb = (long long)a.mtiles * a.ntiles;
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_igemm: bad grid %lld", nb);
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * WM * WN), lds, st, a);

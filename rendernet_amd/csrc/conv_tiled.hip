@@ -115,7 +115,7 @@ static int launch_tiled(const RnConvProblem& p, hipStream_t st)
     constexpr int ROW = (IT2 * PP + ((S1 % 2 == 0) ? IT1 / 2 + 1 : 0)) | 1;
     const size_t lds = ((size_t)K0 * K1 * K2 * CIN * CO + (size_t)IT0 * IT1 * ROW + 16) * sizeof(float);
     auto kern = conv_tiled_kernel<K0, K1, K2, S0, S1, S2, CIN, CO, T0, T1, T2>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(T0 * T1 * T2), lds, st, a);
     return rn_check_launch("conv_tiled");
 }
@@ -218,7 +218,7 @@ static int launch_rows(const RnConvProblem& p, hipStream_t st)
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_rows: bad grid %lld", nb);
     const size_t lds = (size_t)K0 * K1 * K2 * CIN * CO * sizeof(float);
     auto kern = conv_rows_kernel<K0, K1, K2, S0, S1, S2, CIN, CO, OPT>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
     return rn_check_launch("conv_rows");
 }

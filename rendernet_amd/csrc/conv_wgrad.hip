@@ -279,8 +279,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st)
     if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wgrad: bad grid %lld", nb);
     const size_t lds = (size_t)2 * BK * (BM + BN) * 4 + (size_t)WG_MAX_CHUNK * 4;
     auto kern = conv_wgrad_kernel<BM, BN, BK, WM, WN, WK>;
-    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
     return rn_check_launch("conv_wgrad");
 }
@@ -459,9 +458,7 @@ static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, 
     a.nsplit = (a.nitems + a.ipw - 1) / a.ipw;
     const long long nb = (long long)((a.nsplit + 7) / 8) * 72;
     const size_t lds = (size_t)2 * (136 * 32 + 128 * 32) * 4;
-    // per launch, not once per process: the attribute is per device and a process may drive several GPUs
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
     hipLaunchKernelGGL(conv_wgrad_k3d32_kernel, dim3((unsigned)nb), dim3(256), lds, st, a);
     return rn_check_launch("conv_wgrad_k3d32");
 }

@@ -52,3 +52,8 @@ int rn_launch_conv_dgrad_direct(const float* dz, const float* w_fwd_packed, floa
                                 const int* O, int Cout, const int* K, const int* S, const int* P, hipStream_t st); // train_kernels.hip
 
 static inline int rn_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device) -- a
+// process may drive several GPUs -- and never again (the call costs tens of microseconds, which at batch 1 is a third of
+// a short launch).  The cache is per thread: no locks, and a second thread merely repeats the idempotent call once.
+int rn_ensure_dynamic_lds(const void* kernel, size_t bytes);     // capi.hip

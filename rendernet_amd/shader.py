@@ -279,10 +279,11 @@ class Renderer:
         old = V._default
         V.set_default_store(self.store)
         try:
-            net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
-            if taps is not None:
-                taps["net_in"] = net_in
-            return RenderNet(net_in, is_training, prob=prob, spec=s, taps=taps)
+            with torch.no_grad():        # the Renderer is the inference runner (the trainers own the differentiable graph)
+                net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
+                if taps is not None:
+                    taps["net_in"] = net_in
+                return RenderNet(net_in, is_training, prob=prob, spec=s, taps=taps)
         finally:
             V._default = old
 
