@@ -42,44 +42,71 @@ class PackedWeight:
         else:
             self.cout, self.cin = int(w_tf.shape[ndim]), int(w_tf.shape[ndim + 1])
         lib = L.lib()
-        n = lib.rn_packed_weight_floats(kind, ndim, L.ivec(self.kdims), self.cin, self.cout)
-        if n == 0:
+        self._n = lib.rn_packed_weight_floats(kind, ndim, L.ivec(self.kdims), self.cin, self.cout)
+        if self._n == 0:
             raise L.RenderNetHipError("rn_packed_weight_floats: %s" % lib.rn_last_error().decode())
-        self.data = torch.empty(n, dtype=torch.float32, device=w_tf.device)
         self.w_tf = w_tf                  # the TF-layout master copy (what the optimiser updates)
         self._dgrad = None
-        # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 2-D filters whose channel counts the kernel takes;
+        # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
+        # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
+        # forward and input-gradient launches actually read.
+        self._buf = {"data": None, "wino": None, "wino4": None}
+        self._dirty = {"data": True, "wino": True, "wino4": True}
+        # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
         # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
-        self.wino = None
         wkind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO}.get(kind)
-        if wkind is not None and ((ndim == 2 and self.kdims == [3, 3] and lib.rn_conv2d_wino_supported(self.cin, self.cout))
-                                  or (ndim == 3 and self.kdims == [3, 3, 3] and lib.rn_conv3d_wino_supported(self.cin, self.cout))):
-            nw = lib.rn_packed_weight_floats(wkind, ndim, L.ivec(self.kdims), self.cin, self.cout)
-            if nw == 0:
-                raise L.RenderNetHipError("rn_packed_weight_floats (Winograd): %s" % lib.rn_last_error().decode())
-            self.wino_kind = wkind
-            self.wino = torch.empty(nw, dtype=torch.float32, device=w_tf.device)
+        self._wino_kind = wkind if (wkind is not None and (
+            (ndim == 2 and self.kdims == [3, 3] and lib.rn_conv2d_wino_supported(self.cin, self.cout)) or
+            (ndim == 3 and self.kdims == [3, 3, 3] and lib.rn_conv3d_wino_supported(self.cin, self.cout)))) else None
         # 4x4 stride-1 filters (e_conv5, e_conv6; e_conv7_1 as a transposed conv): four 2x2 sub-filters, each F(2x2,2x2)
-        self.wino4 = None
         w4kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO4, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO4}.get(kind)
-        if w4kind is not None and ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_wino4_supported(self.cin, self.cout):
-            nw = lib.rn_packed_weight_floats(w4kind, ndim, L.ivec(self.kdims), self.cin, self.cout)
-            if nw == 0:
-                raise L.RenderNetHipError("rn_packed_weight_floats (Winograd 4x4): %s" % lib.rn_last_error().decode())
-            self.wino4_kind = w4kind
-            self.wino4 = torch.empty(nw, dtype=torch.float32, device=w_tf.device)
-        self.repack()
+        self._wino4_kind = w4kind if (w4kind is not None and ndim == 2 and self.kdims == [4, 4]
+                                      and lib.rn_conv2d_wino4_supported(self.cin, self.cout)) else None
+
+    def _packed(self, which, kind):
+        if self._dirty[which]:
+            lib = L.lib()
+            if self._buf[which] is None:
+                n = self._n if which == "data" else lib.rn_packed_weight_floats(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout)
+                if n == 0:
+                    raise L.RenderNetHipError("rn_packed_weight_floats (%s): %s" % (which, lib.rn_last_error().decode()))
+                self._buf[which] = torch.empty(n, dtype=torch.float32, device=self.w_tf.device)
+            L.check(lib.rn_pack_weights(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout, L.ptr(self.w_tf),
+                                        L.ptr(self._buf[which]), L.stream_ptr()), "rn_pack_weights (%s)" % which)
+            self._dirty[which] = False
+        return self._buf[which]
+
+    @property
+    def data(self):
+        """The direct-kernel pack [phase][K/4][Npad][4]."""
+        return self._packed("data", self.kind)
+
+    @property
+    def wino(self):
+        """The Winograd F(2x2,3x3) pack, or None when this filter does not take that path."""
+        return None if self._wino_kind is None else self._packed("wino", self._wino_kind)
+
+    @wino.setter
+    def wino(self, value):
+        if value is not None:
+            raise ValueError("the Winograd pack can only be switched off (set to None)")
+        self._wino_kind = None
+
+    @property
+    def wino4(self):
+        """The 4x4 (four F(2x2,2x2) sub-filters) pack, or None."""
+        return None if self._wino4_kind is None else self._packed("wino4", self._wino4_kind)
+
+    @wino4.setter
+    def wino4(self, value):
+        if value is not None:
+            raise ValueError("the 4x4 Winograd pack can only be switched off (set to None)")
+        self._wino4_kind = None
 
     def repack(self):
-        """Re-derive the packed copies from the TF-layout master (after an optimiser step)."""
-        L.check(L.lib().rn_pack_weights(self.kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
-                                        L.ptr(self.w_tf), L.ptr(self.data), L.stream_ptr()), "rn_pack_weights")
-        if self.wino is not None:
-            L.check(L.lib().rn_pack_weights(self.wino_kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
-                                            L.ptr(self.w_tf), L.ptr(self.wino), L.stream_ptr()), "rn_pack_weights (Winograd)")
-        if self.wino4 is not None:
-            L.check(L.lib().rn_pack_weights(self.wino4_kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout,
-                                            L.ptr(self.w_tf), L.ptr(self.wino4), L.stream_ptr()), "rn_pack_weights (Winograd 4x4)")
+        """The TF-layout master changed (an optimiser step): every packed form is stale and is rebuilt when next read."""
+        for k in self._dirty:
+            self._dirty[k] = True
         if self._dgrad is not None:
             self._dgrad.repack()
 
@@ -295,27 +322,28 @@ def training(ctx):
 
 def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     lib, st = L.lib(), L.stream_ptr()
-    a = (L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))
+    e = (L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))          # the epilogue arguments of every entry
+    unit = all(int(v) == 1 for v in stride)
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
-        if pw.wino is not None and tuple(stride) == (1, 1, 1):
-            return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *a[2:], B, H, W, D, Cin, pw.cout, act, st)
-        return lib.rn_conv3d_fwd_train(*a, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
+        if unit and pw.wino is not None:
+            return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
+        return lib.rn_conv3d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d":
         B, H, W, Cin = x.shape
-        if pw.wino is not None and tuple(stride) == (1, 1):
-            return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *a[2:], B, H, W, Cin, pw.cout, act, st)
-        if pw.wino4 is not None and tuple(stride) == (1, 1):
-            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *a[2:], B, H, W, Cin, pw.cout, 0, act, st)
-        return lib.rn_conv2d_fwd_train(*a, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
+        if unit and pw.wino is not None:
+            return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
+        if unit and pw.wino4 is not None:
+            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, 0, act, st)
+        return lib.rn_conv2d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d_transpose":
         B, H, W, Cin = x.shape
-        if pw.wino4 is not None and int(stride[0]) == 1:
-            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *a[2:], B, H, W, Cin, pw.cout, 1, act, st)
-        return lib.rn_conv2d_transpose_fwd_train(*a, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
+        if unit and pw.wino4 is not None:
+            return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, 1, act, st)
+        return lib.rn_conv2d_transpose_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
     if mode == "conv3d_transpose":
         B, H, W, D, Cin = x.shape
-        return lib.rn_conv3d_transpose_fwd_train(*a, B, H, W, D, Cin, pw.cout, ksize[0], stride[0], act, st)
+        return lib.rn_conv3d_transpose_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, ksize[0], stride[0], act, st)
     raise ValueError(mode)
 
 
@@ -332,7 +360,7 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False):
-        _chk_dev(x, pw.data, bias, alpha, residual)
+        _chk_dev(x, pw.w_tf, bias, alpha, residual)
         ev = LAUNCH_HOOK(mode, tuple(x.shape), pw) if LAUNCH_HOOK is not None else None
         if ev is not None:
             ev[0].record()
@@ -463,7 +491,7 @@ def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 
 class _Projection(_ForwardOnly):
     @staticmethod
     def forward(ctx, x, pw, bias, alpha):
-        _chk_dev(x, pw.data, bias, alpha)
+        _chk_dev(x, pw.w_tf, bias, alpha)
         B, H, W, D, C = x.shape
         y = torch.empty((B, H, W, D * C), dtype=torch.float32, device=x.device)
         L.check(L.lib().rn_projection_fwd(L.ptr(x), L.ptr(pw.data), L.ptr(bias), L.ptr(alpha), L.ptr(y),
