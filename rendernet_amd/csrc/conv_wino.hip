@@ -148,7 +148,10 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
 // with 6 K steps per item (the 3-D encoder layers) prologue + epilogue used to cost as much as the steps themselves.
 // NT = 16-channel n-tiles per wave: 2 (32 output channels per workgroup; Cout % 32 == 0) or 1 (Cout % 16 == 0 only: the
 // 16-wide 3-D encoder of the texture net).  The filter pack's n-block is 16*NT wide (misc_kernels.hip: pack_wino_kernel).
-template <int PROBE, int NT, int MODE>
+// TAG does nothing in the kernel: the persistent grid is the same for every layer, so a kernel trace could not tell the layers
+// apart; the launcher picks TAG by layer class (0: >= 1024 input channels -- res2; 1: 2-D, fewer -- res3 and the rest;
+// 2: 3x3x3 -- the 3-D encoder), which gives each class its own kernel name in rocprofv3's per-kernel statistics.
+template <int PROBE, int NT, int MODE, int TAG>
 __global__ __launch_bounds__(512, 1)
 void conv_wino_kernel(const WinoArgs a)
 {
@@ -393,19 +396,25 @@ bool rn_wino4_supported(int Cin, int Cout)
 // 16-channel n-tiles per wave; rn_pack_weights follows the same rule (misc_kernels.hip)
 int rn_wino_ntiles(int mode, int Cout) { return mode ? (Cout % 64 == 0 ? 4 : Cout % 32 == 0 ? 2 : 1) : (Cout % 32 == 0 ? 2 : 1); }
 
-template <int PROBE, int NT, int MODE>
-static int wino_launch(const WinoArgs& a, unsigned grid, hipStream_t st)
+template <int PROBE, int NT, int MODE, int TAG>
+static int wino_launch_tag(const WinoArgs& a, unsigned grid, hipStream_t st)
 {
-    // The persistent grid is the same for every layer, so a kernel trace could not tell the layers apart: where the LDS
-    // budget has room, a per-shape tag of 0..15 KiB is added to the (otherwise unused) dynamic LDS size, which
-    // rocprofv3 reports per dispatch (profiles/*_per_shape.md groups by it).
-    size_t lds = wino_lds_bytes(MODE, NT);
-    const size_t tag = (size_t)(((a.Cin >> 5) ^ (a.Cout >> 7) ^ (a.KD * 5)) & 15) * 1024;
-    if (lds + tag <= 160 * 1024) lds += tag;
-    auto kern = conv_wino_kernel<PROBE, NT, MODE>;
+    const size_t lds = wino_lds_bytes(MODE, NT);
+    auto kern = conv_wino_kernel<PROBE, NT, MODE, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)160 * 1024); if (rc_ != RN_OK) return rc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     return rn_check_launch("conv_wino");
+}
+
+template <int PROBE, int NT, int MODE>
+static int wino_launch(const WinoArgs& a, unsigned grid, hipStream_t st)
+{
+    if (PROBE == 0 && NT == 2 && MODE == 0) {       // the product kernel of the trunk: one name per layer class
+        if (a.KD == 3) return wino_launch_tag<0, 2, 0, 2>(a, grid, st);
+        if (a.Cin >= 1024) return wino_launch_tag<0, 2, 0, 0>(a, grid, st);
+        return wino_launch_tag<0, 2, 0, 1>(a, grid, st);
+    }
+    return wino_launch_tag<PROBE, NT, MODE, 0>(a, grid, st);
 }
 
 // x [B,H,W,(D,)Cin] -> y [B,H,W,(D,)Cout], stride 1.
