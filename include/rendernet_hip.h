@@ -303,6 +303,12 @@ int rn_conv2d_wgrad(const float* x, const float* dz, float* dw, int B, int H, in
                     int Cin, int Cout, const int* ksize, const int* stride, void* stream);
 int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
                               int Cin, int Cout, int ksize, int stride, void* stream);
+/* rn_conv2d_wgrad for the 3x3, stride-1 convs (res_block_2d, *_skip: tools/layer_util.py:101-104) through the Winograd
+ * identity dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G: 16 multiplies per 2x2-output tile and channel pair instead
+ * of 36, fp32; same contract (dw [3,3,Cin,Cout] ACCUMULATED with fp32 atomics).  Cin % 64 == 0 and Cout % 64 == 0
+ * (rn_conv2d_wino_wgrad_supported). */
+int rn_conv2d_wino_wgrad_supported(int Cin, int Cout);
+int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream);
 int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
                               int Cin, int Cout, int ksize, int stride, void* stream);
 

@@ -58,6 +58,8 @@ SIGNATURES = {
     "rn_conv3d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
     "rn_conv3d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
     "rn_conv2d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_wino_wgrad_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),
     "rn_conv3d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
     "rn_resample_affine_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 9 + [_c_vp]),

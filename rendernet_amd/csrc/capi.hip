@@ -369,6 +369,15 @@ extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B
     return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_wgrad");
 }
 
+extern "C" int rn_conv2d_wino_wgrad_supported(int Cin, int Cout) { return rn_wino_wgrad_supported(Cin, Cout) ? 1 : 0; }
+
+extern "C" int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream)
+{
+    if (!x || !dz || !dw) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_wgrad: null pointer");
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino_wgrad: bad sizes");
+    return rn_launch_conv_wino_wgrad(x, dz, dw, B, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
 extern "C" int rn_conv2d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
                                int Cin, int Cout, const int* ksize, const int* stride, void* stream)
 {

@@ -409,6 +409,9 @@ class _Conv(torch.autograd.Function):
             rc = 0
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+        elif (mode == "conv2d" and unit and tuple(ksize) == (3, 3) and pw._wino_kind is not None
+              and lib.rn_conv2d_wino_wgrad_supported(Cin, pw.cout)):
+            rc = lib.rn_conv2d_wino_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, st)
         elif mode == "conv2d":
             rc = lib.rn_conv2d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
         elif mode == "conv2d_transpose":

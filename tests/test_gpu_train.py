@@ -144,6 +144,29 @@ def test_wgrad_accumulates_and_large_reduction():
     _close(dw, 2 * wt.grad, "accumulated dw")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 64, 64), (2, 16, 16, 128, 64), (3, 13, 27, 64, 128),
+                                            (1, 37, 5, 64, 64), (2, 32, 32, 256, 256), (1, 1, 1, 64, 64)])
+def test_wino_wgrad(B, H, W, Cin, Cout):
+    """The Winograd filter gradient of the 3x3 stride-1 convs vs autograd over the oracle conv and vs the direct wgrad
+    kernel; ragged planes (partial 4x4-tile groups on both axes), several K splits, accumulation into dw."""
+    from rendernet_amd import _lib as L
+    assert L.lib().rn_conv2d_wino_wgrad_supported(Cin, Cout) == 1
+    assert L.lib().rn_conv2d_wino_wgrad_supported(32, 64) == 0
+    rng = np.random.default_rng(B * 1000 + H * 31 + W + Cin)
+    x, dz = _rand(rng, B, H, W, Cin), _rand(rng, B, H, W, Cout)
+    wt = torch.zeros(3, 3, Cin, Cout, requires_grad=True)
+    OL.conv2d(torch.from_numpy(x), wt).backward(torch.from_numpy(dz))
+    xd, dzd = _dev(x), _dev(dz)
+    dw = torch.zeros(3, 3, Cin, Cout, device="cuda")
+    for _ in range(2):
+        L.check(L.lib().rn_conv2d_wino_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(dw), B, H, W, Cin, Cout, L.stream_ptr()), "wino wgrad")
+    _close(dw, 2 * wt.grad, "accumulated Winograd dw")
+    ref = torch.zeros_like(dw)
+    L.check(L.lib().rn_conv2d_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(ref), B, H, W, Cin, Cout,
+                                    L.ivec([3, 3]), L.ivec([1, 1]), L.stream_ptr()), "rn_conv2d_wgrad")
+    _close(dw, (2 * ref).cpu(), "Winograd vs direct wgrad")
+
+
 @pytest.mark.parametrize("C,act", [(1024, 1), (32, 1), (8, 1), (1, 2), (3, 2), (16, 0), (2048, 1), (20, 1)])
 def test_epilogue_bwd(C, act):
     from rendernet_amd import _lib as L
