@@ -55,6 +55,10 @@ extern "C" {
                                      transform: the input gradient of a stride-1 3x3(x3) conv through
                                      rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
 
+#define RN_PACK_CONV_WINO43     7  /* TF conv filter [3,3,Cin,Cout] -> Winograd F(4x4,3x3) form U = G g G^T (36 planes,
+                                     36*Cin*Cout floats, Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino43_fwd      */
+#define RN_PACK_CONVT_S1_WINO43 8  /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same transform
+                                     (= the input gradient of a 3x3 conv when fed that conv's filter)               */
 #define RN_PACK_CONV_WINO4      5  /* TF conv filter [4,4,Cin,Cout] as four 2x2 sub-filters, each Winograd F(2x2,2x2)
                                      transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 16 == 0) for
                                      rn_conv2d_wino4_fwd                                                          */
@@ -174,6 +178,18 @@ int rn_projection_fwd(const float* x, const float* w_packed, const float* bias, 
  * three depth taps (in channels-last [B,H,W,D,C] the three depth neighbours of a voxel are 3*C contiguous floats, so
  * every output depth slice is a 2-D conv with 3*C input channels): 27 -> 12 multiplies per output and channel pair. */
 int rn_conv2d_wino_supported(int Cin, int Cout);
+/* rn_conv2d_wino43_fwd: the same layers through Winograd F(4x4,3x3) -- 36 multiplies per 4x4 outputs and channel pair
+ * instead of 144 (F(2x2,3x3): 64) -- in three launches: input transform V = B^T d B of every 6x6 patch, 36 exact-fp32 MFMA
+ * GEMMs M[xi] = V[xi] . U[xi], output transform A^T m A fused with the bias / PReLU / residual epilogue.  V and M live in
+ * `workspace` (rn_conv2d_wino43_workspace_floats(B,H,W,Cin,Cout) floats, device memory, contents undefined afterwards).
+ * Same epilogue contract as rn_conv2d_fwd_train.  fp32 rounding: about 2e-5 of max|y| at Cin = 1024 (the transforms'
+ * constants reach 8 and 1/24), against 1e-6 for the F(2x2) path; the end-to-end tolerance of the path is 1e-3.
+ * Needs Cin % 32 == 0 and Cout % 256 == 0 (rn_conv2d_wino43_supported). */
+int rn_conv2d_wino43_supported(int Cin, int Cout);
+size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_wino43_fwd(const float* x, const float* w_wino43, const float* bias, const float* alpha,
+                         const float* residual, float* y, float* preact, float* workspace,
+                         int B, int H, int W, int Cin, int Cout, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

@@ -14,6 +14,7 @@ RN_ACT_NONE, RN_ACT_PRELU, RN_ACT_SIGMOID, RN_ACT_ELU = 0, 1, 2, 4
 RN_PHONG_NP_BLACK, RN_PHONG_NP_WHITE, RN_PHONG_TF_BLACK, RN_PHONG_TF_WHITE, RN_PHONG_NO_MASK = 0, 1, 2, 3, 4
 RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2, RN_PACK_CONV_WINO, RN_PACK_CONVT_S1_WINO = 0, 1, 2, 3, 4
 RN_PACK_CONV_WINO4, RN_PACK_CONVT_S1_WINO4 = 5, 6
+RN_PACK_CONV_WINO43, RN_PACK_CONVT_S1_WINO43 = 7, 8
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -58,6 +59,9 @@ SIGNATURES = {
     "rn_conv3d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
     "rn_conv3d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
     "rn_conv2d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
+    "rn_conv2d_wino43_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino43_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
+    "rn_conv2d_wino43_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 6 + [_c_vp]),
     "rn_conv2d_wino_wgrad_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),

@@ -369,6 +369,22 @@ extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B
     return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_wgrad");
 }
 
+extern "C" int rn_conv2d_wino43_supported(int Cin, int Cout) { return rn_wino43_supported(Cin, Cout) ? 1 : 0; }
+extern "C" size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
+{
+    if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(Cin, Cout)) return 0;
+    return rn_wino43_workspace_floats(B, H, W, Cin, Cout);
+}
+extern "C" int rn_conv2d_wino43_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* residual,
+                                    float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout, int act,
+                                    void* stream)
+{
+    if (!x || !w || !y || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: null pointer");
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: bad sizes");
+    if ((act & 1) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: PReLU without alpha");
+    return rn_launch_conv_wino43(x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, act, (hipStream_t)stream);
+}
+
 extern "C" int rn_conv2d_wino_wgrad_supported(int Cin, int Cout) { return rn_wino_wgrad_supported(Cin, Cout) ? 1 : 0; }
 
 extern "C" int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream)

@@ -1,0 +1,345 @@
+// Stride-1 3x3 2-D convs through Winograd F(4x4,3x3) in three launches, exact-fp32 MFMA for the multiply stage --
+// the wide res_block_2d / *_skip convs (slim.conv2d [3,3]: tools/layer_util.py:91-105, RenderNet_Shader.py:71-84, :91-99),
+// forward and, with the transposed pack, the input gradient.
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        6x6 input patch d -> 4x4 outputs: 36 multiplies instead of 144 (F(2x2): 64)
+//
+//   1. wino43_input_kernel     x [B,H,W,Cin]            -> V [36 xi][T tiles][Cin]     (B^T d B per tile and channel; HBM bound)
+//   2. wino43_gemm_kernel      V, U [36][Cin][Cout]     -> M [36 xi][T][Cout]          (36 GEMMs T x Cin x Cout; MFMA bound)
+//   3. wino43_output_kernel    M, bias, alpha, residual -> y [B,H,W,Cout]              (A^T m A + the conv epilogue; HBM bound)
+//
+// Unlike the fused F(2x2,3x3) kernel (conv_wino.hip), which transforms its patch again for every 32 output channels and
+// holds all xi of a tile in one wave, the 36 xi planes do not fit the accumulator file next to a useful channel block, so
+// the transforms run once, in their own launches, and the multiply stage is a plain batched GEMM with 256 x 256 blocks.
+// V and M live in a caller-provided workspace (36*T*(Cin+Cout) floats: 1.8 GB on the headline res2 shape, against 288 GB).
+//
+// GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), block 256 tiles x 256 channels, K step 32; both operands
+// go global -> LDS by DMA (raw_ptr_buffer_load_lds, 1 KiB per wave instruction), two stages of 64 KiB.  U is the MFMA A
+// operand so that a lane's four accumulator registers are four consecutive output channels; the packed filter places
+// channel n = kq*32 + nt*4 + r of a wave's 128 at MFMA tile nt, row 4*kq + r: a lane ends up with 32 consecutive channels
+// of one tile row = one 128-byte line of M.  Persistent grid (one workgroup per CU), items enumerated so that the 32
+// workgroups of an XCD share one xi and neighbouring blocks (its L2 then holds their U panel and V panels once).
+#include "rn_common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int GBM = 256, GBN = 256, GBK = 32;
+constexpr int G_AB = GBM * GBK * 4, G_UB = GBK * GBN * 4, G_STAGE = G_AB + G_UB;    // 32 KiB + 32 KiB
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// XCD k (= workgroup id % 8) gets a contiguous range of the logical ids: neighbouring tiles share patch pixels / lines
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8) { return (blk & 7u) * (nblk8 >> 3) + (blk >> 3); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. input transform.  thread = (tile, 4 channels).  B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],
+//                                                          [0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
+__device__ __forceinline__ void bt6(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4, const f32x4 d5,
+                                    f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3, f32x4& t4, f32x4& t5)
+{
+    const f32x4 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
+    t0 = 4.f * d0 - 5.f * d2 + d4;
+    t1 = a + b;
+    t2 = a - b;
+    t3 = c + e;
+    t4 = c - e;
+    t5 = 4.f * d1 - 5.f * d3 + d5;
+}
+
+__global__ __launch_bounds__(256)
+void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, int th, int tw,
+                         long long T, unsigned nblk8)
+{
+    const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
+    const long long idx = (long long)blk * 256 + threadIdx.x;
+    const int C4 = C >> 2;
+    const int c4 = (int)(idx % C4);
+    const long long t = idx / C4;
+    if (t >= T) return;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
+    const long long b = t / ((long long)tw * th);
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const float* xb = x + ((size_t)b * H * W) * C + c4 * 4;
+    f32x4 tt[6][6];                                            // (B^T d)[i][col]
+#pragma unroll
+    for (int col = 0; col < 6; ++col) {
+        f32x4 d[6];
+        const int ix = x0 + col;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = y0 + r;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            d[r] = ok ? ld4(xb + ((size_t)iy * W + ix) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bt6(d[0], d[1], d[2], d[3], d[4], d[5], tt[0][col], tt[1][col], tt[2][col], tt[3][col], tt[4][col], tt[5][col]);
+    }
+    float* vb = V + (size_t)t * C + c4 * 4;
+    const size_t plane = (size_t)T * C;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v[6];
+        bt6(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st4(vb + (size_t)(i * 6 + j) * plane, v[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. output transform + conv epilogue.  thread = (tile, 4 channels).  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],
+//                                                                           [0,1,-1,8,-8,1]]
+__device__ __forceinline__ void at6(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
+                                    f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3)
+{
+    const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    y0 = m0 + s12 + s34;
+    y1 = d12 + 2.f * d34;
+    y2 = s12 + 4.f * s34;
+    y3 = d12 + 8.f * d34 + m5;
+}
+
+__global__ __launch_bounds__(256)
+void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
+                          const float* __restrict__ res, float* __restrict__ y, float* __restrict__ z,
+                          int H, int W, int C, int th, int tw, long long T, int act, unsigned nblk8)
+{
+    const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
+    const long long idx = (long long)blk * 256 + threadIdx.x;
+    const int C4 = C >> 2;
+    const int c4 = (int)(idx % C4);
+    const long long t = idx / C4;
+    if (t >= T) return;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
+    const long long b = t / ((long long)tw * th);
+    const float* mb = M + (size_t)t * C + c4 * 4;
+    const size_t plane = (size_t)T * C;
+    f32x4 s[4][6];                                             // (A^T m)[p][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = ld4(mb + (size_t)(i * 6 + j) * plane);
+        at6(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+    }
+    const f32x4 bv = bias ? ld4(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 av = (act & RN_ACT_PRELU) ? ld4(alpha + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x4 o[4];
+        at6(s[p][0], s[p][1], s[p][2], s[p][3], s[p][4], s[p][5], o[0], o[1], o[2], o[3]);
+        const int oy = 4 * ty + p;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ox = 4 * tx + q;
+            if (ox >= W) continue;
+            const size_t off = (((size_t)b * H + oy) * W + ox) * C + c4 * 4;
+            f32x4 v = o[q] + bv;
+            if (z) st4(z + off, v);
+            if (act & RN_ACT_PRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
+            }
+            if (act & RN_ACT_ELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
+            }
+            if (res) v += ld4(res + off);
+            if (act & RN_ACT_SIGMOID) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            }
+            st4(y + off, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. the 36 GEMMs  M[xi] = V[xi] (T x Cin) . U[xi] (Cin x Cout)
+struct W43GemmArgs {
+    const float* V; const float* U; float* M;
+    long long T;
+    int Cin, Cout;
+    int mblocks, nblocks, ksteps;
+    int nitems;                 // 36 * mblocks * nblocks
+    unsigned v_bytes, u_bytes;  // one xi plane of V; one (xi, n-block) panel of U
+};
+
+__global__ __launch_bounds__(512, 1)
+void wino43_gemm_kernel(const W43GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V 256 x 32 | U 8 x 256 x 4]
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;                          // 64-tile group (0..3), 128-channel half (0..1)
+
+    // fragment-read offsets inside a stage.  V rows are 128 B (32 k); their eight 16-B chunks are XOR-swizzled with
+    // (row >> 1) & 7 so that the 16 rows of a b128 read spread over all banks; chunk g*4 + kq holds k = 16g + 4kq .. +3.
+    const unsigned vrow = (unsigned)((wm * 64 + l16) * 128);
+    const unsigned vsw = (unsigned)((l16 >> 1) & 7);
+    const unsigned vaddr0 = vrow + (((unsigned)kq ^ vsw) << 4);
+    const unsigned vaddr1 = vrow + (((unsigned)(4 + kq) ^ vsw) << 4);
+    const unsigned uaddr = (unsigned)(G_AB + ((kq * 256) + wn * 128 + l16) * 16);
+
+    // DMA lane offsets: V piece p = wave + 8i covers rows 8p .. 8p+7 (lane>>3), chunk slot lane&7 holds chunk slot ^ swizzle
+    const unsigned dslot = (unsigned)(lane & 7);
+    const int rounds = (a.nitems + 255) >> 8;
+    const int perm = ((int)(blockIdx.x & 7) << 5) + (int)(blockIdx.x >> 3);          // XCD-contiguous slot in a round
+
+    for (int r = 0; r < rounds; ++r) {
+        const int L = (r << 8) + perm;
+        if (L >= a.nitems) break;
+        const int nb = L % a.nblocks;
+        const int mbx = L / a.nblocks;
+        const int mb = mbx % a.mblocks, xi = mbx / a.mblocks;
+        const long long m0 = (long long)mb * GBM;
+
+        const float* vplane = a.V + (size_t)xi * a.T * a.Cin;
+        const float* upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.Cin * GBN);
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vplane), 0, a.v_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upanel), 0, a.u_bytes, 0x00020000);
+
+        unsigned voff[4], uoff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave + 8 * i;
+            const int row = p * 8 + (lane >> 3);
+            const unsigned chunk = dslot ^ (unsigned)((row >> 1) & 7);
+            voff[i] = (unsigned)(((m0 + row) * a.Cin) * 4) + chunk * 16u;          // rows >= T fall outside v_bytes: zeros
+            uoff[i] = (unsigned)(p * 1024 + lane * 16);
+        }
+
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto issue = [&](int s, int stage) {
+            char* sb = smem + stage * G_STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wave + 8 * i;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + p * 1024), 16, voff[i], s * (GBK * 4), 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = wave + 8 * i;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + G_AB + p * 1024), 16, uoff[i], s * G_UB, 0, 0);
+            }
+        };
+
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int stage = 0;
+        for (int s = 0; s < a.ksteps; ++s) {
+            if (s + 1 < a.ksteps) issue(s + 1, stage ^ 1);
+            const char* sb = smem + stage * G_STAGE;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                f32x4 v[4], u[8];
+                const char* vp = sb + (g ? vaddr1 : vaddr0);
+                const char* up = sb + uaddr + g * (4 * 256 * 16);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const f32x4*>(vp + mt * (16 * 128));
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) u[nt] = *reinterpret_cast<const f32x4*>(up + nt * (16 * 16));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 8; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[nt][j], v[mt][j], acc[mt][nt], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stage ^= 1;
+        }
+
+        // D = U-tile (rows: channel slot 4*kq + r) x V-tile (cols: tile row l16): the lane holds channels
+        // n0 + wn*128 + kq*32 + nt*4 + r of tile row m0 + wm*64 + mt*16 + l16 (see the pack layout)
+        float* mplane = a.M + (size_t)xi * a.T * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const long long m = m0 + wm * 64 + mt * 16 + l16;
+            if (m < a.T) {
+                float* dst = mplane + (size_t)m * a.Cout + nb * GBN + wn * 128 + kq * 32;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) st4(dst + nt * 4, acc[mt][nt]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+bool rn_wino43_supported(int Cin, int Cout)
+{
+    static const bool off = getenv("RN_NO_WINOGRAD43") != nullptr || getenv("RN_NO_WINOGRAD") != nullptr;
+    return !off && Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
+}
+
+size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
+{
+    const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    return 36 * T * ((size_t)Cin + Cout);
+}
+
+// x [B,H,W,Cin] -> y [B,H,W,Cout]; u from pack_wino43_kernel; ws >= rn_wino43_workspace_floats(...) floats
+int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
+                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st)
+{
+    if (!rn_wino43_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: Cin=%d Cout=%d", Cin, Cout);
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    const int cmax = Cin > Cout ? Cin : Cout;
+    if ((long long)th * tw * cmax * 4 >= 0x7fffff00LL)
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: one image's transform plane exceeds the 2 GiB buffer window");
+    if (T * cmax * 4 >= 0x7fffff00LL) {                         // batch chunks: every xi plane must fit a buffer resource
+        const int chunk = (int)(0x7fffff00LL / ((long long)th * tw * cmax * 4));
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = B - b0 < chunk ? B - b0 : chunk;
+            const size_t xo = (size_t)b0 * H * W * Cin, yo = (size_t)b0 * H * W * Cout;
+            const int rc = rn_launch_conv_wino43(x + xo, u, bias, alpha, residual ? residual + yo : nullptr, y + yo,
+                                                 preact ? preact + yo : nullptr, ws, nb, H, W, Cin, Cout, act, st);
+            if (rc != RN_OK) return rc;
+        }
+        return RN_OK;
+    }
+    float* V = ws;
+    float* M = ws + (size_t)36 * T * Cin;
+    {
+        const unsigned long long n = ((unsigned long long)T * (Cin / 4) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL(wino43_input_kernel, dim3(nblk8), dim3(256), 0, st, x, V, H, W, Cin, th, tw, T, nblk8);
+        const int rc = rn_check_launch("wino43_input");
+        if (rc != RN_OK) return rc;
+    }
+    {
+        W43GemmArgs a;
+        a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
+        a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
+        a.nitems = 36 * a.mblocks * a.nblocks;
+        a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4);
+        const size_t lds = (size_t)2 * G_STAGE;
+        { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel), lds); if (rc_ != RN_OK) return rc_; }
+        hipLaunchKernelGGL(wino43_gemm_kernel, dim3(256), dim3(512), lds, st, a);
+        const int rc = rn_check_launch("wino43_gemm");
+        if (rc != RN_OK) return rc;
+    }
+    {
+        const unsigned long long n = ((unsigned long long)T * (Cout / 4) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL(wino43_output_kernel, dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                           H, W, Cout, th, tw, T, act, nblk8);
+        return rn_check_launch("wino43_output");
+    }
+}

@@ -46,6 +46,10 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
                         int mode, int pad, hipStream_t st);
 
+bool rn_wino43_supported(int Cin, int Cout);                                                              // conv_wino43.hip
+size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
+                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st);
 bool rn_wino_wgrad_supported(int Cin, int Cout);                                                          // conv_wino_wgrad.hip
 int rn_launch_conv_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 

@@ -10,6 +10,7 @@ parameter tensors to (one flat buffer, see rendernet_amd/train.py) and reports c
 gradient buckets can be all-reduced while the rest of the backward is still running.
 """
 import contextlib
+import os
 import ctypes
 
 import torch
@@ -50,8 +51,8 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None}
-        self._dirty = {"data": True, "wino": True, "wino4": True}
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None}
+        self._dirty = {"data": True, "wino": True, "wino4": True, "wino43": True}
         # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
         # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
         wkind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO}.get(kind)
@@ -62,6 +63,11 @@ class PackedWeight:
         w4kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO4, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO4}.get(kind)
         self._wino4_kind = w4kind if (w4kind is not None and ndim == 2 and self.kdims == [4, 4]
                                       and lib.rn_conv2d_wino4_supported(self.cin, self.cout)) else None
+
+        # Winograd F(4x4,3x3) (csrc/conv_wino43.hip): the wide 3x3 2-D layers (res2, res3 and their skips)
+        w43kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO43, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO43}.get(kind)
+        self._wino43_kind = w43kind if (w43kind is not None and ndim == 2 and self.kdims == [3, 3]
+                                        and lib.rn_conv2d_wino43_supported(self.cin, self.cout)) else None
 
     def _packed(self, which, kind):
         if self._dirty[which]:
@@ -91,6 +97,17 @@ class PackedWeight:
         if value is not None:
             raise ValueError("the Winograd pack can only be switched off (set to None)")
         self._wino_kind = None
+
+    @property
+    def wino43(self):
+        """The Winograd F(4x4,3x3) pack, or None."""
+        return None if self._wino43_kind is None else self._packed("wino43", self._wino43_kind)
+
+    @wino43.setter
+    def wino43(self, value):
+        if value is not None:
+            raise ValueError("the F(4x4,3x3) Winograd pack can only be switched off (set to None)")
+        self._wino43_kind = None
 
     @property
     def wino4(self):
@@ -320,6 +337,21 @@ def training(ctx):
         TRAIN = old
 
 
+def _wino43_fwd(x, u, e, B, H, W, Cin, Cout, act):
+    """rn_conv2d_wino43_fwd with its workspace (V and M planes) from torch's caching allocator."""
+    lib = L.lib()
+    n = lib.rn_conv2d_wino43_workspace_floats(B, H, W, Cin, Cout)
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    return lib.rn_conv2d_wino43_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
+
+
+def _use_wino43(pw, H, W):
+    return pw._wino43_kind is not None and H * W >= WINO43_MIN_PIXELS
+
+
+WINO43_MIN_PIXELS = int(os.environ.get("RN_WINO43_MIN_PIXELS", "64"))
+
+
 def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     lib, st = L.lib(), L.stream_ptr()
     e = (L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))          # the epilogue arguments of every entry
@@ -331,6 +363,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
         return lib.rn_conv3d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d":
         B, H, W, Cin = x.shape
+        if unit and _use_wino43(pw, H, W):
+            return _wino43_fwd(x, pw.wino43, e, B, H, W, Cin, pw.cout, act)
         if unit and pw.wino is not None:
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
         if unit and pw.wino4 is not None:
@@ -429,6 +463,8 @@ class _Conv(torch.autograd.Function):
                                             B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d":
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+            elif mode == "conv2d" and unit and _use_wino43(dp, H, W):
+                rc = _wino43_fwd(dz, dp.wino43, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
             elif mode == "conv2d" and unit and dp.wino is not None:
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
                 rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,

@@ -31,6 +31,14 @@ def main():
         pw = ops.pack_conv(w)
         flop = 2.0 * B * hw * hw * 9 * c * c
         res = {}
+        if pw.wino43 is not None:
+            ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
+            y43 = ops.conv2d(x, pw, b, al)
+            print("%s B=%d  F(4x4,3x3) %8.3f ms  %7.2f TFLOP/s direct-equivalent, %7.2f TFLOP/s executed (GEMM stage FLOPs / whole time)"
+                  % (sh, B, ms, flop / ms / 1e9, flop / 4.0 / ms / 1e9), flush=True)
+            pw.wino43 = None
+            y23 = ops.conv2d(x, pw, b, al)
+            print("   max|F43-F23| = %.3g (max|y| %.3g)" % (float((y43 - y23).abs().max()), float(y23.abs().max())), flush=True)
         if pw.wino is not None:
             ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
             yw = ops.conv2d(x, pw, b, al)
@@ -41,6 +49,7 @@ def main():
             continue
         wn = pw.wino
         pw.wino = None
+        pw.wino43 = None
         ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
         yd = ops.conv2d(x, pw, b, al)
         print("%s B=%d  direct   %8.3f ms  %7.2f TFLOP/s" % (sh, B, ms, flop / ms / 1e9), flush=True)

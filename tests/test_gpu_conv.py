@@ -224,6 +224,7 @@ def test_conv2d_winograd(case):
     b = _rand(rng, Cout) * 0.1
     alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
     pw = ops.pack_conv(_dev(w))
+    pw.wino43 = None                                                        # this test is about the F(2x2,3x3) kernel
     assert pw.wino is not None, "the Winograd pack must exist for a 3x3 filter with Cin%16==0, Cout%16==0"
     want_u = pack_wino(w)
     assert np.abs(pw.wino.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
@@ -237,6 +238,7 @@ def test_conv2d_winograd(case):
     # A/B against the direct kernel (same entry, Winograd pack dropped)
     pd = ops.pack_conv(_dev(w))
     pd.wino = None
+    pd.wino43 = None
     direct = ops.conv2d(_dev(x), pd, _dev(b), _dev(alpha), _dev(res))
     assert float((got - direct).abs().max()) <= 2e-5 * float(direct.abs().max())
     # input gradient through the transposed Winograd pack == the direct dgrad kernel's result
@@ -253,6 +255,92 @@ def test_conv2d_winograd(case):
     want_dx = OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1))       # w read as [k,k,Cout_T = Cin,Cin_T = Cout]
     _close(dx_w, want_dx, "wino dgrad vs oracle")
     assert float((dx_w - dx_d).abs().max()) <= 2e-5 * float(dx_d.abs().max())
+
+
+# Winograd F(4x4,3x3) path (csrc/conv_wino43.hip; input transform, 36 GEMMs, output transform): planes that are not
+# multiples of 4 (ragged tiles on both axes), tile counts below / across / above the 256-row GEMM block, Cin = 32 (one
+# K step) .. 1024, Cout = 256 .. 1024 (1 .. 4 channel blocks), item counts that are not a multiple of the persistent grid.
+WINO43_CASES = [
+    (1, 4, 4, 32, 256),
+    (2, 16, 16, 256, 256),
+    (1, 9, 11, 64, 512),
+    (3, 33, 5, 96, 256),
+    (1, 16, 16, 1024, 512),
+    (2, 64, 64, 64, 256),
+    (5, 30, 34, 128, 1024),
+    (1, 1, 1, 32, 256),
+]
+
+
+def _pack_wino43_numpy(w):
+    """NumPy statement of the RN_PACK_CONV_WINO43 layout (misc_kernels.hip, pack_wino43_kernel)."""
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                  [0, 0, 1]], np.float64)
+    Cin, Cout = w.shape[2], w.shape[3]
+    U = np.einsum("ia,abck,jb->ijck", G, w.astype(np.float64), G).reshape(36, Cin, Cout)
+    slot = np.arange(256)
+    wn, nt, si = slot >> 7, (slot >> 4) & 7, slot & 15
+    chan = wn * 128 + (si >> 2) * 32 + nt * 4 + (si & 3)                      # channel of the 256-block held by each slot
+    out = np.empty((36, Cout // 256, Cin // 4, 256, 4), np.float32)
+    for nb in range(Cout // 256):
+        blk = U[:, :, nb * 256 + chan]                                       # [36, Cin, 256 slots]
+        out[:, nb] = blk.reshape(36, Cin // 4, 4, 256).transpose(0, 1, 3, 2)
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_conv2d_winograd43(case):
+    """rn_conv2d_wino43_fwd vs the oracle conv (every epilogue flavour, the pre-activation output), vs the F(2x2,3x3) kernel
+    on the same filter, its packed filter vs the NumPy statement, and the input gradient through the transposed pack."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (3, 3, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    old, ops.WINO43_MIN_PIXELS = ops.WINO43_MIN_PIXELS, 1
+    try:
+        pw = ops.pack_conv(_dev(w))
+        assert pw.wino43 is not None
+        want_u = _pack_wino43_numpy(w)
+        assert np.abs(pw.wino43.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+        y0 = OL.conv2d(x, w, b, (1, 1))
+        _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "wino43")
+        res = _rand(rng, *y0.shape)
+        want = OL.prelu(y0, alpha) + torch.from_numpy(res)
+        got = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+        _close(got, want, "wino43+prelu+res")
+        _close(ops.conv2d(_dev(x), pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "wino43+sigmoid")
+        # the pre-activation output of the training forward
+        xd, wd, bd, ad = _dev(x), pw.wino43, _dev(b), _dev(alpha)
+        yy, zz = torch.empty((B, H, W, Cout), device="cuda"), torch.empty((B, H, W, Cout), device="cuda")
+        ws = torch.empty(L.lib().rn_conv2d_wino43_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+        L.check(L.lib().rn_conv2d_wino43_fwd(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(ad), None, L.ptr(yy), L.ptr(zz), L.ptr(ws),
+                                             B, H, W, Cin, Cout, 1, L.stream_ptr()), "rn_conv2d_wino43_fwd")
+        _close(zz, y0, "wino43 preact")
+        _close(yy, OL.prelu(y0, alpha), "wino43 prelu")
+        # A/B against the F(2x2,3x3) kernel
+        p2 = ops.pack_conv(_dev(w))
+        p2.wino43 = None
+        if p2.wino is not None:
+            ref2 = ops.conv2d(_dev(x), p2, _dev(b), _dev(alpha), _dev(res))
+            assert float((got - ref2).abs().max()) <= 1e-4 * float(ref2.abs().max())
+        # input gradient through the transposed pack (roles swap: needs Cout % 32 == 0 -- always -- and Cin % 256 == 0)
+        dp = pw.dgrad_pack(True)
+        if Cin % 256 == 0:
+            assert dp.wino43 is not None
+            dz = _dev(_rand(rng, B, H, W, Cout))
+            dx = torch.empty((B, H, W, Cin), device="cuda")
+            ws = torch.empty(L.lib().rn_conv2d_wino43_workspace_floats(B, H, W, Cout, Cin), device="cuda")
+            L.check(L.lib().rn_conv2d_wino43_fwd(L.ptr(dz), L.ptr(dp.wino43), None, None, None, L.ptr(dx), None, L.ptr(ws),
+                                                 B, H, W, Cout, Cin, 0, L.stream_ptr()), "rn_conv2d_wino43_fwd (dgrad)")
+            _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino43 dgrad vs oracle")
+        else:
+            assert dp.wino43 is None
+    finally:
+        ops.WINO43_MIN_PIXELS = old
 
 
 # ---------------------------------------------------------------------------------------------------------------
