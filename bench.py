@@ -241,7 +241,14 @@ def render_main(args, world, rank, local_rank):
             out = wl["render"](vox, aux, poses)
         # dominant kernel = the 3x3 conv of the res2 trunk (21 launches per step): bracket each of its launches with HIP
         # events on the launch stream during the timed region; same for the resampler's launches
-        events, rs_events = [], []
+        events, rs_events, gemm_events = [], [], []
+
+        def stage_hook(stage, tkn):
+            if stage == "gemm" and tkn[1] == wtrunk and tkn[2] == wtrunk:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                gemm_events.append((ev, tkn))
+                return ev
+            return None
 
         def hook(m, xshape, pw):
             if m == "resample":
@@ -250,11 +257,12 @@ def render_main(args, world, rank, local_rank):
                 return ev
             if m == "conv2d" and pw.cin == wtrunk and pw.cout == wtrunk and pw.kdims[0] == 3:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                events.append((ev, pw.wino is not None))
+                events.append((ev, "wino43" if ops._use_wino43(pw, xshape[1], xshape[2]) else "wino" if pw.wino is not None else "direct"))
                 return ev
             return None
 
         ops.LAUNCH_HOOK = hook
+        ops.STAGE_HOOK = stage_hook
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -262,6 +270,7 @@ def render_main(args, world, rank, local_rank):
         barrier()
         elapsed = time.perf_counter() - t0
         ops.LAUNCH_HOOK = None
+        ops.STAGE_HOOK = None
 
     assert out.shape == (nloc, wl["out_hw"], wl["out_hw"], wl["out_ch"])
     assert bool(torch.isfinite(out).all())
@@ -291,21 +300,37 @@ def render_main(args, world, rank, local_rank):
         "effective_tflops_direct_equiv": round(fps / world * gmac * 2e-3, 2),
     }
     if events:
-        kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in events]))
-        wino = all(w for _, w in events)
+        layer_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in events]))
+        kinds = {k for _, k in events}
+        kind = kinds.pop() if len(kinds) == 1 else "mixed"
         M = nloc * hw * hw
         direct_flop = 2.0 * M * 9 * wtrunk * wtrunk                    # M*K*N*2
-        exec_flop = direct_flop * 16.0 / 36.0 if wino else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
+        where = " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc)
+        if kind == "wino43" and gemm_events:
+            # three launches per layer; the dominant one is the GEMM stage (36 GEMMs T x Cin x Cout), timed on its own
+            kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
+            T = gemm_events[0][1][0]
+            exec_flop = 2.0 * 36 * T * wtrunk * wtrunk
+            name = "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3): 256x256x32 blocks, 16x16x4 fp32 MFMA, LDS-DMA, persistent)"
+            basis = "executed MFMA FLOPs = 2*36*T*Cin*Cout, T = B*ceil(H/4)*ceil(W/4) tiles"
+            tkey = "wino43_gemm_res2"
+        else:
+            kern_ms = layer_ms
+            exec_flop = direct_flop * 16.0 / 36.0 if kind == "wino" else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
+            name = ("conv_wino_kernel (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA, fused transforms)" if kind == "wino" else
+                    "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA)")
+            basis = "executed MFMA FLOPs = 2*(M/4)*16*Cin*Cout" if kind == "wino" else "2*M*9*Cin*Cout"
+            tkey = "conv_wino_res2" if kind == "wino" else "conv_igemm_res2"
         achieved = exec_flop / (kern_ms * 1e-3) / 1e12
-        traffic, tsrc = read_traffic("conv_wino_res2" if wino else "conv_igemm_res2") if (mode == "render" and nloc == 24) else (None, None)
+        traffic, tsrc = read_traffic(tkey) if (mode == "render" and nloc == 24) else (None, None)
         res["roofline"] = {
-            "kernel": ("conv_wino_kernel (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA, fused transforms)" if wino else
-                       "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA)") + " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc),
+            "kernel": name + where,
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(kern_ms, 4),
-            "launches_timed": len(events), "flop_per_launch": exec_flop,
-            "flop_basis": "executed MFMA FLOPs = 2*(M/4)*16*Cin*Cout" if wino else "2*M*9*Cin*Cout",
-            "effective_tflops_direct_equiv": round(direct_flop / (kern_ms * 1e-3) / 1e12, 2),
+            "launches_timed": len(gemm_events) if kind == "wino43" and gemm_events else len(events), "flop_per_launch": exec_flop,
+            "flop_basis": basis,
+            "layer_ms": round(layer_ms, 4),       # the whole layer (wino43: input transform + GEMM + output transform)
+            "layer_effective_tflops_direct_equiv": round(direct_flop / (layer_ms * 1e-3) / 1e12, 2),
             "traffic": traffic, "traffic_source": tsrc}
     if rs_events:
         # second roofline of the path: the resampler is HBM-bound (per frame and channel 1 MiB (64^3) source

@@ -190,6 +190,12 @@ size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
 int rn_conv2d_wino43_fwd(const float* x, const float* w_wino43, const float* bias, const float* alpha,
                          const float* residual, float* y, float* preact, float* workspace,
                          int B, int H, int W, int Cin, int Cout, int act, void* stream);
+/* The three stages of rn_conv2d_wino43_fwd on their own (T = B*ceil(H/4)*ceil(W/4) tiles; V [36][T][Cin], M [36][T][Cout];
+ * every 36-th of V and M must stay below 2 GiB -- rn_conv2d_wino43_fwd splits the batch itself, these do not). */
+int rn_wino43_input_transform(const float* x, float* V, int B, int H, int W, int C, void* stream);
+int rn_wino43_gemm(const float* V, const float* w_wino43, float* M, long long T, int Cin, int Cout, void* stream);
+int rn_wino43_output_transform(const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                               float* preact, int B, int H, int W, int C, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

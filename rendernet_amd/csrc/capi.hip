@@ -385,6 +385,26 @@ extern "C" int rn_conv2d_wino43_fwd(const float* x, const float* w, const float*
     return rn_launch_conv_wino43(x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, act, (hipStream_t)stream);
 }
 
+extern "C" int rn_wino43_input_transform(const float* x, float* V, int B, int H, int W, int C, void* stream)
+{
+    if (!x || !V) return rn_set_error(RN_E_INVALID, "rn_wino43_input_transform: null pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_wino43_input_transform: bad sizes");
+    return rn_launch_wino43_input(x, V, B, H, W, C, (hipStream_t)stream);
+}
+extern "C" int rn_wino43_gemm(const float* V, const float* w, float* M, long long T, int Cin, int Cout, void* stream)
+{
+    if (!V || !w || !M) return rn_set_error(RN_E_INVALID, "rn_wino43_gemm: null pointer");
+    return rn_launch_wino43_gemm(V, w, M, T, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int rn_wino43_output_transform(const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                                          float* preact, int B, int H, int W, int C, int act, void* stream)
+{
+    if (!M || !y) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: null pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: PReLU needs alpha");
+    return rn_launch_wino43_output(M, bias, alpha, residual, y, preact, B, H, W, C, act, (hipStream_t)stream);
+}
+
 extern "C" int rn_conv2d_wino_wgrad_supported(int Cin, int Cout) { return rn_wino_wgrad_supported(Cin, Cout) ? 1 : 0; }
 
 extern "C" int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream)

@@ -287,6 +287,45 @@ bool rn_wino43_supported(int Cin, int Cout)
     return !off && Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
 }
 
+// the three stages on their own (the C ABI exposes them: a caller can keep V / M, or time the stages separately)
+int rn_launch_wino43_input(const float* x, float* V, int B, int H, int W, int C, hipStream_t st)
+{
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
+    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    hipLaunchKernelGGL(wino43_input_kernel, dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8);
+    return rn_check_launch("wino43_input");
+}
+
+int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
+{
+    if (!rn_wino43_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: Cin=%d Cout=%d", Cin, Cout);
+    if (T < 1 || T * (Cin > Cout ? Cin : Cout) * 4 >= 0x7fffff00LL)
+        return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: a transform plane must stay below the 2 GiB buffer window");
+    W43GemmArgs a;
+    a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
+    a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
+    a.nitems = 36 * a.mblocks * a.nblocks;
+    a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4);
+    const size_t lds = (size_t)2 * G_STAGE;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel), lds); if (rc_ != RN_OK) return rc_; }
+    hipLaunchKernelGGL(wino43_gemm_kernel, dim3(256), dim3(512), lds, st, a);
+    return rn_check_launch("wino43_gemm");
+}
+
+int rn_launch_wino43_output(const float* M, const float* bias, const float* alpha, const float* residual, float* y, float* preact,
+                            int B, int H, int W, int C, int act, hipStream_t st)
+{
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
+    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    hipLaunchKernelGGL(wino43_output_kernel, dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                       H, W, C, th, tw, T, act, nblk8);
+    return rn_check_launch("wino43_output");
+}
+
 size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
 {
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
@@ -316,30 +355,9 @@ int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, con
     }
     float* V = ws;
     float* M = ws + (size_t)36 * T * Cin;
-    {
-        const unsigned long long n = ((unsigned long long)T * (Cin / 4) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-        hipLaunchKernelGGL(wino43_input_kernel, dim3(nblk8), dim3(256), 0, st, x, V, H, W, Cin, th, tw, T, nblk8);
-        const int rc = rn_check_launch("wino43_input");
-        if (rc != RN_OK) return rc;
-    }
-    {
-        W43GemmArgs a;
-        a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
-        a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
-        a.nitems = 36 * a.mblocks * a.nblocks;
-        a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4);
-        const size_t lds = (size_t)2 * G_STAGE;
-        { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel), lds); if (rc_ != RN_OK) return rc_; }
-        hipLaunchKernelGGL(wino43_gemm_kernel, dim3(256), dim3(512), lds, st, a);
-        const int rc = rn_check_launch("wino43_gemm");
-        if (rc != RN_OK) return rc;
-    }
-    {
-        const unsigned long long n = ((unsigned long long)T * (Cout / 4) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-        hipLaunchKernelGGL(wino43_output_kernel, dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, Cout, th, tw, T, act, nblk8);
-        return rn_check_launch("wino43_output");
-    }
+    int rc = rn_launch_wino43_input(x, V, B, H, W, Cin, st);
+    if (rc != RN_OK) return rc;
+    rc = rn_launch_wino43_gemm(V, u, M, T, Cin, Cout, st);
+    if (rc != RN_OK) return rc;
+    return rn_launch_wino43_output(M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
 }

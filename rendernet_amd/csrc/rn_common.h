@@ -48,6 +48,10 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
 
 bool rn_wino43_supported(int Cin, int Cout);                                                              // conv_wino43.hip
 size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_launch_wino43_input(const float* x, float* V, int B, int H, int W, int C, hipStream_t st);
+int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st);
+int rn_launch_wino43_output(const float* M, const float* bias, const float* alpha, const float* residual, float* y, float* preact,
+                            int B, int H, int W, int C, int act, hipStream_t st);
 int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
                           float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st);
 bool rn_wino_wgrad_supported(int Cin, int Cout);                                                          // conv_wino_wgrad.hip

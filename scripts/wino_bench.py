@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--shapes", type=str, default="64x1024,64x512")
     ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--only", choices=["f43", "f23", "direct"], default=None, help="time just one implementation")
     args = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
     for sh in args.shapes.split(","):
@@ -31,11 +32,17 @@ def main():
         pw = ops.pack_conv(w)
         flop = 2.0 * B * hw * hw * 9 * c * c
         res = {}
+        if args.only in ("f23", "direct"):
+            pw.wino43 = None
+        if args.only == "direct":
+            pw.wino = None
         if pw.wino43 is not None:
             ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
             y43 = ops.conv2d(x, pw, b, al)
             print("%s B=%d  F(4x4,3x3) %8.3f ms  %7.2f TFLOP/s direct-equivalent, %7.2f TFLOP/s executed (GEMM stage FLOPs / whole time)"
                   % (sh, B, ms, flop / ms / 1e9, flop / 4.0 / ms / 1e9), flush=True)
+            if args.only == "f43":
+                continue
             pw.wino43 = None
             y23 = ops.conv2d(x, pw, b, al)
             print("   max|F43-F23| = %.3g (max|y| %.3g)" % (float((y43 - y23).abs().max()), float(y23.abs().max())), flush=True)
@@ -45,7 +52,7 @@ def main():
             res["wino"] = ms
             print("%s B=%d  winograd %8.3f ms  %7.2f TFLOP/s direct-equivalent, %7.2f TFLOP/s executed"
                   % (sh, B, ms, flop / ms / 1e9, flop / 2.25 / ms / 1e9), flush=True)
-        if args.wino_only:
+        if args.wino_only or args.only == "f23":
             continue
         wn = pw.wino
         pw.wino = None
