@@ -15,19 +15,20 @@
 //
 // GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), block 256 tiles x 256 channels, K step 32; both operands
 // go global -> LDS by DMA (raw_ptr_buffer_load_lds, 1 KiB per wave instruction), two stages of 64 KiB.  U is the MFMA A
-// operand so that a lane's four accumulator registers are four consecutive output channels; the packed filter places
-// channel n = kq*32 + nt*4 + r of a wave's 128 at MFMA tile nt, row 4*kq + r: a lane ends up with 32 consecutive channels
-// of one tile row = one 128-byte line of M.  Persistent grid (one workgroup per CU), items enumerated so that the 32
+// operand so that a lane's four accumulator registers are four consecutive output channels (16-byte stores, 64 contiguous
+// bytes per tile row and store instruction).  Persistent grid (one workgroup per CU), items enumerated so that the 32
 // workgroups of an XCD share one xi and neighbouring blocks (its L2 then holds their U panel and V panels once).
 #include "rn_common.h"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int GBM = 256, GBN = 256, GBK = 32;
-constexpr int G_AB = GBM * GBK * 4, G_UB = GBK * GBN * 4, G_STAGE = G_AB + G_UB;    // 32 KiB + 32 KiB
+constexpr int G_UB = GBK * GBN * 4;                                                  // U part of a stage: 32 KiB
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -160,124 +161,161 @@ void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2. the 36 GEMMs  M[xi] = V[xi] (T x Cin) . U[xi] (Cin x Cout)
+// 2. the GEMMs  M[xi] = V[xi] (T x Cin) . U[xi] (Cin x Cout), xi = 0 .. nxi-1
 struct W43GemmArgs {
     const float* V; const float* U; float* M;
     long long T;
     int Cin, Cout;
-    int mblocks, nblocks, ksteps;
-    int nitems;                 // 36 * mblocks * nblocks
-    unsigned v_bytes, u_bytes;  // one xi plane of V; one (xi, n-block) panel of U
+    int mblocks, nblocks, ksteps;   // 256-row blocks of T, 256-channel blocks, K steps of 32
+    int item_begin, item_end;       // this launch's range of the items L = (xi*mblocks + mb)*nblocks + nb
+    unsigned v_bytes, u_bytes, m_bytes;  // one xi plane of V; one (xi, n-block) panel of U; one xi plane of M
+    int probe;                      // RN_WINO43_PROBE (timing experiments; results are wrong when set): 1 no DMA in the loop, 2 no stores, 4 no barrier
 };
 
+template <int VP> struct W43Item { const float* vplane; const float* upanel; float* mplane; long long m0; int nb; unsigned voff[VP]; };
+
+// WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128, 128 accumulators);
+// 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64): the launcher runs the last, partial round of a launch as half
+// items of this shape so that it costs half a round.
+template <int WM>
 __global__ __launch_bounds__(512, 1)
 void wino43_gemm_kernel(const W43GemmArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V 256 x 32 | U 8 x 256 x 4]
+#if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the stub: the amdgcn builtins below do not instantiate there
+    constexpr int WN = 8 / WM, NT = 16 / WN;                          // 16-channel MFMA tiles per wave along channels (8 | 4)
+    constexpr int BM = WM * 64, VB = BM * GBK * 4, STAGE = VB + G_UB; // V 32 | 16 KiB + U 32 KiB per stage
+    constexpr int VP = BM / 8 / 8;                                    // V DMA pieces per wave and stage (4 | 2)
+    constexpr int HALF = WM == 2 ? 2 : 1;                             // half items per 256-row item
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V BM x 32 | U 8 x 256 x 4]
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;                          // 64-tile group (0..3), 128-channel half (0..1)
+    const int wm = wave / WN, wn = wave % WN;
 
-    // fragment-read offsets inside a stage.  V rows are 128 B (32 k); their eight 16-B chunks are XOR-swizzled with
-    // (row >> 1) & 7 so that the 16 rows of a b128 read spread over all banks; chunk g*4 + kq holds k = 16g + 4kq .. +3.
-    const unsigned vrow = (unsigned)((wm * 64 + l16) * 128);
+    // fragment-read offsets inside a stage.  A K step of 32 is consumed as four sub-groups q of 8 k: lane (l16, kq) supplies
+    // k = 8q + 2kq + j to MFMA j = 0, 1 of the sub-group -- one 8-byte LDS read per operand row.  V rows are 128 B (32 k);
+    // their eight 16-B chunks are XOR-swizzled with (row >> 1) & 7 so that the rows of a read spread over all banks.
+    const unsigned vrow = (unsigned)((wm * 64 + l16) * 128 + (kq & 1) * 8);
     const unsigned vsw = (unsigned)((l16 >> 1) & 7);
-    const unsigned vaddr0 = vrow + (((unsigned)kq ^ vsw) << 4);
-    const unsigned vaddr1 = vrow + (((unsigned)(4 + kq) ^ vsw) << 4);
-    const unsigned uaddr = (unsigned)(G_AB + ((kq * 256) + wn * 128 + l16) * 16);
+    unsigned vaddr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vaddr[q] = vrow + (((unsigned)(2 * q + (kq >> 1)) ^ vsw) << 4);
+    const unsigned uaddr = (unsigned)(VB + (((kq >> 1) * 256) + wn * (NT * 16) + l16) * 16 + (kq & 1) * 8);
 
-    // DMA lane offsets: V piece p = wave + 8i covers rows 8p .. 8p+7 (lane>>3), chunk slot lane&7 holds chunk slot ^ swizzle
-    const unsigned dslot = (unsigned)(lane & 7);
-    const int rounds = (a.nitems + 255) >> 8;
-    const int perm = ((int)(blockIdx.x & 7) << 5) + (int)(blockIdx.x >> 3);          // XCD-contiguous slot in a round
-
-    for (int r = 0; r < rounds; ++r) {
-        const int L = (r << 8) + perm;
-        if (L >= a.nitems) break;
+    // one item: decoded into scalars + the per-lane V offsets of this wave's DMA pieces (piece p = wave + 8i covers rows
+    // 8p .. 8p+7 (lane >> 3); chunk slot lane & 7 holds chunk slot ^ swizzle(row))
+    typedef W43Item<VP> Item;
+    const int rounds_total = (a.item_end - a.item_begin) * HALF;
+    const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // XCD-contiguous slot in a round
+    auto decode = [&](int r, Item& it) -> bool {
+        const int id = r * (int)gridDim.x + perm;                     // gridDim.x is a multiple of 8
+        if (id >= rounds_total) return false;
+        const int L = a.item_begin + id / HALF, h = id % HALF;
         const int nb = L % a.nblocks;
         const int mbx = L / a.nblocks;
         const int mb = mbx % a.mblocks, xi = mbx / a.mblocks;
-        const long long m0 = (long long)mb * GBM;
-
-        const float* vplane = a.V + (size_t)xi * a.T * a.Cin;
-        const float* upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.Cin * GBN);
-        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vplane), 0, a.v_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(upanel), 0, a.u_bytes, 0x00020000);
-
-        unsigned voff[4], uoff[4];
+        it.nb = nb;
+        it.m0 = (long long)mb * GBM + h * BM;
+        it.vplane = a.V + (size_t)xi * a.T * a.Cin;
+        it.upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.Cin * GBN);
+        it.mplane = a.M + (size_t)xi * a.T * a.Cout;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = wave + 8 * i;
-            const int row = p * 8 + (lane >> 3);
-            const unsigned chunk = dslot ^ (unsigned)((row >> 1) & 7);
-            voff[i] = (unsigned)(((m0 + row) * a.Cin) * 4) + chunk * 16u;          // rows >= T fall outside v_bytes: zeros
-            uoff[i] = (unsigned)(p * 1024 + lane * 16);
+        for (int i = 0; i < VP; ++i) {
+            const int row = (wave + 8 * i) * 8 + (lane >> 3);
+            const unsigned chunk = (unsigned)(lane & 7) ^ (unsigned)((row >> 1) & 7);
+            it.voff[i] = (unsigned)(((it.m0 + row) * a.Cin) * 4) + chunk * 16u;     // rows >= T fall outside v_bytes: zeros
         }
+        return true;
+    };
+    auto issue = [&](const Item& it, int s, int stage) {
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(it.vplane), 0, a.v_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(it.upanel), 0, a.u_bytes, 0x00020000);
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < VP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * i) * 1024), 16, it.voff[i], s * (GBK * 4), 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 8 * i) * 1024), 16,
+                                                     (unsigned)((wave + 8 * i) * 1024 + lane * 16), s * G_UB, 0, 0);
+    };
 
-        f32x4 acc[4][8];
+    f32x4 acc[4][NT];
+    // fragments of sub-group (stage buffer sb, q): 4 tile-row groups of V, NT channel groups of U
+    auto load_frags = [&](const char* sb, int q, f32x2 (&v)[4], f32x2 (&u)[NT]) {
+        const char* vp = sb + vaddr[q];
+        const char* up = sb + uaddr + q * (2 * 256 * 16);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const f32x2*>(vp + mt * (16 * 128));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) u[nt] = *reinterpret_cast<const f32x2*>(up + nt * (16 * 16));
+    };
+    auto mfmas = [&](const f32x2 (&v)[4], const f32x2 (&u)[NT]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[nt][j], v[mt][j], acc[mt][nt], 0, 0, 0);
+    };
+
+    Item cur, nxt;
+    if (!decode(0, cur)) return;
+    // Software pipeline: the fragments of sub-group q+1 are read from LDS while the 64 (32) MFMAs of sub-group q run, across
+    // K steps and across items -- the one barrier of a step sits before its last sub-group, where the next stage has landed
+    // (DMAs issued at the head of the step; in an item's last step they fetch the NEXT item's first stage) and every wave
+    // has finished reading the current one.  The epilogue's stores drain under the next item's first step.
+    f32x2 v0[4], u0[NT], v1[4], u1[NT];
+    issue(cur, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(smem, 0, v0, u0);
+    int stage = 0;
+    for (int r = 0;; ++r) {
+        const bool have_next = decode(r + 1, nxt);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        auto issue = [&](int s, int stage) {
-            char* sb = smem + stage * G_STAGE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = wave + 8 * i;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + p * 1024), 16, voff[i], s * (GBK * 4), 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = wave + 8 * i;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + G_AB + p * 1024), 16, uoff[i], s * G_UB, 0, 0);
-            }
-        };
-
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int stage = 0;
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < a.ksteps; ++s) {
-            if (s + 1 < a.ksteps) issue(s + 1, stage ^ 1);
-            const char* sb = smem + stage * G_STAGE;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                f32x4 v[4], u[8];
-                const char* vp = sb + (g ? vaddr1 : vaddr0);
-                const char* up = sb + uaddr + g * (4 * 256 * 16);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const f32x4*>(vp + mt * (16 * 128));
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) u[nt] = *reinterpret_cast<const f32x4*>(up + nt * (16 * 16));
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 8; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[nt][j], v[mt][j], acc[mt][nt], 0, 0, 0);
+            const char* sb = smem + stage * STAGE;
+            const char* sn = smem + (stage ^ 1) * STAGE;
+            const bool last = s + 1 == a.ksteps;
+            if (!(a.probe & 1)) {
+                if (!last) issue(cur, s + 1, stage ^ 1);
+                else if (have_next) issue(nxt, 0, stage ^ 1);
             }
+            load_frags(sb, 1, v1, u1);
+            mfmas(v0, u0);
+            load_frags(sb, 2, v0, u0);
+            mfmas(v1, u1);
+            load_frags(sb, 3, v1, u1);
+            mfmas(v0, u0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!(a.probe & 4)) __syncthreads();
+            if (!last || have_next) load_frags(sn, 0, v0, u0);
+            mfmas(v1, u1);
             stage ^= 1;
         }
-
-        // D = U-tile (rows: channel slot 4*kq + r) x V-tile (cols: tile row l16): the lane holds channels
-        // n0 + wn*128 + kq*32 + nt*4 + r of tile row m0 + wm*64 + mt*16 + l16 (see the pack layout)
-        float* mplane = a.M + (size_t)xi * a.T * a.Cout;
+        // D = U-tile (rows: channel 4*kq + r of the tile) x V-tile (cols: tile row l16): the lane holds channels
+        // n0 + wn*NT*16 + nt*16 + 4*kq + r of tile row m0 + wm*64 + mt*16 + l16; a store covers 64 contiguous bytes per row.
+        // Buffer stores: rows >= T fall outside m_bytes and are dropped by the hardware.
+        if (!(a.probe & 2)) {
+            const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
+            const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l16) * a.Cout + cur.nb * GBN + wn * (NT * 16) + kq * 4) * 4);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const long long m = m0 + wm * 64 + mt * 16 + l16;
-            if (m < a.T) {
-                float* dst = mplane + (size_t)m * a.Cout + nb * GBN + wn * 128 + kq * 32;
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) st4(dst + nt * 4, acc[mt][nt]);
-            }
+                for (int nt = 0; nt < NT; ++nt)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), mrsrc,
+                                                           mo + (unsigned)(mt * 16 * a.Cout * 4) + nt * 64, 0, 0);
         }
+        if (!have_next) break;
+        cur = nxt;
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -298,20 +336,38 @@ int rn_launch_wino43_input(const float* x, float* V, int B, int H, int W, int C,
     return rn_check_launch("wino43_input");
 }
 
+template <int WM>
+static int wino43_gemm_launch(W43GemmArgs a, int begin, int end, hipStream_t st)
+{
+    a.item_begin = begin; a.item_end = end;
+    const size_t lds = (size_t)2 * (WM * 64 * GBK * 4 + G_UB);
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel<WM>), lds); if (rc_ != RN_OK) return rc_; }
+    const int n = (end - begin) * (WM == 2 ? 2 : 1);
+    hipLaunchKernelGGL(wino43_gemm_kernel<WM>, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+    return rn_check_launch("wino43_gemm");
+}
+
 int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
 {
     if (!rn_wino43_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: Cin=%d Cout=%d", Cin, Cout);
-    if (T < 1 || T * (Cin > Cout ? Cin : Cout) * 4 >= 0x7fffff00LL)
+    if (T < 1 || (T + GBM) * (Cin > Cout ? Cin : Cout) * 4 >= 0xffffff00LL || T * (Cin > Cout ? Cin : Cout) * 4 >= 0x7fffff00LL)
         return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: a transform plane must stay below the 2 GiB buffer window");
     W43GemmArgs a;
     a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
     a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
-    a.nitems = 36 * a.mblocks * a.nblocks;
-    a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4);
-    const size_t lds = (size_t)2 * G_STAGE;
-    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel), lds); if (rc_ != RN_OK) return rc_; }
-    hipLaunchKernelGGL(wino43_gemm_kernel, dim3(256), dim3(512), lds, st, a);
-    return rn_check_launch("wino43_gemm");
+    const int nitems = 36 * a.mblocks * a.nblocks;
+    a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4); a.m_bytes = (unsigned)(T * Cout * 4);
+    { static const int probe = getenv("RN_WINO43_PROBE") ? atoi(getenv("RN_WINO43_PROBE")) : 0; a.probe = probe; }
+    // one workgroup per CU takes items id, id + 256, ...: a last round of <= 128 items runs as <= 256 half items (128 rows)
+    static const bool notail = getenv("RN_WINO43_NOTAIL") != nullptr;
+    const int rem = nitems % 256;
+    const int tail = (!notail && rem != 0 && rem <= 128) ? rem : 0;
+    if (nitems - tail > 0) {
+        const int rc = wino43_gemm_launch<4>(a, 0, nitems - tail, st);
+        if (rc != RN_OK) return rc;
+    }
+    if (tail > 0) return wino43_gemm_launch<2>(a, nitems - tail, nitems, st);
+    return RN_OK;
 }
 
 int rn_launch_wino43_output(const float* M, const float* bias, const float* alpha, const float* residual, float* y, float* preact,

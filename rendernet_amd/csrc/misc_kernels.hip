@@ -132,9 +132,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w_tf, float* __restr
 
 // Winograd F(4x4,3x3) filter transform for csrc/conv_wino43.hip: U = G g G^T with G = [[1/4,0,0],[-1/6,-1/6,-1/6],
 // [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], packed [36 xi][Cout/256][Cin/4][256 slots][4 k]: the panel of
-// one (xi, 256-channel block) is contiguous, K step s of the GEMM is its s-th 32 KiB.  Slot (wn, nt, i) = wn*128 + nt*16 + i
-// holds channel wn*128 + (i>>2)*32 + nt*4 + (i&3) of the block: MFMA tile nt, row i of wave half wn (see the kernel's
-// epilogue).  RN_PACK_CONV_WINO43 reads w_tf[3,3,Cin,Cout]; RN_PACK_CONVT_S1_WINO43 w_tf[3,3,Cout,Cin] with the taps flipped.
+// one (xi, 256-channel block) is contiguous, K step s of the GEMM is its s-th 32 KiB; slot n holds channel n of the block.
+// RN_PACK_CONV_WINO43 reads w_tf[3,3,Cin,Cout]; RN_PACK_CONVT_S1_WINO43 w_tf[3,3,Cout,Cin] with the taps flipped.
 __global__ void pack_wino43_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
 {
     const size_t total = (size_t)36 * Cin * Cout;
@@ -146,8 +145,7 @@ __global__ void pack_wino43_kernel(const float* __restrict__ w_tf, float* __rest
         const int kg = (int)(rem % nkg); rem /= nkg;
         const int nb = (int)(rem % nblocks);
         const int xi = (int)(rem / nblocks);
-        const int wn = slot >> 7, nt = (slot >> 4) & 7, si = slot & 15;
-        const int co = nb * 256 + wn * 128 + (si >> 2) * 32 + nt * 4 + (si & 3);
+        const int co = nb * 256 + slot;
         const int c = kg * 4 + r;
         const int i = xi / 6, j = xi - 6 * i;
         float g[3][3];

@@ -278,12 +278,9 @@ def _pack_wino43_numpy(w):
                   [0, 0, 1]], np.float64)
     Cin, Cout = w.shape[2], w.shape[3]
     U = np.einsum("ia,abck,jb->ijck", G, w.astype(np.float64), G).reshape(36, Cin, Cout)
-    slot = np.arange(256)
-    wn, nt, si = slot >> 7, (slot >> 4) & 7, slot & 15
-    chan = wn * 128 + (si >> 2) * 32 + nt * 4 + (si & 3)                      # channel of the 256-block held by each slot
     out = np.empty((36, Cout // 256, Cin // 4, 256, 4), np.float32)
     for nb in range(Cout // 256):
-        blk = U[:, :, nb * 256 + chan]                                       # [36, Cin, 256 slots]
+        blk = U[:, :, nb * 256:(nb + 1) * 256]                               # [36, Cin, 256 channels of the block]
         out[:, nb] = blk.reshape(36, Cin // 4, 4, 256).transpose(0, 1, 3, 2)
     return out.reshape(-1)
 
