@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 150            /* 0.1.5: + Winograd paths (3x3, 3x3x3, 4x4 filters), dropout */
+#define RN_VERSION 160            /* 0.1.6: + Winograd F(4x4,3x3) / F(4x4,4x4) three-launch paths, Winograd filter gradient */
 
 /* error codes */
 #define RN_OK              0
@@ -59,6 +59,10 @@ extern "C" {
                                      36*Cin*Cout floats, Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino43_fwd      */
 #define RN_PACK_CONVT_S1_WINO43 8  /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same transform
                                      (= the input gradient of a 3x3 conv when fed that conv's filter)               */
+#define RN_PACK_CONV_WINO44     9  /* TF conv filter [4,4,Cin,Cout] -> Winograd F(4x4,4x4) form (49 planes, 49*Cin*Cout floats,
+                                     Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino44_fwd                            */
+#define RN_PACK_CONVT_S1_WINO44 10 /* TF conv_transpose filter [4,4,Cout,Cin], stride 1, taps flipped, same transform:
+                                     rn_conv2d_wino44_fwd with transposed = 1                                          */
 #define RN_PACK_CONV_WINO4      5  /* TF conv filter [4,4,Cin,Cout] as four 2x2 sub-filters, each Winograd F(2x2,2x2)
                                      transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 16 == 0) for
                                      rn_conv2d_wino4_fwd                                                          */
@@ -182,20 +186,35 @@ int rn_conv2d_wino_supported(int Cin, int Cout);
  * instead of 144 (F(2x2,3x3): 64) -- in three launches: input transform V = B^T d B of every 6x6 patch, 36 exact-fp32 MFMA
  * GEMMs M[xi] = V[xi] . U[xi], output transform A^T m A fused with the bias / PReLU / residual epilogue.  V and M live in
  * `workspace` (rn_conv2d_wino43_workspace_floats(B,H,W,Cin,Cout) floats, device memory, contents undefined afterwards).
- * Same epilogue contract as rn_conv2d_fwd_train.  fp32 rounding: about 2e-5 of max|y| at Cin = 1024 (the transforms'
- * constants reach 8 and 1/24), against 1e-6 for the F(2x2) path; the end-to-end tolerance of the path is 1e-3.
- * Needs Cin % 32 == 0 and Cout % 256 == 0 (rn_conv2d_wino43_supported). */
+ * Same epilogue contract as rn_conv2d_fwd_train.  fp32 rounding: about 5e-6 of max|y| at Cin = 1024 (interpolation points
+ * 0, 1, -1, 2, -1/2, inf), against 1e-6 for the F(2x2) path; the end-to-end tolerance of the path is 1e-3.
+ * Needs Cin % 32 == 0 and Cout % 256 == 0 (rn_conv2d_wino43_supported).
+ *
+ * rn_conv2d_wino44_fwd: the 4x4, stride-1 layers (e_conv5, e_conv6: slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103)
+ * through F(4x4,4x4): 49 multiplies per 4x4 outputs and channel pair instead of 256 (rn_conv2d_wino4_fwd: 144); same three
+ * launches on 7x7 patches.  transposed = 0: SAME conv (one row/column of padding before), filter packed with
+ * RN_PACK_CONV_WINO44; transposed = 1: stride-1 conv2d_transpose (two before), RN_PACK_CONVT_S1_WINO44 -- the input
+ * gradient of the conv when fed the conv's own filter.  fp32 rounding about 1e-5 of max|y|. */
 int rn_conv2d_wino43_supported(int Cin, int Cout);
 size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
 int rn_conv2d_wino43_fwd(const float* x, const float* w_wino43, const float* bias, const float* alpha,
                          const float* residual, float* y, float* preact, float* workspace,
                          int B, int H, int W, int Cin, int Cout, int act, void* stream);
-/* The three stages of rn_conv2d_wino43_fwd on their own (T = B*ceil(H/4)*ceil(W/4) tiles; V [36][T][Cin], M [36][T][Cout];
- * every 36-th of V and M must stay below 2 GiB -- rn_conv2d_wino43_fwd splits the batch itself, these do not). */
-int rn_wino43_input_transform(const float* x, float* V, int B, int H, int W, int C, void* stream);
-int rn_wino43_gemm(const float* V, const float* w_wino43, float* M, long long T, int Cin, int Cout, void* stream);
-int rn_wino43_output_transform(const float* M, const float* bias, const float* alpha, const float* residual, float* y,
-                               float* preact, int B, int H, int W, int C, int act, void* stream);
+int rn_conv2d_wino44_supported(int Cin, int Cout);
+size_t rn_conv2d_wino44_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_wino44_fwd(const float* x, const float* w_wino44, const float* bias, const float* alpha,
+                         const float* residual, float* y, float* preact, float* workspace,
+                         int B, int H, int W, int Cin, int Cout, int transposed, int act, void* stream);
+/* The three stages on their own; scheme = RN_WINO_F43 (6x6 tiles, 36 planes) | RN_WINO_F44 (7x7 tiles, 49 planes).
+ * T = B*ceil(H/4)*ceil(W/4) tiles; V [nxi][T][Cin], M [nxi][T][Cout]; every plane of V and M must stay below 2 GiB --
+ * the rn_conv2d_wino4x_fwd entries split the batch themselves, these do not.  pad_lo: rows / columns of zero padding
+ * before the first pixel (SAME conv: 1; stride-1 transposed conv: filter size - 2). */
+#define RN_WINO_F43 0
+#define RN_WINO_F44 1
+int rn_winograd_input_transform(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, void* stream);
+int rn_winograd_gemm(int scheme, const float* V, const float* w_packed, float* M, long long T, int Cin, int Cout, void* stream);
+int rn_winograd_output_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                 float* y, float* preact, int B, int H, int W, int C, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

@@ -15,6 +15,8 @@ RN_PHONG_NP_BLACK, RN_PHONG_NP_WHITE, RN_PHONG_TF_BLACK, RN_PHONG_TF_WHITE, RN_P
 RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2, RN_PACK_CONV_WINO, RN_PACK_CONVT_S1_WINO = 0, 1, 2, 3, 4
 RN_PACK_CONV_WINO4, RN_PACK_CONVT_S1_WINO4 = 5, 6
 RN_PACK_CONV_WINO43, RN_PACK_CONVT_S1_WINO43 = 7, 8
+RN_PACK_CONV_WINO44, RN_PACK_CONVT_S1_WINO44 = 9, 10
+RN_WINO_F43, RN_WINO_F44 = 0, 1
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -62,9 +64,12 @@ SIGNATURES = {
     "rn_conv2d_wino43_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino43_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
     "rn_conv2d_wino43_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 6 + [_c_vp]),
-    "rn_wino43_input_transform": (_c_int, [_c_vp, _c_vp] + [_c_int] * 4 + [_c_vp]),
-    "rn_wino43_gemm": (_c_int, [_c_vp] * 3 + [ctypes.c_longlong, _c_int, _c_int, _c_vp]),
-    "rn_wino43_output_transform": (_c_int, [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
+    "rn_conv2d_wino44_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino44_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
+    "rn_conv2d_wino44_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 7 + [_c_vp]),
+    "rn_winograd_input_transform": (_c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
+    "rn_winograd_gemm": (_c_int, [_c_int] + [_c_vp] * 3 + [ctypes.c_longlong, _c_int, _c_int, _c_vp]),
+    "rn_winograd_output_transform": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_wino_wgrad_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),

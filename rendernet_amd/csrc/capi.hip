@@ -369,40 +369,62 @@ extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B
     return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_wgrad");
 }
 
-extern "C" int rn_conv2d_wino43_supported(int Cin, int Cout) { return rn_wino43_supported(Cin, Cout) ? 1 : 0; }
+extern "C" int rn_conv2d_wino43_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F43, Cin, Cout) ? 1 : 0; }
+extern "C" int rn_conv2d_wino44_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F44, Cin, Cout) ? 1 : 0; }
 extern "C" size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
 {
-    if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(Cin, Cout)) return 0;
-    return rn_wino43_workspace_floats(B, H, W, Cin, Cout);
+    if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(RN_WINO_F43, Cin, Cout)) return 0;
+    return rn_wino43_workspace_floats(RN_WINO_F43, B, H, W, Cin, Cout);
+}
+extern "C" size_t rn_conv2d_wino44_workspace_floats(int B, int H, int W, int Cin, int Cout)
+{
+    if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(RN_WINO_F44, Cin, Cout)) return 0;
+    return rn_wino43_workspace_floats(RN_WINO_F44, B, H, W, Cin, Cout);
+}
+static int wino4x_fwd(int scheme, const char* who, const float* x, const float* w, const float* bias, const float* alpha,
+                      const float* residual, float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout,
+                      int pad_lo, int act, void* stream)
+{
+    if (!x || !w || !y || !workspace) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "%s: PReLU needs alpha", who);
+    return rn_launch_conv_wino43(scheme, x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, pad_lo, act,
+                                 (hipStream_t)stream);
 }
 extern "C" int rn_conv2d_wino43_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* residual,
                                     float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout, int act,
                                     void* stream)
 {
-    if (!x || !w || !y || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: null pointer");
-    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: bad sizes");
-    if ((act & 1) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_fwd: PReLU without alpha");
-    return rn_launch_conv_wino43(x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, act, (hipStream_t)stream);
+    return wino4x_fwd(RN_WINO_F43, "rn_conv2d_wino43_fwd", x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, 1, act, stream);
+}
+extern "C" int rn_conv2d_wino44_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* residual,
+                                    float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout,
+                                    int transposed, int act, void* stream)
+{
+    return wino4x_fwd(RN_WINO_F44, "rn_conv2d_wino44_fwd", x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout,
+                      transposed ? 2 : 1, act, stream);
 }
 
-extern "C" int rn_wino43_input_transform(const float* x, float* V, int B, int H, int W, int C, void* stream)
+extern "C" int rn_winograd_input_transform(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, void* stream)
 {
-    if (!x || !V) return rn_set_error(RN_E_INVALID, "rn_wino43_input_transform: null pointer");
-    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_wino43_input_transform: bad sizes");
-    return rn_launch_wino43_input(x, V, B, H, W, C, (hipStream_t)stream);
+    if (!x || !V) return rn_set_error(RN_E_INVALID, "rn_winograd_input_transform: null pointer");
+    if (rn_wino_scheme_nxi(scheme) == 0 || B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0 || pad_lo < 0 || pad_lo > 3)
+        return rn_set_error(RN_E_INVALID, "rn_winograd_input_transform: bad arguments");
+    return rn_launch_wino_input(scheme, x, V, B, H, W, C, pad_lo, (hipStream_t)stream);
 }
-extern "C" int rn_wino43_gemm(const float* V, const float* w, float* M, long long T, int Cin, int Cout, void* stream)
+extern "C" int rn_winograd_gemm(int scheme, const float* V, const float* w, float* M, long long T, int Cin, int Cout, void* stream)
 {
-    if (!V || !w || !M) return rn_set_error(RN_E_INVALID, "rn_wino43_gemm: null pointer");
-    return rn_launch_wino43_gemm(V, w, M, T, Cin, Cout, (hipStream_t)stream);
+    if (!V || !w || !M) return rn_set_error(RN_E_INVALID, "rn_winograd_gemm: null pointer");
+    return rn_launch_wino_gemm(scheme, V, w, M, T, Cin, Cout, (hipStream_t)stream);
 }
-extern "C" int rn_wino43_output_transform(const float* M, const float* bias, const float* alpha, const float* residual, float* y,
-                                          float* preact, int B, int H, int W, int C, int act, void* stream)
+extern "C" int rn_winograd_output_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                            float* y, float* preact, int B, int H, int W, int C, int act, void* stream)
 {
-    if (!M || !y) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: null pointer");
-    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: bad sizes");
-    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_wino43_output_transform: PReLU needs alpha");
-    return rn_launch_wino43_output(M, bias, alpha, residual, y, preact, B, H, W, C, act, (hipStream_t)stream);
+    if (!M || !y) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform: null pointer");
+    if (rn_wino_scheme_nxi(scheme) == 0 || B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0)
+        return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform: bad arguments");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform: PReLU needs alpha");
+    return rn_launch_wino_output(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, (hipStream_t)stream);
 }
 
 extern "C" int rn_conv2d_wino_wgrad_supported(int Cin, int Cout) { return rn_wino_wgrad_supported(Cin, Cout) ? 1 : 0; }

@@ -1,17 +1,22 @@
-// Stride-1 3x3 2-D convs through Winograd F(4x4,3x3) in three launches, exact-fp32 MFMA for the multiply stage --
-// the wide res_block_2d / *_skip convs (slim.conv2d [3,3]: tools/layer_util.py:91-105, RenderNet_Shader.py:71-84, :91-99),
-// forward and, with the transposed pack, the input gradient.
+// Stride-1 2-D convs through Winograd minimal filtering with 4x4 output tiles, in three launches, exact-fp32 MFMA for the
+// multiply stage:
+//   scheme F43 -- F(4x4,3x3), 6x6 input tiles, 36 products per 16 outputs instead of 144 (the fused F(2x2,3x3) kernel: 64):
+//                 the wide res_block_2d / *_skip convs (slim.conv2d [3,3]: tools/layer_util.py:91-105,
+//                 RenderNet_Shader.py:71-84, :91-99);
+//   scheme F44 -- F(4x4,4x4), 7x7 input tiles, 49 products per 16 outputs instead of 256 (the F(2x2,2x2)x4 kernel: 144):
+//                 e_conv5 / e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103);
+// forward and, with the transposed pack (taps flipped, channel roles swapped, pad_lo = R - 2), the input gradient.
 //
-//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        6x6 input patch d -> 4x4 outputs: 36 multiplies instead of 144 (F(2x2): 64)
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A          matrices: wino_mats.h (generated, scripts/gen_wino_mats.py)
 //
-//   1. wino43_input_kernel     x [B,H,W,Cin]            -> V [36 xi][T tiles][Cin]     (B^T d B per tile and channel; HBM bound)
-//   2. wino43_gemm_kernel      V, U [36][Cin][Cout]     -> M [36 xi][T][Cout]          (36 GEMMs T x Cin x Cout; MFMA bound)
-//   3. wino43_output_kernel    M, bias, alpha, residual -> y [B,H,W,Cout]              (A^T m A + the conv epilogue; HBM bound)
+//   1. wino_input_kernel     x [B,H,W,Cin]            -> V [nxi][T tiles][Cin]     (B^T d B per tile and channel; HBM bound)
+//   2. wino43_gemm_kernel    V, U [nxi][Cin][Cout]    -> M [nxi][T][Cout]          (nxi GEMMs T x Cin x Cout; MFMA bound)
+//   3. wino_output_kernel    M, bias, alpha, residual -> y [B,H,W,Cout]            (A^T m A + the conv epilogue; HBM bound)
 //
 // Unlike the fused F(2x2,3x3) kernel (conv_wino.hip), which transforms its patch again for every 32 output channels and
-// holds all xi of a tile in one wave, the 36 xi planes do not fit the accumulator file next to a useful channel block, so
-// the transforms run once, in their own launches, and the multiply stage is a plain batched GEMM with 256 x 256 blocks.
-// V and M live in a caller-provided workspace (36*T*(Cin+Cout) floats: 1.8 GB on the headline res2 shape, against 288 GB).
+// holds all xi of a tile in one wave, the 36 / 49 xi planes do not fit the accumulator file next to a useful channel block,
+// so the transforms run once, in their own launches, and the multiply stage is a plain batched GEMM with 256 x 256 blocks.
+// V and M live in a caller-provided workspace (nxi*T*(Cin+Cout) floats: 1.8 GB on the headline res2 shape, against 288 GB).
 //
 // GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), block 256 tiles x 256 channels, K step 32; both operands
 // go global -> LDS by DMA (raw_ptr_buffer_load_lds, 1 KiB per wave instruction), two stages of 64 KiB.  U is the MFMA A
@@ -19,6 +24,7 @@
 // bytes per tile row and store instruction).  Persistent grid (one workgroup per CU), items enumerated so that the 32
 // workgroups of an XCD share one xi and neighbouring blocks (its L2 then holds their U panel and V panels once).
 #include "rn_common.h"
+#include "wino_mats.h"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,123 +45,132 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8)
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 1. input transform.  thread = (tile, 4 channels).  B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],
-//                                                          [0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
-__device__ __forceinline__ void bt6(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4, const f32x4 d5,
-                                    f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3, f32x4& t4, f32x4& t5)
-{
-    const f32x4 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
-    t0 = 4.f * d0 - 5.f * d2 + d4;
-    t1 = a + b;
-    t2 = a - b;
-    t3 = c + e;
-    t4 = c - e;
-    t5 = 4.f * d1 - 5.f * d3 + d5;
-}
-
+// 1. input transform V = B^T d B.  thread = (tile, VW channels); S = WinoF43 | WinoF44 (wino_mats.h).  The matrix entries
+// are compile-time constants of fully unrolled loops: zero entries cost nothing, the rest become FMAs.
+template <class S, int VW>
 __global__ __launch_bounds__(256)
-void wino43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, int th, int tw,
-                         long long T, unsigned nblk8)
+void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, int th, int tw,
+                       long long T, unsigned nblk8, int pad_lo)
 {
+    typedef float vec __attribute__((ext_vector_type(VW)));
+    constexpr int A = S::TA;
     const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
     const long long idx = (long long)blk * 256 + threadIdx.x;
-    const int C4 = C >> 2;
-    const int c4 = (int)(idx % C4);
-    const long long t = idx / C4;
+    const int CV = C / VW;
+    const int cv = (int)(idx % CV);
+    const long long t = idx / CV;
     if (t >= T) return;
     const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
     const long long b = t / ((long long)tw * th);
-    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-    const float* xb = x + ((size_t)b * H * W) * C + c4 * 4;
-    f32x4 tt[6][6];                                            // (B^T d)[i][col]
+    const int y0 = 4 * ty - pad_lo, x0 = 4 * tx - pad_lo;
+    const float* xb = x + ((size_t)b * H * W) * C + cv * VW;
+    vec tt[A][A];                                              // (B^T d)[i][col]
 #pragma unroll
-    for (int col = 0; col < 6; ++col) {
-        f32x4 d[6];
+    for (int col = 0; col < A; ++col) {
+        vec d[A];
         const int ix = x0 + col;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
+        for (int r = 0; r < A; ++r) {
             const int iy = y0 + r;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            d[r] = ok ? ld4(xb + ((size_t)iy * W + ix) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
         }
-        bt6(d[0], d[1], d[2], d[3], d[4], d[5], tt[0][col], tt[1][col], tt[2][col], tt[3][col], tt[4][col], tt[5][col]);
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            vec acc = vec(0.f);
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const float c = S::BT(i, k);
+                if (c != 0.f) acc += c * d[k];
+            }
+            tt[i][col] = acc;
+        }
     }
-    float* vb = V + (size_t)t * C + c4 * 4;
+    float* vb = V + (size_t)t * C + cv * VW;
     const size_t plane = (size_t)T * C;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        f32x4 v[6];
-        bt6(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+    for (int i = 0; i < A; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) st4(vb + (size_t)(i * 6 + j) * plane, v[j]);
-    }
+        for (int j = 0; j < A; ++j) {
+            vec acc = vec(0.f);
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const float c = S::BT(j, k);
+                if (c != 0.f) acc += c * tt[i][k];
+            }
+            *reinterpret_cast<vec*>(vb + (size_t)(i * A + j) * plane) = acc;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 3. output transform + conv epilogue.  thread = (tile, 4 channels).  A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],
-//                                                                           [0,1,-1,8,-8,1]]
-__device__ __forceinline__ void at6(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
-                                    f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3)
-{
-    const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-    y0 = m0 + s12 + s34;
-    y1 = d12 + 2.f * d34;
-    y2 = s12 + 4.f * s34;
-    y3 = d12 + 8.f * d34 + m5;
-}
-
+// 3. output transform Y = A^T m A + the conv epilogue.  thread = (tile, VW channels).
+template <class S, int VW>
 __global__ __launch_bounds__(256)
-void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
-                          const float* __restrict__ res, float* __restrict__ y, float* __restrict__ z,
-                          int H, int W, int C, int th, int tw, long long T, int act, unsigned nblk8)
+void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
+                        const float* __restrict__ res, float* __restrict__ y, float* __restrict__ z,
+                        int H, int W, int C, int th, int tw, long long T, int act, unsigned nblk8)
 {
+    typedef float vec __attribute__((ext_vector_type(VW)));
+    constexpr int A = S::TA;
     const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
     const long long idx = (long long)blk * 256 + threadIdx.x;
-    const int C4 = C >> 2;
-    const int c4 = (int)(idx % C4);
-    const long long t = idx / C4;
+    const int CV = C / VW;
+    const int cv = (int)(idx % CV);
+    const long long t = idx / CV;
     if (t >= T) return;
     const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
     const long long b = t / ((long long)tw * th);
-    const float* mb = M + (size_t)t * C + c4 * 4;
+    const float* mb = M + (size_t)t * C + cv * VW;
     const size_t plane = (size_t)T * C;
-    f32x4 s[4][6];                                             // (A^T m)[p][j]
+    vec s[4][A];                                               // (A^T m)[p][j]
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        f32x4 m[6];
+    for (int j = 0; j < A; ++j) {
+        vec m[A];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) m[i] = ld4(mb + (size_t)(i * 6 + j) * plane);
-        at6(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+        for (int i = 0; i < A; ++i) m[i] = *reinterpret_cast<const vec*>(mb + (size_t)(i * A + j) * plane);
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            vec acc = vec(0.f);
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float c = S::AT(p_, i);
+                if (c != 0.f) acc += c * m[i];
+            }
+            s[p_][j] = acc;
+        }
     }
-    const f32x4 bv = bias ? ld4(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 av = (act & RN_ACT_PRELU) ? ld4(alpha + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const vec bv = bias ? *reinterpret_cast<const vec*>(bias + cv * VW) : vec(0.f);
+    const vec av = (act & RN_ACT_PRELU) ? *reinterpret_cast<const vec*>(alpha + cv * VW) : vec(0.f);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f32x4 o[4];
-        at6(s[p][0], s[p][1], s[p][2], s[p][3], s[p][4], s[p][5], o[0], o[1], o[2], o[3]);
-        const int oy = 4 * ty + p;
+    for (int p_ = 0; p_ < 4; ++p_) {
+        const int oy = 4 * ty + p_;
         if (oy >= H) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ox = 4 * tx + q;
             if (ox >= W) continue;
-            const size_t off = (((size_t)b * H + oy) * W + ox) * C + c4 * 4;
-            f32x4 v = o[q] + bv;
-            if (z) st4(z + off, v);
+            vec v = bv;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float c = S::AT(q, j);
+                if (c != 0.f) v += c * s[p_][j];
+            }
+            const size_t off = (((size_t)b * H + oy) * W + ox) * C + cv * VW;
+            if (z) *reinterpret_cast<vec*>(z + off) = v;
             if (act & RN_ACT_PRELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
+                for (int e = 0; e < VW; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
             }
             if (act & RN_ACT_ELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
+                for (int e = 0; e < VW; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
             }
-            if (res) v += ld4(res + off);
+            if (res) v += *reinterpret_cast<const vec*>(res + off);
             if (act & RN_ACT_SIGMOID) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+                for (int e = 0; e < VW; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
             }
-            st4(y + off, v);
+            *reinterpret_cast<vec*>(y + off) = v;
         }
     }
 }
@@ -319,21 +334,73 @@ void wino43_gemm_kernel(const W43GemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-bool rn_wino43_supported(int Cin, int Cout)
+// filter transform U = G g G^T, packed [nxi][Cout/256][Cin/4][256 channels][4 k]: the panel of one (xi, 256-channel block)
+// is contiguous, K step s of the GEMM is its s-th 32 KiB.  transposed = 0 reads a conv filter w_tf[R,R,Cin,Cout];
+// transposed = 1 a conv_transpose filter w_tf[R,R,Cout,Cin] with the taps flipped (a stride-1 transposed conv = the input
+// gradient of the conv with that filter).  Off the hot path (once per weight update): the R*R-term sums run in double.
+template <class S>
+__global__ void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
+{
+    constexpr int A = S::TA, R = S::R;
+    const size_t total = (size_t)S::NXI * Cin * Cout;
+    const int nkg = Cin / 4, nblocks = Cout / 256;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t rem = idx;
+        const int r = (int)(rem & 3); rem >>= 2;
+        const int slot = (int)(rem & 255); rem >>= 8;
+        const int kg = (int)(rem % nkg); rem /= nkg;
+        const int nb = (int)(rem % nblocks);
+        const int xi = (int)(rem / nblocks);
+        const int co = nb * 256 + slot, c = kg * 4 + r;
+        const int i = xi / A, j = xi - A * i;
+        double acc = 0.0;
+#pragma unroll
+        for (int p_ = 0; p_ < R; ++p_)
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const float g = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
+                                           : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
+                acc += S::G(i, p_) * S::G(j, q) * (double)g;
+            }
+        u[idx] = (float)acc;
+    }
+}
+
+int rn_wino_scheme_nxi(int scheme) { return scheme == RN_WINO_F43 ? WinoF43::NXI : scheme == RN_WINO_F44 ? WinoF44::NXI : 0; }
+int rn_wino_scheme_r(int scheme) { return scheme == RN_WINO_F43 ? 3 : scheme == RN_WINO_F44 ? 4 : 0; }
+
+bool rn_wino43_supported(int scheme, int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD43") != nullptr || getenv("RN_NO_WINOGRAD") != nullptr;
-    return !off && Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
+    static const bool off44 = getenv("RN_NO_WINOGRAD44") != nullptr;
+    if (off || (scheme == RN_WINO_F44 && off44) || rn_wino_scheme_nxi(scheme) == 0) return false;
+    return Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
+}
+
+int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Cout, int transposed, hipStream_t st)
+{
+    const size_t tot = (size_t)rn_wino_scheme_nxi(scheme) * Cin * Cout;
+    const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
+    if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    else hipLaunchKernelGGL(wino_pack_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    return rn_check_launch("wino_pack");
 }
 
 // the three stages on their own (the C ABI exposes them: a caller can keep V / M, or time the stages separately)
-int rn_launch_wino43_input(const float* x, float* V, int B, int H, int W, int C, hipStream_t st)
+int rn_launch_wino_input(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, hipStream_t st)
 {
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
-    const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
-    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-    hipLaunchKernelGGL(wino43_input_kernel, dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8);
-    return rn_check_launch("wino43_input");
+    if (scheme == RN_WINO_F43) {
+        const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL((wino_input_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8, pad_lo);
+    } else {
+        const unsigned long long n = ((unsigned long long)T * (C / 2) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL((wino_input_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8, pad_lo);
+    }
+    return rn_check_launch("wino_input");
 }
 
 template <int WM>
@@ -347,15 +414,15 @@ static int wino43_gemm_launch(W43GemmArgs a, int begin, int end, hipStream_t st)
     return rn_check_launch("wino43_gemm");
 }
 
-int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
+int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
 {
-    if (!rn_wino43_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: Cin=%d Cout=%d", Cin, Cout);
+    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
     if (T < 1 || (T + GBM) * (Cin > Cout ? Cin : Cout) * 4 >= 0xffffff00LL || T * (Cin > Cout ? Cin : Cout) * 4 >= 0x7fffff00LL)
-        return rn_set_error(RN_E_UNSUPPORTED, "wino43_gemm: a transform plane must stay below the 2 GiB buffer window");
+        return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm: a transform plane must stay below the 2 GiB buffer window");
     W43GemmArgs a;
     a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
     a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
-    const int nitems = 36 * a.mblocks * a.nblocks;
+    const int nitems = rn_wino_scheme_nxi(scheme) * a.mblocks * a.nblocks;
     a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO43_PROBE") ? atoi(getenv("RN_WINO43_PROBE")) : 0; a.probe = probe; }
     // one workgroup per CU takes items id, id + 256, ...: a last round of <= 128 items runs as <= 256 half items (128 rows)
@@ -370,29 +437,37 @@ int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T,
     return RN_OK;
 }
 
-int rn_launch_wino43_output(const float* M, const float* bias, const float* alpha, const float* residual, float* y, float* preact,
-                            int B, int H, int W, int C, int act, hipStream_t st)
+int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                          float* preact, int B, int H, int W, int C, int act, hipStream_t st)
 {
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
-    const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
-    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-    hipLaunchKernelGGL(wino43_output_kernel, dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                       H, W, C, th, tw, T, act, nblk8);
-    return rn_check_launch("wino43_output");
+    if (scheme == RN_WINO_F43) {
+        const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL((wino_output_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                           H, W, C, th, tw, T, act, nblk8);
+    } else {
+        const unsigned long long n = ((unsigned long long)T * (C / 2) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL((wino_output_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                           H, W, C, th, tw, T, act, nblk8);
+    }
+    return rn_check_launch("wino_output");
 }
 
-size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
+size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout)
 {
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    return 36 * T * ((size_t)Cin + Cout);
+    return (size_t)rn_wino_scheme_nxi(scheme) * T * ((size_t)Cin + Cout);
 }
 
-// x [B,H,W,Cin] -> y [B,H,W,Cout]; u from pack_wino43_kernel; ws >= rn_wino43_workspace_floats(...) floats
-int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
-                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st)
+// x [B,H,W,Cin] -> y [B,H,W,Cout]; u from wino_pack_kernel; ws >= rn_wino43_workspace_floats(...) floats; pad_lo = rows /
+// columns of zero padding before the first pixel (SAME conv: (R-1)/2 = 1; stride-1 transposed conv: R-1-1)
+int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
+                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st)
 {
-    if (!rn_wino43_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: Cin=%d Cout=%d", Cin, Cout);
+    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
@@ -403,17 +478,17 @@ int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, con
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = B - b0 < chunk ? B - b0 : chunk;
             const size_t xo = (size_t)b0 * H * W * Cin, yo = (size_t)b0 * H * W * Cout;
-            const int rc = rn_launch_conv_wino43(x + xo, u, bias, alpha, residual ? residual + yo : nullptr, y + yo,
-                                                 preact ? preact + yo : nullptr, ws, nb, H, W, Cin, Cout, act, st);
+            const int rc = rn_launch_conv_wino43(scheme, x + xo, u, bias, alpha, residual ? residual + yo : nullptr, y + yo,
+                                                 preact ? preact + yo : nullptr, ws, nb, H, W, Cin, Cout, pad_lo, act, st);
             if (rc != RN_OK) return rc;
         }
         return RN_OK;
     }
     float* V = ws;
-    float* M = ws + (size_t)36 * T * Cin;
-    int rc = rn_launch_wino43_input(x, V, B, H, W, Cin, st);
+    float* M = ws + (size_t)rn_wino_scheme_nxi(scheme) * T * Cin;
+    int rc = rn_launch_wino_input(scheme, x, V, B, H, W, Cin, pad_lo, st);
     if (rc != RN_OK) return rc;
-    rc = rn_launch_wino43_gemm(V, u, M, T, Cin, Cout, st);
+    rc = rn_launch_wino_gemm(scheme, V, u, M, T, Cin, Cout, st);
     if (rc != RN_OK) return rc;
-    return rn_launch_wino43_output(M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
+    return rn_launch_wino_output(scheme, M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
 }

@@ -130,43 +130,8 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w_tf, float* __restr
     }
 }
 
-// Winograd F(4x4,3x3) filter transform for csrc/conv_wino43.hip: U = G g G^T with G = [[1/4,0,0],[-1/6,-1/6,-1/6],
-// [-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], packed [36 xi][Cout/256][Cin/4][256 slots][4 k]: the panel of
-// one (xi, 256-channel block) is contiguous, K step s of the GEMM is its s-th 32 KiB; slot n holds channel n of the block.
-// RN_PACK_CONV_WINO43 reads w_tf[3,3,Cin,Cout]; RN_PACK_CONVT_S1_WINO43 w_tf[3,3,Cout,Cin] with the taps flipped.
-__global__ void pack_wino43_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
-{
-    const size_t total = (size_t)36 * Cin * Cout;
-    const int nkg = Cin / 4, nblocks = Cout / 256;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        size_t rem = idx;
-        const int r = (int)(rem & 3); rem >>= 2;
-        const int slot = (int)(rem & 255); rem >>= 8;
-        const int kg = (int)(rem % nkg); rem /= nkg;
-        const int nb = (int)(rem % nblocks);
-        const int xi = (int)(rem / nblocks);
-        const int co = nb * 256 + slot;
-        const int c = kg * 4 + r;
-        const int i = xi / 6, j = xi - 6 * i;
-        float g[3][3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                g[p][q] = transposed ? w_tf[((size_t)((2 - p) * 3 + (2 - q)) * Cout + co) * Cin + c]
-                                     : w_tf[((size_t)(p * 3 + q) * Cin + c) * Cout + co];
-        const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-        double acc = 0.0;                            // the pack is off the hot path: accumulate the 9 terms in double
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc += (double)G[i][p] * (double)G[j][q] * (double)g[p][q];
-        u[idx] = (float)acc;
-    }
-}
-
-static bool is_wino43_kind(int kind) { return kind == RN_PACK_CONV_WINO43 || kind == RN_PACK_CONVT_S1_WINO43; }
+static bool is_wino43_kind(int kind) { return kind == RN_PACK_CONV_WINO43 || kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44; }
+static int wino43_scheme(int kind) { return (kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44) ? RN_WINO_F44 : RN_WINO_F43; }
 static bool is_wino_kind(int kind) { return kind == RN_PACK_CONV_WINO || kind == RN_PACK_CONVT_S1_WINO; }
 static bool is_wino4_kind(int kind) { return kind == RN_PACK_CONV_WINO4 || kind == RN_PACK_CONVT_S1_WINO4; }
 
@@ -179,12 +144,13 @@ static int wino4_pack_check(int ndim, const int* kdims, int Cin, int Cout)
     return RN_OK;
 }
 
-static int wino43_pack_check(int ndim, const int* kdims, int Cin, int Cout)
+static int wino43_pack_check(int kind, int ndim, const int* kdims, int Cin, int Cout)
 {
-    if (!kdims || ndim != 2 || kdims[0] != 3 || kdims[1] != 3)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the F(4x4,3x3) Winograd packs need a 2-D 3x3 filter");
+    const int r = rn_wino_scheme_r(wino43_scheme(kind));
+    if (!kdims || ndim != 2 || kdims[0] != r || kdims[1] != r)
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: this Winograd pack needs a 2-D %dx%d filter", r, r);
     if (Cin < 32 || Cin % 32 != 0 || Cout < 256 || Cout % 256 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the F(4x4,3x3) Winograd packs need Cin %% 32 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the F(4x4,RxR) Winograd packs need Cin %% 32 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
     return RN_OK;
 }
 
@@ -221,7 +187,7 @@ extern "C" size_t rn_packed_weight_floats(int kind, int ndim, const int* kdims, 
 {
     if (is_wino_kind(kind)) return wino_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)16 * (ndim == 3 ? 3 : 1) * Cin * Cout : 0;
     if (is_wino4_kind(kind)) return wino4_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)36 * Cin * Cout : 0;
-    if (is_wino43_kind(kind)) return wino43_pack_check(ndim, kdims, Cin, Cout) == RN_OK ? (size_t)36 * Cin * Cout : 0;
+    if (is_wino43_kind(kind)) return wino43_pack_check(kind, ndim, kdims, Cin, Cout) == RN_OK ? (size_t)rn_wino_scheme_nxi(wino43_scheme(kind)) * Cin * Cout : 0;
     PackArgs a;
     if (pack_geometry(kind, ndim, kdims, Cin, Cout, a) != RN_OK) return 0;
     return (size_t)a.nphase * a.Kq * a.Npad * 4;
@@ -252,14 +218,11 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
         return rn_check_launch("pack_wino4");
     }
     if (is_wino43_kind(kind)) {
-        const int rcw = wino43_pack_check(ndim, kdims, Cin, Cout);
+        const int rcw = wino43_pack_check(kind, ndim, kdims, Cin, Cout);
         if (rcw != RN_OK) return rcw;
         if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
-        const size_t tot = (size_t)36 * Cin * Cout;
-        const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
-        hipLaunchKernelGGL(pack_wino43_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
-                           kind == RN_PACK_CONVT_S1_WINO43 ? 1 : 0);
-        return rn_check_launch("pack_wino43");
+        return rn_launch_wino_pack(wino43_scheme(kind), w_tf, w_packed, Cin, Cout,
+                                   (kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONVT_S1_WINO44) ? 1 : 0, (hipStream_t)stream);
     }
     PackArgs a;
     int rc = pack_geometry(kind, ndim, kdims, Cin, Cout, a);

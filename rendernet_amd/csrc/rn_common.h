@@ -46,14 +46,17 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
                         int mode, int pad, hipStream_t st);
 
-bool rn_wino43_supported(int Cin, int Cout);                                                              // conv_wino43.hip
-size_t rn_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
-int rn_launch_wino43_input(const float* x, float* V, int B, int H, int W, int C, hipStream_t st);
-int rn_launch_wino43_gemm(const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st);
-int rn_launch_wino43_output(const float* M, const float* bias, const float* alpha, const float* residual, float* y, float* preact,
-                            int B, int H, int W, int C, int act, hipStream_t st);
-int rn_launch_conv_wino43(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
-                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int act, hipStream_t st);
+bool rn_wino43_supported(int scheme, int Cin, int Cout);                                                  // conv_wino43.hip
+int rn_wino_scheme_nxi(int scheme);
+int rn_wino_scheme_r(int scheme);
+size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout);
+int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Cout, int transposed, hipStream_t st);
+int rn_launch_wino_input(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, hipStream_t st);
+int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st);
+int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                          float* preact, int B, int H, int W, int C, int act, hipStream_t st);
+int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
+                          float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st);
 bool rn_wino_wgrad_supported(int Cin, int Cout);                                                          // conv_wino_wgrad.hip
 int rn_launch_conv_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 

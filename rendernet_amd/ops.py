@@ -64,10 +64,13 @@ class PackedWeight:
         self._wino4_kind = w4kind if (w4kind is not None and ndim == 2 and self.kdims == [4, 4]
                                       and lib.rn_conv2d_wino4_supported(self.cin, self.cout)) else None
 
-        # Winograd F(4x4,3x3) (csrc/conv_wino43.hip): the wide 3x3 2-D layers (res2, res3 and their skips)
-        w43kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO43, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO43}.get(kind)
-        self._wino43_kind = w43kind if (w43kind is not None and ndim == 2 and self.kdims == [3, 3]
-                                        and lib.rn_conv2d_wino43_supported(self.cin, self.cout)) else None
+        # Winograd with 4x4 output tiles in three launches (csrc/conv_wino43.hip): F(4x4,3x3) for the wide 3x3 2-D layers
+        # (res2, res3 and their skips), F(4x4,4x4) for the wide 4x4 ones (e_conv5, e_conv6)
+        self._wino43_kind = None
+        if ndim == 2 and self.kdims == [3, 3] and lib.rn_conv2d_wino43_supported(self.cin, self.cout):
+            self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO43, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO43}.get(kind)
+        elif ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_wino44_supported(self.cin, self.cout):
+            self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO44, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO44}.get(kind)
 
     def _packed(self, which, kind):
         if self._dirty[which]:
@@ -100,7 +103,7 @@ class PackedWeight:
 
     @property
     def wino43(self):
-        """The Winograd F(4x4,3x3) pack, or None."""
+        """The Winograd F(4x4,3x3) (3x3 filters) / F(4x4,4x4) (4x4 filters) pack, or None."""
         return None if self._wino43_kind is None else self._packed("wino43", self._wino43_kind)
 
     @wino43.setter
@@ -340,27 +343,34 @@ def training(ctx):
 STAGE_HOOK = None      # bench.py: callable(stage, (T, Cin, Cout)) -> (start_event, end_event) | None, brackets the GEMM stage
 
 
-def _wino43_fwd(x, u, e, B, H, W, Cin, Cout, act):
-    """rn_conv2d_wino43_fwd with its workspace (V and M planes) from torch's caching allocator."""
+def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act):
+    """rn_conv2d_wino43_fwd / rn_conv2d_wino44_fwd with the workspace (V and M planes) from torch's caching allocator.
+    pw: the PackedWeight whose .wino43 form the launch reads (a stride-1 transposed-conv pack pads two pixels before)."""
     lib = L.lib()
-    n = lib.rn_conv2d_wino43_workspace_floats(B, H, W, Cin, Cout)
+    u = pw.wino43
+    f44 = pw.kdims == [4, 4]
+    transposed = 1 if pw.kind == L.RN_PACK_CONVT_S1 else 0
+    n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
     ev = STAGE_HOOK("gemm", (T, Cin, Cout)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
     if ev is None:
+        if f44:
+            return lib.rn_conv2d_wino44_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, transposed, act, L.stream_ptr())
         return lib.rn_conv2d_wino43_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
     # the same three launches through the stage entry points, the GEMM bracketed by the caller's events
     st = L.stream_ptr()
-    V, M = L.ptr(ws), ctypes.c_void_p(ws.data_ptr() + 4 * 36 * T * Cin)
-    rc = lib.rn_wino43_input_transform(L.ptr(x), V, B, H, W, Cin, st)
+    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F43, 36)
+    V, M = L.ptr(ws), ctypes.c_void_p(ws.data_ptr() + 4 * nxi * T * Cin)
+    rc = lib.rn_winograd_input_transform(scheme, L.ptr(x), V, B, H, W, Cin, 2 if (f44 and transposed) else 1, st)
     if rc != 0:
         return rc
     ev[0].record()
-    rc = lib.rn_wino43_gemm(V, L.ptr(u), M, T, Cin, Cout, st)
+    rc = lib.rn_winograd_gemm(scheme, V, L.ptr(u), M, T, Cin, Cout, st)
     ev[1].record()
     if rc != 0:
         return rc
-    return lib.rn_wino43_output_transform(M, *e, B, H, W, Cout, act, st)
+    return lib.rn_winograd_output_transform(scheme, M, *e, B, H, W, Cout, act, st)
 
 
 def _use_wino43(pw, H, W):
@@ -382,7 +392,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     if mode == "conv2d":
         B, H, W, Cin = x.shape
         if unit and _use_wino43(pw, H, W):
-            return _wino43_fwd(x, pw.wino43, e, B, H, W, Cin, pw.cout, act)
+            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act)
         if unit and pw.wino is not None:
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
         if unit and pw.wino4 is not None:
@@ -390,6 +400,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
         return lib.rn_conv2d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d_transpose":
         B, H, W, Cin = x.shape
+        if unit and _use_wino43(pw, H, W):
+            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act)
         if unit and pw.wino4 is not None:
             return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, 1, act, st)
         return lib.rn_conv2d_transpose_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
@@ -481,8 +493,8 @@ class _Conv(torch.autograd.Function):
                                             B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d":
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
-            elif mode == "conv2d" and unit and _use_wino43(dp, H, W):
-                rc = _wino43_fwd(dz, dp.wino43, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
+            elif mode in ("conv2d", "conv2d_transpose") and unit and _use_wino43(dp, H, W):
+                rc = _wino43_fwd(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
             elif mode == "conv2d" and unit and dp.wino is not None:
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
                 rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,

@@ -272,16 +272,22 @@ WINO43_CASES = [
 ]
 
 
-def _pack_wino43_numpy(w):
-    """NumPy statement of the RN_PACK_CONV_WINO43 layout (misc_kernels.hip, pack_wino43_kernel)."""
-    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                  [0, 0, 1]], np.float64)
+def _pack_wino43_numpy(w, scheme="F43", transposed=False):
+    """NumPy statement of the RN_PACK_CONV_WINO43 / _WINO44 layouts (conv_wino43.hip, wino_pack_kernel): U = G g G^T with
+    the generated matrices (scripts/gen_wino_mats.py), packed [nxi][Cout/256][Cin/4][256][4]."""
+    from scripts.gen_wino_mats import SCHEMES, winograd_mats
+    m, r, pts = SCHEMES[scheme]
+    _, G, _ = winograd_mats(m, r, pts)
+    G = np.array([[float(v) for v in row] for row in G], np.float64)
+    if transposed:                                      # conv_transpose filter [R,R,Cout,Cin], taps flipped
+        w = w[::-1, ::-1].transpose(0, 1, 3, 2)
     Cin, Cout = w.shape[2], w.shape[3]
-    U = np.einsum("ia,abck,jb->ijck", G, w.astype(np.float64), G).reshape(36, Cin, Cout)
-    out = np.empty((36, Cout // 256, Cin // 4, 256, 4), np.float32)
+    nxi = (m + r - 1) ** 2
+    U = np.einsum("ia,abck,jb->ijck", G, w.astype(np.float64), G).reshape(nxi, Cin, Cout)
+    out = np.empty((nxi, Cout // 256, Cin // 4, 256, 4), np.float32)
     for nb in range(Cout // 256):
-        blk = U[:, :, nb * 256:(nb + 1) * 256]                               # [36, Cin, 256 channels of the block]
-        out[:, nb] = blk.reshape(36, Cin // 4, 4, 256).transpose(0, 1, 3, 2)
+        blk = U[:, :, nb * 256:(nb + 1) * 256]                               # [nxi, Cin, 256 channels of the block]
+        out[:, nb] = blk.reshape(nxi, Cin // 4, 4, 256).transpose(0, 1, 3, 2)
     return out.reshape(-1)
 
 
@@ -336,6 +342,68 @@ def test_conv2d_winograd43(case):
             _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino43 dgrad vs oracle")
         else:
             assert dp.wino43 is None
+    finally:
+        ops.WINO43_MIN_PIXELS = old
+
+
+# Winograd F(4x4,4x4) for the wide 4x4 stride-1 layers (same three launches on 7x7 tiles): SAME conv (pad 1 before, 2
+# after) and stride-1 transposed conv (2 before, 1 after), ragged planes, 1..2 channel blocks, the e_conv5 / e_conv6 widths.
+WINO44_CASES = [
+    (1, 4, 4, 32, 256),
+    (2, 16, 16, 256, 256),
+    (1, 9, 11, 64, 512),
+    (3, 33, 5, 96, 256),
+    (1, 16, 16, 1024, 512),
+    (2, 32, 32, 512, 256),
+    (1, 1, 1, 32, 256),
+]
+
+
+@pytest.mark.parametrize("case", WINO44_CASES)
+def test_conv2d_winograd44(case):
+    """rn_conv2d_wino44_fwd (conv and stride-1 transposed conv) vs the oracle, vs the F(2x2,2x2)x4 kernel on the same filter,
+    the packed filters vs their NumPy statement, and the input gradients through the opposite packs."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 7)
+    x = _rand(rng, B, H, W, Cin)
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    old, ops.WINO43_MIN_PIXELS = ops.WINO43_MIN_PIXELS, 1
+    try:
+        # conv
+        w = _xavier(rng, (4, 4, Cin, Cout))
+        pw = ops.pack_conv(_dev(w))
+        assert pw.wino43 is not None
+        want_u = _pack_wino43_numpy(w, "F44")
+        assert np.abs(pw.wino43.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+        y0 = OL.conv2d(x, w, b, (1, 1))
+        res = _rand(rng, *y0.shape)
+        got = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+        _close(got, OL.prelu(y0, alpha) + torch.from_numpy(res), "wino44 conv+prelu+res")
+        p2 = ops.pack_conv(_dev(w))
+        p2.wino43 = None
+        if p2.wino4 is not None:
+            ref2 = ops.conv2d(_dev(x), p2, _dev(b), _dev(alpha), _dev(res))
+            assert float((got - ref2).abs().max()) <= 1e-4 * float(ref2.abs().max())
+        if Cin % 256 == 0:                               # the conv's input gradient = stride-1 transposed conv of dz
+            dp = pw.dgrad_pack(True)
+            assert dp.wino43 is not None
+            dz = _dev(_rand(rng, B, H, W, Cout))
+            dx = torch.empty((B, H, W, Cin), device="cuda")
+            ws = torch.empty(L.lib().rn_conv2d_wino44_workspace_floats(B, H, W, Cout, Cin), device="cuda")
+            L.check(L.lib().rn_conv2d_wino44_fwd(L.ptr(dz), L.ptr(dp.wino43), None, None, None, L.ptr(dx), None, L.ptr(ws),
+                                                 B, H, W, Cout, Cin, 1, 0, L.stream_ptr()), "rn_conv2d_wino44_fwd (dgrad)")
+            _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino44 dgrad vs oracle")
+        # stride-1 transposed conv (filter [4,4,Cout,Cin])
+        wt = _xavier(rng, (4, 4, Cout, Cin))
+        pt = ops.pack_conv_transpose(_dev(wt), 1)
+        assert pt.wino43 is not None
+        want_ut = _pack_wino43_numpy(wt, "F44", transposed=True)
+        assert np.abs(pt.wino43.cpu().numpy() - want_ut).max() <= 1e-6 * np.abs(want_ut).max()
+        yt = OL.conv2d_transpose(x, wt, b, (1, 1))
+        _close(ops.conv2d_transpose(_dev(x), pt, _dev(b), _dev(alpha), None, (1, 1)), OL.prelu(yt, alpha), "wino44 convT+prelu")
     finally:
         ops.WINO43_MIN_PIXELS = old
 
