@@ -349,6 +349,14 @@ int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B,
  * of 36, fp32; same contract (dw [3,3,Cin,Cout] ACCUMULATED with fp32 atomics).  Cin % 64 == 0 and Cout % 64 == 0
  * (rn_conv2d_wino_wgrad_supported). */
 int rn_conv2d_wino_wgrad_supported(int Cin, int Cout);
+/* ... and through F(4x4,3x3) on the three-launch path's GEMM structure (conv_wino43_wgrad.hip): V = B^T d B of the input,
+ * dM = A dY A^T of the output gradient, 36 exact-fp32 MFMA GEMMs dU[xi] = V[xi]^T . dM[xi] over the tiles (K-split into
+ * planes), dw += G^T (sum dU) G.  36 multiplies per 4x4 outputs and channel pair.  Cin % 256 == 0 and Cout % 256 == 0;
+ * `workspace`: rn_conv2d_wino43_wgrad_workspace_floats(B,H,W,Cin,Cout) floats of device memory. */
+int rn_conv2d_wino43_wgrad_supported(int Cin, int Cout);
+size_t rn_conv2d_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_wino43_wgrad(const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
 int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream);
 int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
                               int Cin, int Cout, int ksize, int stride, void* stream);

@@ -339,30 +339,58 @@ void wino43_gemm_kernel(const W43GemmArgs a)
 // transposed = 1 a conv_transpose filter w_tf[R,R,Cout,Cin] with the taps flipped (a stride-1 transposed conv = the input
 // gradient of the conv with that filter).  Off the hot path (once per weight update): the R*R-term sums run in double.
 template <class S>
-__global__ void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
+__global__ __launch_bounds__(256)
+void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int transposed)
 {
+    // thread = (4 input channels kg, output channel co): the R*R taps of its four filters are read once (coalesced along
+    // co for a conv filter; along c for a transposed one), every xi plane gets one 16-byte store (contiguous along co)
     constexpr int A = S::TA, R = S::R;
-    const size_t total = (size_t)S::NXI * Cin * Cout;
     const int nkg = Cin / 4, nblocks = Cout / 256;
+    const size_t total = (size_t)nkg * Cout;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        size_t rem = idx;
-        const int r = (int)(rem & 3); rem >>= 2;
-        const int slot = (int)(rem & 255); rem >>= 8;
-        const int kg = (int)(rem % nkg); rem /= nkg;
-        const int nb = (int)(rem % nblocks);
-        const int xi = (int)(rem / nblocks);
-        const int co = nb * 256 + slot, c = kg * 4 + r;
-        const int i = xi / A, j = xi - A * i;
-        double acc = 0.0;
+        const int slot = (int)(idx & 255);
+        const size_t rest = idx >> 8;
+        const int kg = (int)(rest % nkg), nb = (int)(rest / nkg);
+        const int co = nb * 256 + slot;
+        float g[R][R][4];
 #pragma unroll
         for (int p_ = 0; p_ < R; ++p_)
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const float g = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
-                                           : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
-                acc += S::G(i, p_) * S::G(j, q) * (double)g;
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = kg * 4 + r;
+                    g[p_][q][r] = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
+                                             : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
+                }
+        double gg[A][R][4];                                     // (G g)[i][q]
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p_ = 0; p_ < R; ++p_) acc += S::G(i, p_) * (double)g[p_][q][r];
+                    gg[i][q][r] = acc;
+                }
+        float* ub = u + (((size_t)nb * nkg + kg) * 256 + slot) * 4;
+        const size_t plane = (size_t)nblocks * nkg * 1024;      // floats per xi
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) acc += gg[i][q][r] * S::G(j, q);
+                    o[r] = (float)acc;
+                }
+                st4(ub + (size_t)(i * A + j) * plane, o);
             }
-        u[idx] = (float)acc;
     }
 }
 
@@ -379,7 +407,7 @@ bool rn_wino43_supported(int scheme, int Cin, int Cout)
 
 int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Cout, int transposed, hipStream_t st)
 {
-    const size_t tot = (size_t)rn_wino_scheme_nxi(scheme) * Cin * Cout;
+    const size_t tot = (size_t)(Cin / 4) * Cout;
     const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
     if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else hipLaunchKernelGGL(wino_pack_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);

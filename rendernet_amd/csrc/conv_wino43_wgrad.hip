@@ -1,0 +1,353 @@
+// Filter gradient of the wide stride-1 3x3 2-D convs through Winograd F(4x4,3x3), exact-fp32 MFMA for the multiply stage --
+// tf.nn.conv2d_backprop_filter of the res_block_2d / *_skip convs (tools/layer_util.py:101-104, RenderNet_Shader.py:71-84,
+// :91-99) in the training step.
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A      =>      dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G
+//
+//   1. wino_input_kernel (conv_wino43.hip)   x  [B,H,W,Cin]   -> V  [36][T tiles][Cin]        (the forward's input transform)
+//   2. wino_dout_kernel                      dz [B,H,W,Cout]  -> dM [36][T][Cout]             (A dY A^T per 4x4 output tile)
+//   3. wino43_wgrad_gemm_kernel              V, dM            -> dU [36*S][Cin][Cout]         (36 GEMMs Cin x T x Cout, S K-splits)
+//   4. wino_dfilter_kernel                   dU               -> dw [3,3,Cin,Cout] += G^T (sum_S dU) G
+//
+// 36 multiplies per 4x4 outputs and channel pair instead of 144 (conv_wino_wgrad.hip, F(2x2,3x3): 64).  The GEMM reduces
+// over the tiles (K = T): block 256 ci x 256 co, K step 32 tiles; both operand panels are [tile][channel] rows of 1 KiB that
+// go global -> LDS by DMA, one row per wave instruction, their sixteen 64-byte granules XOR-swizzled with (row & 3) so that
+// the four k-lanes of a fragment read (rows t, t+1, t+2, t+3) hit different banks.  dM is the MFMA A operand: a lane holds
+// four consecutive output channels of one input channel (16-byte stores into dU [ci][co]).  Same persistent, XCD-aware
+// enumeration and one-sub-group-ahead fragment pipeline as the forward GEMM (conv_wino43.hip).
+#include "rn_common.h"
+#include "wino_mats.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int WBK = 32;                            // tiles per K step
+constexpr int W_OPB = WBK * 256 * 4;               // one operand of a stage: 32 rows x 1 KiB
+constexpr int W_STAGE = 2 * W_OPB;                 // V rows | dM rows
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8) { return (blk & 7u) * (nblk8 >> 3) + (blk >> 3); }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. dM = A dY A^T: the 4x4 tile of the output gradient -> 6x6 (the adjoint of the output transform).  thread = (tile, 4 ch)
+template <class S>
+__global__ __launch_bounds__(256)
+void wino_dout_kernel(const float* __restrict__ dz, float* __restrict__ dM, int H, int W, int C, int th, int tw,
+                      long long T, unsigned nblk8)
+{
+    constexpr int A = S::TA;
+    const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
+    const long long idx = (long long)blk * 256 + threadIdx.x;
+    const int C4 = C >> 2;
+    const int c4 = (int)(idx % C4);
+    const long long t = idx / C4;
+    if (t >= T) return;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
+    const long long b = t / ((long long)tw * th);
+    const float* zb = dz + ((size_t)b * H * W) * C + c4 * 4;
+    f32x4 tt[A][4];                                            // (A dY)[i][q]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 d[4];
+        const int ox = 4 * tx + q;
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int oy = 4 * ty + p_;
+            d[p_] = (oy < H && ox < W) ? *reinterpret_cast<const f32x4*>(zb + ((size_t)oy * W + ox) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) {
+                const float c = S::AT(p_, i);
+                if (c != 0.f) acc += c * d[p_];
+            }
+            tt[i][q] = acc;
+        }
+    }
+    float* mb = dM + (size_t)t * C + c4 * 4;
+    const size_t plane = (size_t)T * C;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float c = S::AT(q, j);
+                if (c != 0.f) acc += c * tt[i][q];
+            }
+            *reinterpret_cast<f32x4*>(mb + (size_t)(i * A + j) * plane) = acc;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 4. dw[a][b][ci][co] += sum_{i,j} G[i][a] G[j][b] sum_split dU[xi = (i,j)][split][ci][co].  thread = (ci, 4 co)
+template <class S>
+__global__ __launch_bounds__(256)
+void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cin, int Cout, int nsplit)
+{
+    constexpr int A = S::TA, R = S::R;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)Cin * (Cout / 4);
+    if (idx >= n) return;
+    const size_t plane = (size_t)Cin * Cout;
+    const float* ub = dU + idx * 4;
+    f32x4 e[R][A];                                             // (G^T dU)[a][j]
+#pragma unroll
+    for (int a_ = 0; a_ < R; ++a_)
+#pragma unroll
+        for (int j = 0; j < A; ++j) e[a_][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < nsplit; ++s) u += *reinterpret_cast<const f32x4*>(ub + ((size_t)(i * A + j) * nsplit + s) * plane);
+#pragma unroll
+            for (int a_ = 0; a_ < R; ++a_) {
+                const float c = (float)S::G(i, a_);
+                if (c != 0.f) e[a_][j] += c * u;
+            }
+        }
+#pragma unroll
+    for (int a_ = 0; a_ < R; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < R; ++b_) {
+            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const float c = (float)S::G(j, b_);
+                if (c != 0.f) w += c * e[a_][j];
+            }
+            f32x4* d = reinterpret_cast<f32x4*>(dw + (size_t)(a_ * R + b_) * plane + idx * 4);
+            *d += w;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. dU[xi][split] (Cin x Cout) = V[xi]^T (Cin x T) . dM[xi] (T x Cout) over the split's tiles
+struct W43WgradArgs {
+    const float* V; const float* dM; float* dU;
+    long long T;
+    int Cin, Cout;
+    int ciblocks, coblocks;         // 256-channel blocks
+    int nsplit, steps_per_split;    // K splits; K steps (32 tiles) per split
+    int nitems;                     // 36 * nsplit * ciblocks * coblocks
+    unsigned v_bytes, m_bytes, u_bytes;   // one xi plane of V / dM; one (xi, split) plane of dU
+};
+
+__global__ __launch_bounds__(512, 1)
+void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V 32 x 256 | dM 32 x 256]
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;                          // 64-ci group (0..3), 128-co half (0..1)
+
+    // fragment reads: k-group g of a stage = rows 4g + kq; a row's 64-byte granule x sits at granule x ^ (row & 3) = x ^ kq
+    unsigned xk[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) xk[x] = (unsigned)(((x ^ kq) << 6) + kq * 1024 + l16 * 4);
+    const unsigned vbase = (unsigned)(wm * 4 * 64);                   // + xk[mt]
+    const unsigned mbase = (unsigned)(W_OPB + wn * 8 * 64);           // + (nt & 4) * 64 + xk[nt & 3]
+    // DMA: piece p = wave + 8i is row p of the stage (p & 3 == wave & 3); lane L moves the 16 bytes that land at position L
+    const unsigned dlane = (unsigned)((((lane >> 2) ^ (wave & 3)) << 6) + (lane & 3) * 16);
+
+    struct Item { const float* vplane; const float* mplane; float* uplane; int ci0, co0; long long t0; };
+    const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    auto decode = [&](int r, Item& it) -> bool {
+        const int L = r * (int)gridDim.x + perm;
+        if (L >= a.nitems) return false;
+        const int cob = L % a.coblocks;
+        int rest = L / a.coblocks;
+        const int cib = rest % a.ciblocks; rest /= a.ciblocks;
+        const int sp = rest % a.nsplit, xi = rest / a.nsplit;
+        it.ci0 = cib * 256; it.co0 = cob * 256;
+        it.t0 = (long long)sp * a.steps_per_split * WBK;
+        it.vplane = a.V + (size_t)xi * a.T * a.Cin;
+        it.mplane = a.dM + (size_t)xi * a.T * a.Cout;
+        it.uplane = a.dU + ((size_t)xi * a.nsplit + sp) * ((size_t)a.Cin * a.Cout);
+        return true;
+    };
+    auto issue = [&](const Item& it, int s, int stage) {
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(it.vplane), 0, a.v_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(it.mplane), 0, a.m_bytes, 0x00020000);
+        char* sb = smem + stage * W_STAGE;
+        const long long t = it.t0 + (long long)s * WBK;                // rows >= T fall outside the plane: zeros
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave + 8 * i;
+            // the row offset rides in the VGPR offset: the hardware's range check does not see the scalar offset
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + p * 1024), 16,
+                                                     dlane + (unsigned)(((t + p) * a.Cin + it.ci0) * 4), 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave + 8 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(mrsrc, (lds_void*)(sb + W_OPB + p * 1024), 16,
+                                                     dlane + (unsigned)(((t + p) * a.Cout + it.co0) * 4), 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];
+    auto load_frags = [&](const char* sb, int g, float (&v)[4], float (&m)[8]) {
+        const char* base = sb + g * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const float*>(base + vbase + xk[mt]);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) m[nt] = *reinterpret_cast<const float*>(base + mbase + (nt & 4) * 64 + xk[nt & 3]);
+    };
+    auto mfmas = [&](const float (&v)[4], const float (&m)[8]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[nt], v[mt], acc[mt][nt], 0, 0, 0);
+    };
+
+    Item cur, nxt;
+    if (!decode(0, cur)) return;
+    float v0[4], m0[8], v1[4], m1[8];
+    issue(cur, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(smem, 0, v0, m0);
+    int stage = 0;
+    for (int r = 0;; ++r) {
+        const bool have_next = decode(r + 1, nxt);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < a.steps_per_split; ++s) {
+            const char* sb = smem + stage * W_STAGE;
+            const char* sn = smem + (stage ^ 1) * W_STAGE;
+            const bool last = s + 1 == a.steps_per_split;
+            if (!last) issue(cur, s + 1, stage ^ 1);
+            else if (have_next) issue(nxt, 0, stage ^ 1);
+            // eight k-groups of 4 tiles; the fragments of group g+1 are read while the 32 MFMAs of group g run
+            load_frags(sb, 1, v1, m1); mfmas(v0, m0);
+            load_frags(sb, 2, v0, m0); mfmas(v1, m1);
+            load_frags(sb, 3, v1, m1); mfmas(v0, m0);
+            load_frags(sb, 4, v0, m0); mfmas(v1, m1);
+            load_frags(sb, 5, v1, m1); mfmas(v0, m0);
+            load_frags(sb, 6, v0, m0); mfmas(v1, m1);
+            load_frags(sb, 7, v1, m1); mfmas(v0, m0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!last || have_next) load_frags(sn, 0, v0, m0);
+            mfmas(v1, m1);
+            stage ^= 1;
+        }
+        // D = dM-tile (rows: co 4*kq + r of the tile) x V-tile (cols: ci l16): 16-byte stores into dU [ci][co]
+        {
+            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(cur.uplane, 0, a.u_bytes, 0x00020000);
+            const unsigned uo = (unsigned)(((size_t)(cur.ci0 + wm * 64 + l16) * a.Cout + cur.co0 + wn * 128 + kq * 4) * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), ursrc,
+                                                           uo + (unsigned)(mt * 16 * a.Cout * 4) + nt * 64, 0, 0);
+        }
+        if (!have_next) break;
+        cur = nxt;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+bool rn_wino43_wgrad_supported(int Cin, int Cout)
+{
+    static const bool off = getenv("RN_NO_WINOGRAD43_WGRAD") != nullptr || getenv("RN_NO_WINOGRAD43") != nullptr ||
+                            getenv("RN_NO_WINOGRAD") != nullptr;
+    return !off && Cin >= 256 && Cin % 256 == 0 && Cout >= 256 && Cout % 256 == 0;
+}
+
+static int wgrad_splits(long long T, int Cin, int Cout)
+{
+    static const int forced = getenv("RN_WINO43_WGRAD_SPLIT") ? atoi(getenv("RN_WINO43_WGRAD_SPLIT")) : 0;
+    const int ksteps = (int)((T + WBK - 1) / WBK);
+    if (forced > 0) return forced < ksteps ? forced : ksteps;
+    // cost in K steps: rounds of 256 items x (steps per item + ~3 steps of item overhead), plus what the extra dU planes cost
+    // to write and read back (one plane of 256x256 per item ~ 1 step of MFMA time)
+    const long long blocks = 36LL * (Cin / 256) * (Cout / 256);
+    int best = 1; double bc = 1e30;
+    for (int s = 1; s <= 16 && s <= ksteps; s *= 2) {
+        const int per = (ksteps + s - 1) / s;
+        const double cost = (double)((blocks * s + 255) / 256) * (per + 3.0) + 0.02 * s * blocks / 256.0 * 2.0;
+        if (cost < bc) { bc = cost; best = s; }
+    }
+    return best;
+}
+
+size_t rn_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout)
+{
+    const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    // V, dM, the K-split planes of dU (the split count of a batch chunk never exceeds the whole batch's)
+    return 36 * T * ((size_t)Cin + Cout) + (size_t)36 * wgrad_splits((long long)T, Cin, Cout) * Cin * Cout;
+}
+
+// x [B,H,W,Cin], dz [B,H,W,Cout] -> dw [3,3,Cin,Cout] += conv2d_backprop_filter (3x3, stride 1, SAME)
+int rn_launch_conv_wino43_wgrad(const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin, int Cout,
+                                hipStream_t st)
+{
+    if (!rn_wino43_wgrad_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: Cin=%d Cout=%d", Cin, Cout);
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    const int cmax = Cin > Cout ? Cin : Cout;
+    if ((long long)th * tw * cmax * 4 >= 0x7fffff00LL)
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: one image's transform plane exceeds the 2 GiB buffer window");
+    if ((T + WBK) * cmax * 4 >= 0x7fffff00LL) {                 // batch chunks (dw accumulates)
+        const int chunk = (int)(0x7fffff00LL / ((long long)th * tw * cmax * 4)) - 1;
+        if (chunk < 1) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: transform plane too large");
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = B - b0 < chunk ? B - b0 : chunk;
+            const int rc = rn_launch_conv_wino43_wgrad(x + (size_t)b0 * H * W * Cin, dz + (size_t)b0 * H * W * Cout, dw, ws,
+                                                       nb, H, W, Cin, Cout, st);
+            if (rc != RN_OK) return rc;
+        }
+        return RN_OK;
+    }
+    float* V = ws;
+    float* dM = V + (size_t)36 * T * Cin;
+    float* dU = dM + (size_t)36 * T * Cout;
+    int rc = rn_launch_wino_input(RN_WINO_F43, x, V, B, H, W, Cin, 1, st);
+    if (rc != RN_OK) return rc;
+    {
+        const unsigned long long n = ((unsigned long long)T * (Cout / 4) + 255) / 256;
+        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+        hipLaunchKernelGGL(wino_dout_kernel<WinoF43>, dim3(nblk8), dim3(256), 0, st, dz, dM, H, W, Cout, th, tw, T, nblk8);
+        rc = rn_check_launch("wino_dout");
+        if (rc != RN_OK) return rc;
+    }
+    W43WgradArgs a;
+    a.V = V; a.dM = dM; a.dU = dU; a.T = T; a.Cin = Cin; a.Cout = Cout;
+    a.ciblocks = Cin / 256; a.coblocks = Cout / 256;
+    a.nsplit = wgrad_splits(T, Cin, Cout);
+    const int ksteps = (int)((T + WBK - 1) / WBK);
+    a.steps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
+    a.nsplit = (ksteps + a.steps_per_split - 1) / a.steps_per_split;         // no empty split
+    a.nitems = 36 * a.nsplit * a.ciblocks * a.coblocks;
+    a.v_bytes = (unsigned)(T * Cin * 4); a.m_bytes = (unsigned)(T * Cout * 4); a.u_bytes = (unsigned)((size_t)Cin * Cout * 4);
+    {
+        const size_t lds = (size_t)2 * W_STAGE;
+        const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_wgrad_gemm_kernel), lds);
+        if (rc_ != RN_OK) return rc_;
+        const int n = a.nitems;
+        hipLaunchKernelGGL(wino43_wgrad_gemm_kernel, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+        rc = rn_check_launch("wino43_wgrad_gemm");
+        if (rc != RN_OK) return rc;
+    }
+    {
+        const size_t n = (size_t)Cin * (Cout / 4);
+        hipLaunchKernelGGL(wino_dfilter_kernel<WinoF43>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
+        return rn_check_launch("wino_dfilter");
+    }
+}
