@@ -34,7 +34,7 @@ for tag in sq fetch write tcc; do
     run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done
 for name in wino43 wino res1 res1w resample; do
-    flt=""; [ $name = wino43 ] && flt=wino43_; [ $name = wino ] && flt=conv_wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
+    flt=""; [ $name = wino43 ] && flt=wino; [ $name = wino ] && flt=conv_wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
     : > "$OUT/$name.txt"
     for tag in sq fetch write tcc; do
         f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)
