@@ -70,7 +70,9 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     """Trainer.save_checkpoint / load_checkpoint carry weights, Adam moments and global_step: two steps + restart + one
     step lands where three uninterrupted steps land (to within the run-to-run spread of the fp32-atomic filter
     gradients), while a weights-only restart -- Adam at t = 1 with zero moments, the learning-rate staircase back at step
-    0 -- does not."""
+    0 -- does not.  Distances are the 99th percentile of |delta parameter|, not the maximum: the net is piecewise linear, and
+    ONE pre-activation within 1e-6 of its PReLU kink taking the other branch in one of two runs (their filter gradients
+    differ in the last bits: atomics) moves ~0.05 % of the parameters by a full Adam step -- measured, not a defect."""
     from rendernet_amd.shader import tiny_spec, init_shader_weights
     from rendernet_amd.train import Trainer
     spec = tiny_spec(1)
@@ -88,7 +90,10 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
 
     ref = run(Trainer(spec, w, **kw), range(3))
     ref2 = run(Trainer(spec, w, **kw), range(3))
-    spread = float((ref2.param - ref.param).abs().max())            # wgrad accumulates with atomics: order varies
+    def dist(p, q):
+        return float(torch.quantile((p - q).abs()[::7].float(), 0.99))          # every 7th parameter: quantile() caps its input size
+
+    spread = dist(ref2.param, ref.param)                            # wgrad accumulates with atomics: order varies
     a = run(Trainer(spec, w, **kw), range(2))
     path = str(tmp_path / "ck.npz")
     a.save_checkpoint(path, epoch=7)
@@ -97,9 +102,9 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     assert b.load_checkpoint(dict(np.load(path))) == 7 and b.global_step == 2
     assert torch.equal(b.param, a.param) and torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
     run(b, [2])
-    resumed = float((b.param - ref.param).abs().max())
+    resumed = dist(b.param, ref.param)
     c = Trainer(spec, {k: v for k, v in a.state_dict().items()}, **kw)     # weights only: the round-1 checkpoint
     run(c, [2])
-    cold = float((c.param - ref.param).abs().max())
-    assert b.global_step == 3 and resumed <= max(20 * spread, 5e-5), (resumed, spread)     # lr = 1e-3: a step is ~1e-3
+    cold = dist(c.param, ref.param)
+    assert b.global_step == 3 and resumed <= max(20 * spread, 2e-5), (resumed, spread)     # lr = 1e-3: a step is ~1e-3
     assert cold > 10 * (resumed + 1e-7), (cold, resumed)
