@@ -11,6 +11,8 @@
 // are the constant act(bias).
 #include "rn_common.h"
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 struct TiledArgs2 {
     const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* y; float* z;
     int B, I0, I1, I2, O0, O1, O2, Cout, Npad;
@@ -223,6 +225,163 @@ static int launch_rows(const RnConvProblem& p, hipStream_t st)
     return rn_check_launch("conv_rows");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_stem_kernel: the 5^3 stride-2 stems with a handful of input channels (e_conv1: Cin 1 | 5 -> 8), depth rows staged in
+// LDS.  A workgroup = RPW/4 waves owns RPW output rows (o0, RPW*g ..) of one item: wave w rows 4w .. 4w+3, a lane one row
+// (lane >> 4) and FOUR consecutive output depths 4*(lane & 15) .. +3 (chunks of 64 depths when O2 > 64).  For every input plane
+// i0 = 2*o0 - P0 + k0 the 35 input rows i1 those output rows touch go global -> LDS with whole-row coalesced loads
+// ((I2 + 10) positions x CIN floats per row: SAME padding = zero positions on both sides; 3 of a row's 5 uses are by a
+// neighbouring output row), together with a per-row "any non-zero" flag; a lane then walks its five rows: the 11-position
+// window of its four outputs is read ONCE into registers (contiguous in the staged row), every filter value -- a wave-uniform
+// 16-byte LDS broadcast per 4 output channels -- feeds four outputs.  Rows that are all zero for every lane of the wave are
+// skipped (most of the resampled grid is empty).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN, int CO, int RPW>
+__global__ __launch_bounds__(RPW * 16)
+void conv_stem_kernel(const TiledArgs2 a)
+{
+    constexpr int K = 5, S = 2, NROW = (RPW - 1) * S + K;          // RPW output rows per workgroup (RPW/4 waves), staged rows
+    constexpr int NTH = RPW * 16, NW = RPW / 4;
+    constexpr int NPOS = 4, WIN = ((NPOS - 1) * S + K) * CIN;         // 4 outputs per lane: 11 positions x CIN floats
+    constexpr int KTOT = K * K * K * CIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                    // [KTOT][CO]
+    constexpr int LH = 4;                                          // zero positions before the row (LH*CIN floats: 16-byte multiple)
+    const int rowlen = (a.I2 + LH + 8) * CIN;                      // floats per staged row: LH zero positions before, 8 after (SAME
+                                                                   // padding + the window of a lane whose last outputs are past O2)
+    const int rowpitch = rowlen | 1;                               // odd pitch: the four rows of a wave start in different banks
+    float* rows = wl + KTOT * CO;                                  // [NROW][rowpitch]
+    int* flags = reinterpret_cast<int*>(rows + NROW * rowpitch);   // [NROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int blk = blockIdx.x;
+    const int ng = (a.O1 + RPW - 1) / RPW;
+    const int g = blk % ng; blk /= ng;
+    const int o0 = blk % a.O0; const int b = blk / a.O0;
+    const int rl = wave * 4 + (lane >> 4);                         // output row within the workgroup
+    const int o1 = g * RPW + rl;
+
+    for (int i = tid; i < KTOT * CO; i += NTH) {
+        const int k = i / CO, n = i % CO;
+        wl[i] = (n < a.Cout) ? a.w[((size_t)(k >> 2) * a.Npad + n) * 4 + (k & 3)] : 0.f;
+    }
+    for (int i = tid; i < NROW * rowpitch; i += NTH) rows[i] = 0.f;      // the halos stay zero for the whole kernel
+    const int nf4 = a.I2 * CIN / 4;                                // 16-byte pieces of an input row (the launcher checks divisibility)
+    const int nchunk = (a.O2 + 63) / 64;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int o2 = ch * 64 + (lane & 15) * NPOS;               // first of this lane's four output depths
+        float acc[NPOS][CO];
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q)
+#pragma unroll
+            for (int n = 0; n < CO; ++n) acc[q][n] = 0.f;
+        // window start in the staged row: position 2*o2 - P2, the row itself starts at position -2; clamped so that lanes
+        // past the end of the depth axis (their outputs are not stored) stay inside the row
+        const int w0 = min((o2 * S - a.P2 + LH) * CIN, rowlen - WIN);
+        for (int k0 = 0; k0 < K; ++k0) {
+            const int i0 = o0 * S - a.P0 + k0;
+            if ((unsigned)i0 >= (unsigned)a.I0) continue;          // uniform per workgroup
+            __syncthreads();                                       // the previous plane's rows are consumed
+            if (tid < NROW) flags[tid] = 0;
+            __syncthreads();
+            // stage the rows: row j <- input row i1 = 32*g - P1 + j.  Wave w takes rows w, w+4, ...; its (row, 16-byte piece)
+            // pairs are walked in batches of 8 per lane with all loads of a batch issued before the first LDS write
+            {
+                const int nrw = (NROW - wave + NW - 1) / NW;       // rows of this wave
+                const int total = nrw * nf4;
+                const float* xp = a.x + (((size_t)b * a.I0 + i0) * a.I1) * a.I2 * CIN;
+                for (int base = 0; base < total; base += 64 * 8) {
+                    f32x4s v[8]; int dst[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = base + u * 64 + lane;
+                        dst[u] = -1;
+                        v[u] = f32x4s{0.f, 0.f, 0.f, 0.f};
+                        if (idx < total) {
+                            const int r = idx / nf4, f = idx - r * nf4;
+                            const int j = wave + NW * r;
+                            const int i1 = g * RPW * S - a.P1 + j;
+                            dst[u] = j * rowpitch + LH * CIN + f * 4;
+                            if ((unsigned)i1 < (unsigned)a.I1)
+                                v[u] = *reinterpret_cast<const f32x4s*>(xp + (size_t)i1 * a.I2 * CIN + f * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (dst[u] >= 0) {
+                            float* d = rows + dst[u];
+                            d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+                            if (v[u][0] != 0.f || v[u][1] != 0.f || v[u][2] != 0.f || v[u][3] != 0.f)
+                                flags[(dst[u] - LH * CIN) / rowpitch] = 1;         // benign race: every writer stores 1
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k1 = 0; k1 < K; ++k1) {
+                const int j = rl * S + k1;
+                if (!__any(flags[j] != 0)) continue;               // all four rows of this wave are empty here
+                const float* xr = rows + j * rowpitch + w0;
+                float xw[WIN];
+#pragma unroll
+                for (int e = 0; e < WIN; ++e) xw[e] = xr[e];
+                const float* wr = wl + (size_t)((k0 * K + k1) * K) * CIN * CO;
+#pragma unroll
+                for (int e = 0; e < K * CIN; ++e) {
+                    float wv[CO];
+#pragma unroll
+                    for (int n = 0; n < CO; ++n) wv[n] = wr[e * CO + n];
+#pragma unroll
+                    for (int q = 0; q < NPOS; ++q) {
+                        const float xv = xw[q * S * CIN + e];
+#pragma unroll
+                        for (int n = 0; n < CO; ++n) acc[q][n] = fmaf(xv, wv[n], acc[q][n]);
+                    }
+                }
+            }
+        }
+        if (o1 < a.O1) {
+#pragma unroll
+            for (int q = 0; q < NPOS; ++q) {
+                if (o2 + q >= a.O2) break;
+                const size_t oo = ((((size_t)b * a.O0 + o0) * a.O1 + o1) * a.O2 + o2 + q) * a.Cout;
+#pragma unroll
+                for (int n = 0; n < CO; ++n) {
+                    if (n < a.Cout) {
+                        float v = acc[q][n] + (a.bias ? a.bias[n] : 0.f);
+                        if (a.z) a.z[oo + n] = v;
+                        if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+                        if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
+                        if (a.res) v += a.res[oo + n];
+                        if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                        a.y[oo + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int CO, int RPW>
+static int launch_stem(const RnConvProblem& p, hipStream_t st)
+{
+    TiledArgs2 a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
+    a.B = p.B; a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2];
+    a.Cout = p.Cout; a.Npad = p.Npad; a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = p.P[2];
+    a.nt0 = a.nt1 = a.nt2 = 0; a.act = p.act;
+    const long long nb = (long long)p.B * p.O[0] * ((p.O[1] + RPW - 1) / RPW);
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_stem: bad grid %lld", nb);
+    const int rowpitch = ((p.I[2] + 12) * CIN) | 1;
+    constexpr int NROW = (RPW - 1) * 2 + 5;
+    const size_t lds = ((size_t)125 * CIN * CO + (size_t)NROW * rowpitch) * sizeof(float) + NROW * sizeof(int);
+    if (lds > 150 * 1024 || (p.I[2] * CIN) % 4 != 0 || (reinterpret_cast<size_t>(p.x) & 15) != 0) return RN_E_UNSUPPORTED;
+    auto kern = conv_stem_kernel<CIN, CO, RPW>;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(RPW * 16), lds, st, a);
+    return rn_check_launch("conv_stem");
+}
+
 static bool is_plain(const RnConvProblem& p)
 {
     // contiguous channels-last output covering the whole grid (no sub-pixel phase addressing)
@@ -236,9 +395,22 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     static const bool off = getenv("RN_NO_TILED") != nullptr;
     if (off || !is_plain(p)) return RN_E_UNSUPPORTED;
     const bool k555s2 = p.K[0] == 5 && p.K[1] == 5 && p.K[2] == 5 && p.S[0] == 2 && p.S[1] == 2 && p.S[2] == 2;
+    static const bool stem1 = getenv("RN_STEM_KERNEL_CIN1") != nullptr;
+    if (stem1 && k555s2 && p.Cout == 8 && p.Cin == 1 && p.P[2] <= 2 && (p.O[2] - 1) * 2 - p.P[2] + 4 <= p.I[2] + 1) {
+        static const int rpw = getenv("RN_STEM_RPW") ? atoi(getenv("RN_STEM_RPW")) : 16;
+        const int rc = rpw == 16 ? launch_stem<1, 8, 16>(p, st) : rpw == 4 ? launch_stem<1, 8, 4>(p, st) : launch_stem<1, 8, 8>(p, st);
+        if (rc != RN_E_UNSUPPORTED) return rc;
+    }
     if (k555s2 && p.Cout == 8 && p.Cin == 1) return launch_tiled<5, 5, 5, 2, 2, 2, 1, 8, 4, 4, 16>(p, st);
-    // the texture net's 5-channel stem (LDS-tiled with one output per thread: 5.5 ms at tile 4x4x16; the generic direct
-    // kernel: 5.0 ms): four outputs per thread along the depth axis, row windows in registers
+    // the texture net's 5-channel stem: generic direct kernel 5.0 ms, LDS-tiled with one output per thread 5.5 ms (tile 4x4x16),
+    // conv_rows_kernel (four outputs per thread, row windows read straight from global memory) 4.9 ms, conv_stem_kernel
+    // (rows staged in LDS by whole-row loads, below) 2.45 ms on dense input -- less on the mostly empty resampled grid
+    static const bool no_stem = getenv("RN_NO_STEM_KERNEL") != nullptr;
+    if (!no_stem && k555s2 && p.Cout == 8 && p.Cin == 5 && p.P[2] <= 2 && (p.O[2] - 1) * 2 - p.P[2] + 4 <= p.I[2] + 1) {             // row-staged stem (conv_stem_kernel)
+        static const int rpw = getenv("RN_STEM_RPW") ? atoi(getenv("RN_STEM_RPW")) : 16;
+        const int rc = rpw == 16 ? launch_stem<5, 8, 16>(p, st) : rpw == 4 ? launch_stem<5, 8, 4>(p, st) : launch_stem<5, 8, 8>(p, st);
+        if (rc != RN_E_UNSUPPORTED) return rc;
+    }
     if (k555s2 && p.Cout == 8 && p.Cin == 5) return launch_rows<5, 5, 5, 2, 2, 2, 5, 8, 4>(p, st);
     // (e_conv2 -- 3^3 stride (1,1,2), 8 -> 16 -- measured 0.98 ms tiled vs 0.79 ms with the generic direct kernel: its 8-float
     //  channel runs already coalesce, and 16 accumulators x 216 taps leave the tile's 4 waves per CU latency-bound.  Not routed here.)

@@ -192,7 +192,8 @@ template <int VP> struct W43Item { const float* vplane; const float* upanel; flo
 // WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128, 128 accumulators);
 // 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64): the launcher runs the last, partial round of a launch as half
 // items of this shape so that it costs half a round.
-template <int WM>
+// TAG only names the kernel per layer class in profiler tables (0: Cin >= 1024 -- the res2 trunk; 1: narrower 3x3 layers; 2: F(4x4,4x4))
+template <int WM, int TAG>
 __global__ __launch_bounds__(512, 1)
 void wino43_gemm_kernel(const W43GemmArgs a)
 {
@@ -431,15 +432,23 @@ int rn_launch_wino_input(int scheme, const float* x, float* V, int B, int H, int
     return rn_check_launch("wino_input");
 }
 
-template <int WM>
-static int wino43_gemm_launch(W43GemmArgs a, int begin, int end, hipStream_t st)
+template <int WM, int TAG>
+static int wino43_gemm_launch_t(W43GemmArgs a, int begin, int end, hipStream_t st)
 {
     a.item_begin = begin; a.item_end = end;
     const size_t lds = (size_t)2 * (WM * 64 * GBK * 4 + G_UB);
-    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_gemm_kernel<WM>), lds); if (rc_ != RN_OK) return rc_; }
+    auto kern = wino43_gemm_kernel<WM, TAG>;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
     const int n = (end - begin) * (WM == 2 ? 2 : 1);
-    hipLaunchKernelGGL(wino43_gemm_kernel<WM>, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
     return rn_check_launch("wino43_gemm");
+}
+
+template <int WM>
+static int wino43_gemm_launch(int tag, const W43GemmArgs& a, int begin, int end, hipStream_t st)
+{
+    return tag == 0 ? wino43_gemm_launch_t<WM, 0>(a, begin, end, st) : tag == 1 ? wino43_gemm_launch_t<WM, 1>(a, begin, end, st)
+                                                                                  : wino43_gemm_launch_t<WM, 2>(a, begin, end, st);
 }
 
 int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
@@ -455,13 +464,14 @@ int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, lo
     { static const int probe = getenv("RN_WINO43_PROBE") ? atoi(getenv("RN_WINO43_PROBE")) : 0; a.probe = probe; }
     // one workgroup per CU takes items id, id + 256, ...: a last round of <= 128 items runs as <= 256 half items (128 rows)
     static const bool notail = getenv("RN_WINO43_NOTAIL") != nullptr;
+    const int tag = scheme == RN_WINO_F44 ? 2 : Cin >= 1024 ? 0 : 1;
     const int rem = nitems % 256;
     const int tail = (!notail && rem != 0 && rem <= 128) ? rem : 0;
     if (nitems - tail > 0) {
-        const int rc = wino43_gemm_launch<4>(a, 0, nitems - tail, st);
+        const int rc = wino43_gemm_launch<4>(tag, a, 0, nitems - tail, st);
         if (rc != RN_OK) return rc;
     }
-    if (tail > 0) return wino43_gemm_launch<2>(a, nitems - tail, nitems, st);
+    if (tail > 0) return wino43_gemm_launch<2>(tag, a, nitems - tail, nitems, st);
     return RN_OK;
 }
 

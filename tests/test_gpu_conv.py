@@ -50,6 +50,25 @@ CONV3D_CASES = [
 ]
 
 
+@pytest.mark.parametrize("cin", [1, 5])
+def test_conv3d_stem_sparse_and_deep(cin, monkeypatch):
+    """The row-staged 5^3 stride-2 stem kernel (conv_stem_kernel): a mostly empty volume (all-zero rows are skipped), more than
+    64 output depths (two lane chunks), odd sizes (SAME pads 2 before on odd extents, 1 on even ones), ragged row groups."""
+    from rendernet_amd import ops
+    monkeypatch.setenv("RN_STEM_KERNEL_CIN1", "1")                   # read once per process: harmless if already latched
+    rng = np.random.default_rng(77 + cin)
+    for (B, H, W, D) in [(2, 10, 14, 136), (1, 9, 7, 21)]:
+        x = _rand(rng, B, H, W, D, cin)
+        x[:, :, : W // 2] = 0.0                                       # half of the rows empty
+        x[:, H // 2:, :, D // 3:] = 0.0
+        w = _xavier(rng, (5, 5, 5, cin, 8))
+        b = _rand(rng, 8) * 0.1
+        alpha = rng.uniform(0, 0.25, 8).astype(np.float32)
+        pw = ops.pack_conv(_dev(w))
+        _close(ops.conv3d(_dev(x), pw, _dev(b), _dev(alpha), stride=(2, 2, 2)), OL.prelu(OL.conv3d(x, w, b, (2, 2, 2)), alpha),
+               "stem %s" % ((B, H, W, D, cin),))
+
+
 @pytest.mark.parametrize("case", CONV3D_CASES)
 def test_conv3d(case):
     from rendernet_amd import ops
