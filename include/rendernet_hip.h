@@ -357,6 +357,11 @@ int rn_conv2d_wino43_wgrad_supported(int Cin, int Cout);
 size_t rn_conv2d_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
 int rn_conv2d_wino43_wgrad(const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W, int Cin, int Cout,
                            void* stream);
+/* the same for the 4x4, stride-1 convs (e_conv5, e_conv6) through F(4x4,4x4): dw [4,4,Cin,Cout], 49 GEMMs */
+int rn_conv2d_wino44_wgrad_supported(int Cin, int Cout);
+size_t rn_conv2d_wino44_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_wino44_wgrad(const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
 int rn_conv2d_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, void* stream);
 int rn_conv3d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int D,
                               int Cin, int Cout, int ksize, int stride, void* stream);

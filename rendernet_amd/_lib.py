@@ -73,6 +73,9 @@ SIGNATURES = {
     "rn_conv2d_wino43_wgrad_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino43_wgrad_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
     "rn_conv2d_wino43_wgrad": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
+    "rn_conv2d_wino44_wgrad_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino44_wgrad_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
+    "rn_conv2d_wino44_wgrad": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_wino_wgrad_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_c_vp]),
     "rn_conv2d_transpose_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),

@@ -427,18 +427,31 @@ extern "C" int rn_winograd_output_transform(int scheme, const float* M, const fl
     return rn_launch_wino_output(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, (hipStream_t)stream);
 }
 
-extern "C" int rn_conv2d_wino43_wgrad_supported(int Cin, int Cout) { return rn_wino43_wgrad_supported(Cin, Cout) ? 1 : 0; }
-extern "C" size_t rn_conv2d_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout)
+extern "C" int rn_conv2d_wino43_wgrad_supported(int Cin, int Cout) { return rn_wino43_wgrad_supported(RN_WINO_F43, Cin, Cout) ? 1 : 0; }
+extern "C" int rn_conv2d_wino44_wgrad_supported(int Cin, int Cout) { return rn_wino43_wgrad_supported(RN_WINO_F44, Cin, Cout) ? 1 : 0; }
+static size_t wino4x_wgrad_ws(int scheme, int B, int H, int W, int Cin, int Cout)
 {
-    if (B < 1 || H < 1 || W < 1 || !rn_wino43_wgrad_supported(Cin, Cout)) return 0;
-    return rn_wino43_wgrad_workspace_floats(B, H, W, Cin, Cout);
+    if (B < 1 || H < 1 || W < 1 || !rn_wino43_wgrad_supported(scheme, Cin, Cout)) return 0;
+    return rn_wino43_wgrad_workspace_floats(scheme, B, H, W, Cin, Cout);
+}
+extern "C" size_t rn_conv2d_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout) { return wino4x_wgrad_ws(RN_WINO_F43, B, H, W, Cin, Cout); }
+extern "C" size_t rn_conv2d_wino44_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout) { return wino4x_wgrad_ws(RN_WINO_F44, B, H, W, Cin, Cout); }
+static int wino4x_wgrad(int scheme, const char* who, const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W,
+                        int Cin, int Cout, void* stream)
+{
+    if (!x || !dz || !dw || !workspace) return rn_set_error(RN_E_INVALID, "%s: null pointer", who);
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "%s: bad sizes", who);
+    return rn_launch_conv_wino43_wgrad(scheme, x, dz, dw, workspace, B, H, W, Cin, Cout, (hipStream_t)stream);
 }
 extern "C" int rn_conv2d_wino43_wgrad(const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W, int Cin,
                                       int Cout, void* stream)
 {
-    if (!x || !dz || !dw || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_wgrad: null pointer");
-    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_wino43_wgrad: bad sizes");
-    return rn_launch_conv_wino43_wgrad(x, dz, dw, workspace, B, H, W, Cin, Cout, (hipStream_t)stream);
+    return wino4x_wgrad(RN_WINO_F43, "rn_conv2d_wino43_wgrad", x, dz, dw, workspace, B, H, W, Cin, Cout, stream);
+}
+extern "C" int rn_conv2d_wino44_wgrad(const float* x, const float* dz, float* dw, float* workspace, int B, int H, int W, int Cin,
+                                      int Cout, void* stream)
+{
+    return wino4x_wgrad(RN_WINO_F44, "rn_conv2d_wino44_wgrad", x, dz, dw, workspace, B, H, W, Cin, Cout, stream);
 }
 
 extern "C" int rn_conv2d_wino_wgrad_supported(int Cin, int Cout) { return rn_wino_wgrad_supported(Cin, Cout) ? 1 : 0; }

@@ -263,21 +263,22 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-bool rn_wino43_wgrad_supported(int Cin, int Cout)
+bool rn_wino43_wgrad_supported(int scheme, int Cin, int Cout)
 {
+    if (rn_wino_scheme_nxi(scheme) == 0 || !rn_wino43_supported(scheme, 256, 256)) return false;
     static const bool off = getenv("RN_NO_WINOGRAD43_WGRAD") != nullptr || getenv("RN_NO_WINOGRAD43") != nullptr ||
                             getenv("RN_NO_WINOGRAD") != nullptr;
     return !off && Cin >= 256 && Cin % 256 == 0 && Cout >= 256 && Cout % 256 == 0;
 }
 
-static int wgrad_splits(long long T, int Cin, int Cout)
+static int wgrad_splits(int nxi, long long T, int Cin, int Cout)
 {
     static const int forced = getenv("RN_WINO43_WGRAD_SPLIT") ? atoi(getenv("RN_WINO43_WGRAD_SPLIT")) : 0;
     const int ksteps = (int)((T + WBK - 1) / WBK);
     if (forced > 0) return forced < ksteps ? forced : ksteps;
     // cost in K steps: rounds of 256 items x (steps per item + ~3 steps of item overhead), plus what the extra dU planes cost
     // to write and read back (one plane of 256x256 per item ~ 1 step of MFMA time)
-    const long long blocks = 36LL * (Cin / 256) * (Cout / 256);
+    const long long blocks = (long long)nxi * (Cin / 256) * (Cout / 256);
     int best = 1; double bc = 1e30;
     for (int s = 1; s <= 16 && s <= ksteps; s *= 2) {
         const int per = (ksteps + s - 1) / s;
@@ -287,18 +288,21 @@ static int wgrad_splits(long long T, int Cin, int Cout)
     return best;
 }
 
-size_t rn_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout)
+size_t rn_wino43_wgrad_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout)
 {
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    const size_t nxi = (size_t)rn_wino_scheme_nxi(scheme);
     // V, dM, the K-split planes of dU (the split count of a batch chunk never exceeds the whole batch's)
-    return 36 * T * ((size_t)Cin + Cout) + (size_t)36 * wgrad_splits((long long)T, Cin, Cout) * Cin * Cout;
+    return nxi * T * ((size_t)Cin + Cout) + nxi * wgrad_splits((int)nxi, (long long)T, Cin, Cout) * Cin * Cout;
 }
 
-// x [B,H,W,Cin], dz [B,H,W,Cout] -> dw [3,3,Cin,Cout] += conv2d_backprop_filter (3x3, stride 1, SAME)
-int rn_launch_conv_wino43_wgrad(const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin, int Cout,
-                                hipStream_t st)
+// x [B,H,W,Cin], dz [B,H,W,Cout] -> dw [R,R,Cin,Cout] += conv2d_backprop_filter (RxR, stride 1, SAME); scheme F43: R = 3, F44: R = 4
+int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin,
+                                int Cout, hipStream_t st)
 {
-    if (!rn_wino43_wgrad_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: Cin=%d Cout=%d", Cin, Cout);
+    if (!rn_wino43_wgrad_supported(scheme, Cin, Cout))
+        return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    const int nxi = rn_wino_scheme_nxi(scheme);
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
@@ -309,32 +313,33 @@ int rn_launch_conv_wino43_wgrad(const float* x, const float* dz, float* dw, floa
         if (chunk < 1) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: transform plane too large");
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = B - b0 < chunk ? B - b0 : chunk;
-            const int rc = rn_launch_conv_wino43_wgrad(x + (size_t)b0 * H * W * Cin, dz + (size_t)b0 * H * W * Cout, dw, ws,
+            const int rc = rn_launch_conv_wino43_wgrad(scheme, x + (size_t)b0 * H * W * Cin, dz + (size_t)b0 * H * W * Cout, dw, ws,
                                                        nb, H, W, Cin, Cout, st);
             if (rc != RN_OK) return rc;
         }
         return RN_OK;
     }
     float* V = ws;
-    float* dM = V + (size_t)36 * T * Cin;
-    float* dU = dM + (size_t)36 * T * Cout;
-    int rc = rn_launch_wino_input(RN_WINO_F43, x, V, B, H, W, Cin, 1, st);
+    float* dM = V + (size_t)nxi * T * Cin;
+    float* dU = dM + (size_t)nxi * T * Cout;
+    int rc = rn_launch_wino_input(scheme, x, V, B, H, W, Cin, 1, st);
     if (rc != RN_OK) return rc;
     {
         const unsigned long long n = ((unsigned long long)T * (Cout / 4) + 255) / 256;
         const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-        hipLaunchKernelGGL(wino_dout_kernel<WinoF43>, dim3(nblk8), dim3(256), 0, st, dz, dM, H, W, Cout, th, tw, T, nblk8);
+        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_dout_kernel<WinoF43>, dim3(nblk8), dim3(256), 0, st, dz, dM, H, W, Cout, th, tw, T, nblk8);
+        else hipLaunchKernelGGL(wino_dout_kernel<WinoF44>, dim3(nblk8), dim3(256), 0, st, dz, dM, H, W, Cout, th, tw, T, nblk8);
         rc = rn_check_launch("wino_dout");
         if (rc != RN_OK) return rc;
     }
     W43WgradArgs a;
     a.V = V; a.dM = dM; a.dU = dU; a.T = T; a.Cin = Cin; a.Cout = Cout;
     a.ciblocks = Cin / 256; a.coblocks = Cout / 256;
-    a.nsplit = wgrad_splits(T, Cin, Cout);
+    a.nsplit = wgrad_splits(nxi, T, Cin, Cout);
     const int ksteps = (int)((T + WBK - 1) / WBK);
     a.steps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
     a.nsplit = (ksteps + a.steps_per_split - 1) / a.steps_per_split;         // no empty split
-    a.nitems = 36 * a.nsplit * a.ciblocks * a.coblocks;
+    a.nitems = nxi * a.nsplit * a.ciblocks * a.coblocks;
     a.v_bytes = (unsigned)(T * Cin * 4); a.m_bytes = (unsigned)(T * Cout * 4); a.u_bytes = (unsigned)((size_t)Cin * Cout * 4);
     {
         const size_t lds = (size_t)2 * W_STAGE;
@@ -347,7 +352,8 @@ int rn_launch_conv_wino43_wgrad(const float* x, const float* dz, float* dw, floa
     }
     {
         const size_t n = (size_t)Cin * (Cout / 4);
-        hipLaunchKernelGGL(wino_dfilter_kernel<WinoF43>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
+        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_dfilter_kernel<WinoF43>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
+        else hipLaunchKernelGGL(wino_dfilter_kernel<WinoF44>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
         return rn_check_launch("wino_dfilter");
     }
 }

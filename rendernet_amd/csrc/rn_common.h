@@ -57,9 +57,9 @@ int rn_launch_wino_output(int scheme, const float* M, const float* bias, const f
                           float* preact, int B, int H, int W, int C, int act, hipStream_t st);
 int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
                           float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st);
-bool rn_wino43_wgrad_supported(int Cin, int Cout);                                                        // conv_wino43_wgrad.hip
-size_t rn_wino43_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
-int rn_launch_conv_wino43_wgrad(const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t st);
+bool rn_wino43_wgrad_supported(int scheme, int Cin, int Cout);                                            // conv_wino43_wgrad.hip
+size_t rn_wino43_wgrad_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout);
+int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 bool rn_wino_wgrad_supported(int Cin, int Cout);                                                          // conv_wino_wgrad.hip
 int rn_launch_conv_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 

@@ -477,6 +477,10 @@ class _Conv(torch.autograd.Function):
               and lib.rn_conv2d_wino43_wgrad_supported(Cin, pw.cout)):
             ws = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, pw.cout), dtype=torch.float32, device=x.device)
             rc = lib.rn_conv2d_wino43_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(ws), B, H, W, Cin, pw.cout, st)
+        elif (mode == "conv2d" and unit and tuple(ksize) == (4, 4) and _use_wino43(pw, H, W)
+              and lib.rn_conv2d_wino44_wgrad_supported(Cin, pw.cout)):
+            ws = torch.empty(lib.rn_conv2d_wino44_wgrad_workspace_floats(B, H, W, Cin, pw.cout), dtype=torch.float32, device=x.device)
+            rc = lib.rn_conv2d_wino44_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(ws), B, H, W, Cin, pw.cout, st)
         elif (mode == "conv2d" and unit and tuple(ksize) == (3, 3) and pw._wino_kind is not None
               and lib.rn_conv2d_wino_wgrad_supported(Cin, pw.cout)):
             rc = lib.rn_conv2d_wino_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, Cin, pw.cout, st)

@@ -193,6 +193,29 @@ def test_wino43_wgrad(B, H, W, Cin, Cout):
     _close(dw, (2 * ref).cpu(), "F(4x4,3x3) vs direct wgrad")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 256, 256), (2, 16, 16, 512, 256), (3, 13, 27, 256, 256), (1, 1, 1, 256, 256)])
+def test_wino44_wgrad(B, H, W, Cin, Cout):
+    """The F(4x4,4x4) filter gradient of the 4x4 stride-1 convs (e_conv5 / e_conv6) vs autograd over the oracle conv and vs
+    the direct wgrad kernel."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    assert lib.rn_conv2d_wino44_wgrad_supported(Cin, Cout) == 1
+    rng = np.random.default_rng(B * 1000 + H * 31 + W + Cin + 1)
+    x, dz = _rand(rng, B, H, W, Cin), _rand(rng, B, H, W, Cout)
+    wt = torch.zeros(4, 4, Cin, Cout, requires_grad=True)
+    OL.conv2d(torch.from_numpy(x), wt).backward(torch.from_numpy(dz))
+    xd, dzd = _dev(x), _dev(dz)
+    dw = torch.zeros(4, 4, Cin, Cout, device="cuda")
+    ws = torch.empty(lib.rn_conv2d_wino44_wgrad_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+    for _ in range(2):
+        L.check(lib.rn_conv2d_wino44_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(dw), L.ptr(ws), B, H, W, Cin, Cout, L.stream_ptr()), "wino44 wgrad")
+    _close(dw, 2 * wt.grad, "accumulated F(4x4,4x4) dw")
+    ref = torch.zeros_like(dw)
+    L.check(lib.rn_conv2d_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(ref), B, H, W, Cin, Cout,
+                                L.ivec([4, 4]), L.ivec([1, 1]), L.stream_ptr()), "rn_conv2d_wgrad")
+    _close(dw, (2 * ref).cpu(), "F(4x4,4x4) vs direct wgrad")
+
+
 @pytest.mark.parametrize("C,act", [(1024, 1), (32, 1), (8, 1), (1, 2), (3, 2), (16, 0), (2048, 1), (20, 1)])
 def test_epilogue_bwd(C, act):
     from rendernet_amd import _lib as L
