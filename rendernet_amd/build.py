@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "librendernet_hip.so"
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv_wino43.hip", "conv_wino43_wgrad.hip", "conv3d_drun.hip", "conv_direct.hip", "conv_tiled.hip", "resample.hip", "resample_tiled.hip", "misc_kernels.hip",
            "conv_wgrad.hip", "train_kernels.hip", "resample_bwd.hip"]
-HEADERS = ["rn_common.h", os.path.join("..", "..", "include", "rendernet_hip.h")]
+HEADERS = ["rn_common.h", "wino_mats.h", os.path.join("..", "..", "include", "rendernet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # the resampler must round after every multiply and add (bit parity with the reference's op-by-op
