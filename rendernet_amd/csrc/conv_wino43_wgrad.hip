@@ -6,8 +6,8 @@
 //
 //   1. wino_input_kernel (conv_wino43.hip)   x  [B,H,W,Cin]   -> V  [36][T tiles][Cin]        (the forward's input transform)
 //   2. wino_dout_kernel                      dz [B,H,W,Cout]  -> dM [36][T][Cout]             (A dY A^T per 4x4 output tile)
-//   3. wino43_wgrad_gemm_kernel              V, dM            -> dU [36*S][Cin][Cout]         (36 GEMMs Cin x T x Cout, S K-splits)
-//   4. wino_dfilter_kernel                   dU               -> dw [3,3,Cin,Cout] += G^T (sum_S dU) G
+//   3. wino43_wgrad_gemm_kernel              V, dM            -> dU [36][Cin][Cout]           (36 GEMMs Cin x T x Cout)
+//   4. wino_dfilter_kernel                   dU               -> dw [3,3,Cin,Cout] += G^T dU G
 //
 // 36 multiplies per 4x4 outputs and channel pair instead of 144 (conv_wino_wgrad.hip, F(2x2,3x3): 64).  The GEMM reduces
 // over the tiles (K = T): block 256 ci x 256 co, K step 32 tiles; both operand panels are [tile][channel] rows of 1 KiB that
@@ -84,10 +84,10 @@ void wino_dout_kernel(const float* __restrict__ dz, float* __restrict__ dM, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 4. dw[a][b][ci][co] += sum_{i,j} G[i][a] G[j][b] sum_split dU[xi = (i,j)][split][ci][co].  thread = (ci, 4 co)
+// 4. dw[a][b][ci][co] += sum_{i,j} G[i][a] G[j][b] dU[xi = (i,j)][ci][co].  thread = (ci, 4 co)
 template <class S>
 __global__ __launch_bounds__(256)
-void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cin, int Cout, int nsplit)
+void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cin, int Cout)
 {
     constexpr int A = S::TA, R = S::R;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -104,8 +104,7 @@ void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, i
     for (int i = 0; i < A; ++i)
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < nsplit; ++s) u += *reinterpret_cast<const f32x4*>(ub + ((size_t)(i * A + j) * nsplit + s) * plane);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(ub + (size_t)(i * A + j) * plane);
 #pragma unroll
             for (int a_ = 0; a_ < R; ++a_) {
                 const float c = (float)S::G(i, a_);
@@ -128,17 +127,38 @@ void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 3. dU[xi][split] (Cin x Cout) = V[xi]^T (Cin x T) . dM[xi] (T x Cout) over the split's tiles
+// 3. dU[xi] (Cin x Cout) = V[xi]^T (Cin x T) . dM[xi] (T x Cout).  One item = one 256 x 256 block of one xi over ALL tiles
+// -- except the blocks of a last, partial round of the persistent grid, which are cut into `ksplit` parts along the tiles so
+// that they fill the machine: those write partial blocks (SPLIT = true) that wino43_wgrad_reduce_kernel sums into dU.
+// (fp32 atomics into a zeroed block instead: 0.31 ms for the 64 tail blocks of the res2 shape against 0.15 ms this way.)
 struct W43WgradArgs {
-    const float* V; const float* dM; float* dU;
+    const float* V; const float* dM; float* dU; float* parts;   // parts: [tail block][part][256][256] partial blocks of the split items
     long long T;
     int Cin, Cout;
     int ciblocks, coblocks;         // 256-channel blocks
-    int nsplit, steps_per_split;    // K splits; K steps (32 tiles) per split
-    int nitems;                     // 36 * nsplit * ciblocks * coblocks
-    unsigned v_bytes, m_bytes, u_bytes;   // one xi plane of V / dM; one (xi, split) plane of dU
+    int item_begin, item_end;       // this launch's blocks L = (xi*ciblocks + cib)*coblocks + cob
+    int ksplit, steps_per_split, ksteps;   // parts per block; K steps (32 tiles) per part; K steps in all
+    unsigned v_bytes, m_bytes, u_bytes;   // one xi plane of V / dM / dU
 };
 
+// dU block = sum of its parts, for the blocks [item_begin, item_end)
+__global__ __launch_bounds__(256)
+void wino43_wgrad_reduce_kernel(const W43WgradArgs a)
+{
+    const int tb = blockIdx.x / 64;                                   // 64 workgroups per block: 4 rows of 256 floats each
+    const int L = a.item_begin + tb;
+    const int cob = L % a.coblocks;
+    const int rest = L / a.coblocks;
+    const int cib = rest % a.ciblocks, xi = rest / a.ciblocks;
+    const int row = (blockIdx.x % 64) * 4 + (threadIdx.x >> 6), c4 = threadIdx.x & 63;
+    const float* p = a.parts + ((size_t)tb * a.ksplit) * 65536 + row * 256 + c4 * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < a.ksplit; ++k) acc += *reinterpret_cast<const f32x4*>(p + (size_t)k * 65536);
+    float* d = a.dU + (size_t)xi * a.Cin * a.Cout + (size_t)(cib * 256 + row) * a.Cout + cob * 256 + c4 * 4;
+    *reinterpret_cast<f32x4*>(d) = acc;
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 1)
 void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
 {
@@ -159,20 +179,23 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
     // DMA: piece p = wave + 8i is row p of the stage (p & 3 == wave & 3); lane L moves the 16 bytes that land at position L
     const unsigned dlane = (unsigned)((((lane >> 2) ^ (wave & 3)) << 6) + (lane & 3) * 16);
 
-    struct Item { const float* vplane; const float* mplane; float* uplane; int ci0, co0; long long t0; };
+    struct Item { const float* vplane; const float* mplane; float* ubase; int upitch, ci0, co0, nsteps; long long t0; };
     const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int nids = (a.item_end - a.item_begin) * a.ksplit;
     auto decode = [&](int r, Item& it) -> bool {
-        const int L = r * (int)gridDim.x + perm;
-        if (L >= a.nitems) return false;
+        const int id = r * (int)gridDim.x + perm;
+        if (id >= nids) return false;
+        const int L = a.item_begin + id / a.ksplit, sp = id % a.ksplit;
         const int cob = L % a.coblocks;
-        int rest = L / a.coblocks;
-        const int cib = rest % a.ciblocks; rest /= a.ciblocks;
-        const int sp = rest % a.nsplit, xi = rest / a.nsplit;
+        const int rest = L / a.coblocks;
+        const int cib = rest % a.ciblocks, xi = rest / a.ciblocks;
         it.ci0 = cib * 256; it.co0 = cob * 256;
         it.t0 = (long long)sp * a.steps_per_split * WBK;
+        it.nsteps = min(a.steps_per_split, a.ksteps - sp * a.steps_per_split);
         it.vplane = a.V + (size_t)xi * a.T * a.Cin;
         it.mplane = a.dM + (size_t)xi * a.T * a.Cout;
-        it.uplane = a.dU + ((size_t)xi * a.nsplit + sp) * ((size_t)a.Cin * a.Cout);
+        if (SPLIT) { it.ubase = a.parts + (size_t)id * 65536; it.upitch = 256; }
+        else { it.ubase = a.dU + (size_t)xi * ((size_t)a.Cin * a.Cout) + (size_t)it.ci0 * a.Cout + it.co0; it.upitch = a.Cout; }
         return true;
     };
     auto issue = [&](const Item& it, int s, int stage) {
@@ -225,10 +248,10 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < a.steps_per_split; ++s) {
+        for (int s = 0; s < cur.nsteps; ++s) {
             const char* sb = smem + stage * W_STAGE;
             const char* sn = smem + (stage ^ 1) * W_STAGE;
-            const bool last = s + 1 == a.steps_per_split;
+            const bool last = s + 1 == cur.nsteps;
             if (!last) issue(cur, s + 1, stage ^ 1);
             else if (have_next) issue(nxt, 0, stage ^ 1);
             // eight k-groups of 4 tiles; the fragments of group g+1 are read while the 32 MFMAs of group g run
@@ -245,16 +268,14 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
             mfmas(v1, m1);
             stage ^= 1;
         }
-        // D = dM-tile (rows: co 4*kq + r of the tile) x V-tile (cols: ci l16): 16-byte stores into dU [ci][co]
+        // D = dM-tile (rows: co 4*kq + r of the tile) x V-tile (cols: ci l16): 16-byte stores, 64 contiguous bytes per ci row
         {
-            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(cur.uplane, 0, a.u_bytes, 0x00020000);
-            const unsigned uo = (unsigned)(((size_t)(cur.ci0 + wm * 64 + l16) * a.Cout + cur.co0 + wn * 128 + kq * 4) * 4);
+            float* ub = cur.ubase + (size_t)(wm * 64 + l16) * cur.upitch + wn * 128 + kq * 4;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), ursrc,
-                                                           uo + (unsigned)(mt * 16 * a.Cout * 4) + nt * 64, 0, 0);
+                    *reinterpret_cast<f32x4*>(ub + (size_t)mt * 16 * cur.upitch + nt * 16) = acc[mt][nt];
         }
         if (!have_next) break;
         cur = nxt;
@@ -271,29 +292,11 @@ bool rn_wino43_wgrad_supported(int scheme, int Cin, int Cout)
     return !off && Cin >= 256 && Cin % 256 == 0 && Cout >= 256 && Cout % 256 == 0;
 }
 
-static int wgrad_splits(int nxi, long long T, int Cin, int Cout)
-{
-    static const int forced = getenv("RN_WINO43_WGRAD_SPLIT") ? atoi(getenv("RN_WINO43_WGRAD_SPLIT")) : 0;
-    const int ksteps = (int)((T + WBK - 1) / WBK);
-    if (forced > 0) return forced < ksteps ? forced : ksteps;
-    // cost in K steps: rounds of 256 items x (steps per item + ~3 steps of item overhead), plus what the extra dU planes cost
-    // to write and read back (one plane of 256x256 per item ~ 1 step of MFMA time)
-    const long long blocks = (long long)nxi * (Cin / 256) * (Cout / 256);
-    int best = 1; double bc = 1e30;
-    for (int s = 1; s <= 16 && s <= ksteps; s *= 2) {
-        const int per = (ksteps + s - 1) / s;
-        const double cost = (double)((blocks * s + 255) / 256) * (per + 3.0) + 0.02 * s * blocks / 256.0 * 2.0;
-        if (cost < bc) { bc = cost; best = s; }
-    }
-    return best;
-}
-
 size_t rn_wino43_wgrad_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout)
 {
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
     const size_t nxi = (size_t)rn_wino_scheme_nxi(scheme);
-    // V, dM, the K-split planes of dU (the split count of a batch chunk never exceeds the whole batch's)
-    return nxi * T * ((size_t)Cin + Cout) + nxi * wgrad_splits((int)nxi, (long long)T, Cin, Cout) * Cin * Cout;
+    return nxi * T * ((size_t)Cin + Cout) + nxi * Cin * Cout + (size_t)256 * 65536;   // V, dM, dU, <= 256 partial blocks
 }
 
 // x [B,H,W,Cin], dz [B,H,W,Cout] -> dw [R,R,Cin,Cout] += conv2d_backprop_filter (RxR, stride 1, SAME); scheme F43: R = 3, F44: R = 4
@@ -333,27 +336,49 @@ int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, flo
         if (rc != RN_OK) return rc;
     }
     W43WgradArgs a;
-    a.V = V; a.dM = dM; a.dU = dU; a.T = T; a.Cin = Cin; a.Cout = Cout;
+    a.V = V; a.dM = dM; a.dU = dU; a.parts = dU + (size_t)nxi * Cin * Cout; a.T = T; a.Cin = Cin; a.Cout = Cout;
     a.ciblocks = Cin / 256; a.coblocks = Cout / 256;
-    a.nsplit = wgrad_splits(nxi, T, Cin, Cout);
-    const int ksteps = (int)((T + WBK - 1) / WBK);
-    a.steps_per_split = (ksteps + a.nsplit - 1) / a.nsplit;
-    a.nsplit = (ksteps + a.steps_per_split - 1) / a.steps_per_split;         // no empty split
-    a.nitems = nxi * a.nsplit * a.ciblocks * a.coblocks;
+    a.ksteps = (int)((T + WBK - 1) / WBK);
     a.v_bytes = (unsigned)(T * Cin * 4); a.m_bytes = (unsigned)(T * Cout * 4); a.u_bytes = (unsigned)((size_t)Cin * Cout * 4);
-    {
-        const size_t lds = (size_t)2 * W_STAGE;
-        const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_wgrad_gemm_kernel), lds);
+    const int blocks = nxi * a.ciblocks * a.coblocks;
+    // one workgroup per CU takes blocks id, id + 256, ...; the blocks of a last, partial round (or all of them when there are
+    // fewer than 256) are cut along the tiles into as many parts as fill the machine once
+    static const int forced = getenv("RN_WINO43_WGRAD_SPLIT") ? atoi(getenv("RN_WINO43_WGRAD_SPLIT")) : 0;
+    const int rem = blocks % 256;
+    int split = 1;
+    if (rem > 0) {
+        while (rem * split * 2 <= 256 && split * 2 <= a.ksteps) split *= 2;
+        if (forced > 0 && rem * forced <= 256) split = forced < a.ksteps ? forced : a.ksteps;
+    }
+    const int tail = split > 1 ? rem : 0;
+    const size_t lds = (size_t)2 * W_STAGE;
+    if (blocks - tail > 0) {
+        a.item_begin = 0; a.item_end = blocks - tail; a.ksplit = 1; a.steps_per_split = a.ksteps;
+        const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_wgrad_gemm_kernel<false>), lds);
         if (rc_ != RN_OK) return rc_;
-        const int n = a.nitems;
-        hipLaunchKernelGGL(wino43_wgrad_gemm_kernel, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+        const int n = blocks - tail;
+        hipLaunchKernelGGL(wino43_wgrad_gemm_kernel<false>, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
         rc = rn_check_launch("wino43_wgrad_gemm");
+        if (rc != RN_OK) return rc;
+    }
+    if (tail > 0) {
+        a.item_begin = blocks - tail; a.item_end = blocks; a.ksplit = split;
+        a.steps_per_split = (a.ksteps + split - 1) / split;
+        a.ksplit = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;          // no empty part
+        const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(wino43_wgrad_gemm_kernel<true>), lds);
+        if (rc_ != RN_OK) return rc_;
+        const int n = tail * a.ksplit;
+        hipLaunchKernelGGL(wino43_wgrad_gemm_kernel<true>, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+        rc = rn_check_launch("wino43_wgrad_gemm (split)");
+        if (rc != RN_OK) return rc;
+        hipLaunchKernelGGL(wino43_wgrad_reduce_kernel, dim3((unsigned)(tail * 64)), dim3(256), 0, st, a);
+        rc = rn_check_launch("wino43_wgrad_reduce");
         if (rc != RN_OK) return rc;
     }
     {
         const size_t n = (size_t)Cin * (Cout / 4);
-        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_dfilter_kernel<WinoF43>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
-        else hipLaunchKernelGGL(wino_dfilter_kernel<WinoF44>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout, a.nsplit);
+        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_dfilter_kernel<WinoF43>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout);
+        else hipLaunchKernelGGL(wino_dfilter_kernel<WinoF44>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dU, dw, Cin, Cout);
         return rn_check_launch("wino_dfilter");
     }
 }
