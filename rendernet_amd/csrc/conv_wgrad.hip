@@ -255,6 +255,138 @@ void conv_wgrad_small_kernel(const WgradArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow variant with LDS staging (taps*Cg <= 1024 threads, Ca <= 8): e_conv1 (A = x with 1 | 5 channels, 125 taps, G = dz
+// with 8) and the wgrad of e_conv11 (A = dz with 1 | 3 channels, G = x with 16 | 32).  The kernel above walks its positions
+// with one gathered A sample and Cg broadcast G loads from global memory per position and thread -- a chain of memory
+// latencies (e_conv11 at crop 64: 2.0 ms for 107 MB of operands).  Here a workgroup stages a T0 x T1 x T2 tile of output
+// positions -- its G rows and the A box they touch -- in LDS with coalesced row loads (zeros where SAME padding applies),
+// thread (tap, cg) then runs over the tile's positions out of LDS with Ca accumulators, and the workgroup keeps
+// accumulating over its tiles (id, id + grid, ...) before it adds its taps*Ca*Cg sums to dw with one atomic each.
+// ------------------------------------------------------------------------------------------------
+struct WgradTileArgs {
+    WgradArgs w;
+    int T0, T1, T2;              // output positions per tile
+    int R0, R1, R2;              // A box of a tile: (T-1)*S + K
+    int nt0, nt1, nt2, ntiles;   // tiles per item and dimension; tiles in all (B * nt0 * nt1 * nt2)
+};
+
+template <int CA>
+__global__ __launch_bounds__(1024)
+void conv_wgrad_tile_kernel(const WgradTileArgs ta)
+{
+    const WgradArgs& a = ta.w;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int abox = ta.R0 * ta.R1 * ta.R2 * CA;
+    float* As = reinterpret_cast<float*>(smem);           // [R0][R1][R2][CA]
+    float* Gs = As + ((abox + 3) & ~3);                   // [T0*T1*T2][Cg]
+    const int taps = a.K0 * a.K1 * a.K2;
+    const int t = threadIdx.x, nth = blockDim.x;
+    const bool live = t < taps * a.Cg;
+    const int cg = live ? t % a.Cg : 0, tap = live ? t / a.Cg : 0;
+    const int t2 = tap % a.K2, t1 = (tap / a.K2) % a.K1, t0 = tap / (a.K2 * a.K1);
+    const int tbase = ((t0 * ta.R1 + t1) * ta.R2 + t2) * CA;      // this thread's tap inside the A box
+    const int P = ta.T0 * ta.T1 * ta.T2;
+    float acc[CA];
+#pragma unroll
+    for (int c = 0; c < CA; ++c) acc[c] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ta.ntiles; tile += gridDim.x) {
+        int r = tile;
+        const int b2 = r % ta.nt2; r /= ta.nt2;
+        const int b1 = r % ta.nt1; r /= ta.nt1;
+        const int b0 = r % ta.nt0; const int b = r / ta.nt0;
+        const int o0b = b0 * ta.T0, o1b = b1 * ta.T1, o2b = b2 * ta.T2;
+        const int i0b = o0b * a.S0 - a.P0, i1b = o1b * a.S1 - a.P1, i2b = o2b * a.S2 - a.P2;
+        __syncthreads();                                  // the previous tile is consumed
+        // A box: rows of R2*CA floats (contiguous along the last input axis)
+        const int rowa = ta.R2 * CA;
+        for (int i = t; i < abox; i += nth) {
+            const int e = i % rowa, rr = i / rowa;
+            const int r1 = rr % ta.R1, r0 = rr / ta.R1;
+            const int i0 = i0b + r0, i1 = i1b + r1, i2 = i2b + e / CA;
+            float v = 0.f;
+            if ((unsigned)i0 < (unsigned)a.I0 && (unsigned)i1 < (unsigned)a.I1 && (unsigned)i2 < (unsigned)a.I2)
+                v = a.a[((((size_t)b * a.I0 + i0) * a.I1 + i1) * a.I2 + i2b) * CA + e];
+            As[i] = v;
+        }
+        // G rows: T2*Cg floats per (q0, q1); positions past the end of an axis read as zero (they contribute nothing)
+        const int rowg = ta.T2 * a.Cg;
+        for (int i = t; i < P * a.Cg; i += nth) {
+            const int e = i % rowg, rr = i / rowg;
+            const int q1 = rr % ta.T1, q0 = rr / ta.T1;
+            const int o0 = o0b + q0, o1 = o1b + q1, o2 = o2b + e / a.Cg;
+            float v = 0.f;
+            if (o0 < a.O0 && o1 < a.O1 && o2 < a.O2)
+                v = a.g[((((size_t)b * a.O0 + o0) * a.O1 + o1) * a.O2 + o2b) * a.Cg + e];
+            Gs[i] = v;
+        }
+        __syncthreads();
+        if (live) {
+            const float* gp = Gs + cg;
+            for (int q0 = 0; q0 < ta.T0; ++q0)
+                for (int q1 = 0; q1 < ta.T1; ++q1) {
+                    const float* ap = As + tbase + ((q0 * a.S0 * ta.R1 + q1 * a.S1) * ta.R2) * CA;
+                    const float* gq = gp + (size_t)((q0 * ta.T1 + q1) * ta.T2) * a.Cg;
+#pragma unroll 4
+                    for (int q2 = 0; q2 < ta.T2; ++q2) {
+                        const float g = gq[q2 * a.Cg];
+#pragma unroll
+                        for (int c = 0; c < CA; ++c) acc[c] = fmaf(ap[q2 * a.S2 * CA + c], g, acc[c]);
+                    }
+                }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < CA; ++c) unsafeAtomicAdd(a.dw + ((size_t)tap * CA + c) * a.Cg + cg, acc[c]);
+    }
+}
+
+// picks a tile that fits LDS; returns RN_E_UNSUPPORTED when the shape is not for this kernel
+static int launch_wgrad_tile(const WgradArgs& a, int B, hipStream_t st)
+{
+    static const bool off = getenv("RN_WGRAD_NO_TILE") != nullptr;
+    const int taps = a.K0 * a.K1 * a.K2;
+    if (off || taps * a.Cg > 1024 || a.Ca > 8 || (a.Ca != 1 && a.Ca != 3 && a.Ca != 5)) return RN_E_UNSUPPORTED;
+    WgradTileArgs ta;
+    ta.w = a;
+    if (a.I2 == 1 && a.O2 == 1 && a.K2 == 1) {          // a 2-D layer [H][W][1][C] is the 3-D layer [1][H][W][C]: same memory, same taps
+        WgradArgs& w = ta.w;
+        w.I2 = a.I1; w.I1 = a.I0; w.I0 = 1; w.O2 = a.O1; w.O1 = a.O0; w.O0 = 1;
+        w.K2 = a.K1; w.K1 = a.K0; w.K0 = 1; w.S2 = a.S1; w.S1 = a.S0; w.S0 = 1; w.P2 = a.P1; w.P1 = a.P0; w.P0 = 0;
+    }
+    {
+        const WgradArgs& w = ta.w;
+        // the last axis long (coalesced rows), a few rows of the others
+        ta.T2 = w.O2 < 64 ? w.O2 : (w.S2 == 1 ? 64 : 32);
+        ta.T1 = w.O1 < 8 ? w.O1 : (w.O0 == 1 ? 8 : 4);
+        ta.T0 = w.O0 < 2 ? w.O0 : 2;
+    }
+    const WgradArgs& a_ = ta.w;
+    for (;;) {
+        ta.R0 = (ta.T0 - 1) * a_.S0 + a_.K0; ta.R1 = (ta.T1 - 1) * a_.S1 + a_.K1; ta.R2 = (ta.T2 - 1) * a_.S2 + a_.K2;
+        const size_t lds = ((size_t)((ta.R0 * ta.R1 * ta.R2 * a.Ca + 3) & ~3) + (size_t)ta.T0 * ta.T1 * ta.T2 * a.Cg) * 4;
+        if (lds <= 64 * 1024) break;
+        if (ta.T0 > 1) ta.T0 = (ta.T0 + 1) / 2; else if (ta.T1 > 1) ta.T1 = (ta.T1 + 1) / 2; else if (ta.T2 > 8) ta.T2 /= 2; else return RN_E_UNSUPPORTED;
+    }
+    ta.nt0 = (a_.O0 + ta.T0 - 1) / ta.T0; ta.nt1 = (a_.O1 + ta.T1 - 1) / ta.T1; ta.nt2 = (a_.O2 + ta.T2 - 1) / ta.T2;
+    const long long nt = (long long)B * ta.nt0 * ta.nt1 * ta.nt2;
+    if (nt > 0x7fffffffLL) return RN_E_UNSUPPORTED;
+    ta.ntiles = (int)nt;
+    const size_t lds = ((size_t)((ta.R0 * ta.R1 * ta.R2 * a.Ca + 3) & ~3) + (size_t)ta.T0 * ta.T1 * ta.T2 * a.Cg) * 4;
+    const int nth = (taps * a.Cg + 63) / 64 * 64;
+    const int per_cu = nth > 512 ? 1 : 2;
+    const unsigned grid = (unsigned)(nt < 256 * per_cu ? nt : 256 * per_cu);
+    auto go = [&](auto kern) -> int {
+        const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc_ != RN_OK) return rc_;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nth), lds, st, ta);
+        return rn_check_launch("conv_wgrad_tile");
+    };
+    return a.Ca == 1 ? go(conv_wgrad_tile_kernel<1>) : a.Ca == 3 ? go(conv_wgrad_tile_kernel<3>) : go(conv_wgrad_tile_kernel<5>);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int WK>
 static int launch_wgrad(WgradArgs& a, hipStream_t st)
 {
@@ -503,6 +635,10 @@ int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const
         P[0] == 1 && P[1] == 1 && P[2] == 1 && O[0] == I[0] && O[1] == I[1] && O[2] == I[2])
         return launch_wgrad_k3d32(A, G, dw, B, I[0], I[1], I[2], a.a_bytes, a.g_bytes, st);
     if (Ca % 4 != 0 || Cg % 4 != 0 || Ca < 8) {
+        {   // LDS-staged narrow kernel where its shape limits allow
+            const int rct = launch_wgrad_tile(a, B, st);
+            if (rct != RN_E_UNSUPPORTED) return rct;
+        }
         // narrow path: one thread per (tap, ca)
         if ((long long)taps * Ca > 1024 || Cg > 32)
             return rn_set_error(RN_E_UNSUPPORTED, "conv_wgrad: Ca=%d Cg=%d taps=%d has no kernel", Ca, Cg, taps);
