@@ -190,8 +190,8 @@ struct W43GemmArgs {
 template <int VP> struct W43Item { const float* vplane; const float* upanel; float* mplane; long long m0; int nb; unsigned voff[VP]; };
 
 // WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128, 128 accumulators);
-// 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64): the launcher runs the last, partial round of a launch as half
-// items of this shape so that it costs half a round.
+// 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64); 1 -> block 64 x 256 (waves 1 x 8, wave tile 64 x 32): the launcher
+// runs the last, partial round of a launch as half or quarter items so that it costs half / three quarters of a round.
 // TAG only names the kernel per layer class in profiler tables (0: Cin >= 1024 -- the res2 trunk; 1: narrower 3x3 layers; 2: F(4x4,4x4))
 template <int WM, int TAG>
 __global__ __launch_bounds__(512, 1)
@@ -200,8 +200,8 @@ void wino43_gemm_kernel(const W43GemmArgs a)
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the stub: the amdgcn builtins below do not instantiate there
     constexpr int WN = 8 / WM, NT = 16 / WN;                          // 16-channel MFMA tiles per wave along channels (8 | 4)
     constexpr int BM = WM * 64, VB = BM * GBK * 4, STAGE = VB + G_UB; // V 32 | 16 KiB + U 32 KiB per stage
-    constexpr int VP = BM / 8 / 8;                                    // V DMA pieces per wave and stage (4 | 2)
-    constexpr int HALF = WM == 2 ? 2 : 1;                             // half items per 256-row item
+    constexpr int VP = BM / 8 / 8;                                    // V DMA pieces per wave and stage (4 | 2 | 1)
+    constexpr int HALF = 4 / WM;                                      // parts of a 256-row item (1 | 2 | 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V BM x 32 | U 8 x 256 x 4]
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
@@ -439,7 +439,7 @@ static int wino43_gemm_launch_t(W43GemmArgs a, int begin, int end, hipStream_t s
     const size_t lds = (size_t)2 * (WM * 64 * GBK * 4 + G_UB);
     auto kern = wino43_gemm_kernel<WM, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
-    const int n = (end - begin) * (WM == 2 ? 2 : 1);
+    const int n = (end - begin) * (4 / WM);
     hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
     return rn_check_launch("wino43_gemm");
 }
@@ -462,16 +462,24 @@ int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, lo
     const int nitems = rn_wino_scheme_nxi(scheme) * a.mblocks * a.nblocks;
     a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO43_PROBE") ? atoi(getenv("RN_WINO43_PROBE")) : 0; a.probe = probe; }
-    // one workgroup per CU takes items id, id + 256, ...: a last round of <= 128 items runs as <= 256 half items (128 rows)
+    // one workgroup per CU takes items id, id + 256, ...: the items of a last, partial round run as half items (128 rows:
+    // rounds of half the length) or quarter items (64 rows) when that fills the machine better -- rem = 128: 256 half items =
+    // half a round; rem = 176: 704 quarter items = 3 quarter rounds instead of a whole one
     static const bool notail = getenv("RN_WINO43_NOTAIL") != nullptr;
     const int tag = scheme == RN_WINO_F44 ? 2 : Cin >= 1024 ? 0 : 1;
     const int rem = nitems % 256;
-    const int tail = (!notail && rem != 0 && rem <= 128) ? rem : 0;
+    int tail_wm = 4;
+    if (!notail && rem != 0) {
+        const int half = (2 * rem + 255) / 256 * 2, quarter = (4 * rem + 255) / 256;       // cost in quarter rounds (whole: 4)
+        if (half < 4) tail_wm = 2;
+        if (quarter < (tail_wm == 2 ? half : 4)) tail_wm = 1;
+    }
+    const int tail = tail_wm == 4 ? 0 : rem;
     if (nitems - tail > 0) {
         const int rc = wino43_gemm_launch<4>(tag, a, 0, nitems - tail, st);
         if (rc != RN_OK) return rc;
     }
-    if (tail > 0) return wino43_gemm_launch<2>(tag, a, nitems - tail, nitems, st);
+    if (tail > 0) return tail_wm == 2 ? wino43_gemm_launch<2>(tag, a, nitems - tail, nitems, st) : wino43_gemm_launch<1>(tag, a, nitems - tail, nitems, st);
     return RN_OK;
 }
 

@@ -21,7 +21,7 @@ def main():
         U = torch.randn(36 * Cin * Cout, device="cuda") * 0.02
         M = torch.empty(36 * T * Cout, device="cuda")
         def run():
-            L.check(L.lib().rn_wino43_gemm(L.ptr(V), L.ptr(U), L.ptr(M), T, Cin, Cout, L.stream_ptr()), "gemm")
+            L.check(L.lib().rn_winograd_gemm(L.RN_WINO_F43, L.ptr(V), L.ptr(U), L.ptr(M), T, Cin, Cout, L.stream_ptr()), "gemm")
         run(); run()
         torch.cuda.synchronize()
         evs = []

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 csv.field_size_limit(1 << 30)
 
 KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s), algorithmic bytes per launch at B=24)
-    # the GEMM stage runs as two launches: full rounds with 256-row blocks (<4>) and the last half round as 128-row blocks (<2>)
+    # the GEMM stage runs as two launches: full rounds with 256-row blocks (<4, .>) and the last partial round as 128-row blocks (<2, .>)
     "wino43_gemm_res2": ("wino43", ["wino43_gemm_kernel<4, 0>", "wino43_gemm_kernel<2, 0>"], 36 * 6144 * (1024 + 1024) * 4 + 36 * 1024 * 1024 * 4),
     "wino43_input_res2": ("wino43", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 36 * 6144 * 1024 * 4),
     "wino43_output_res2": ("wino43", ["wino_output_kernel"], 36 * 6144 * 1024 * 4 + 2 * 24 * 64 * 64 * 1024 * 4),
