@@ -133,14 +133,28 @@ def train_main(args, world, rank, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
+    from rendernet_amd import ops
     for i in range(args.warmup):
         loss = tr.step(vox, poses, targets, patch_size=p, start_point=starts[i])
+    # dominant kernel of the step: the GEMM stage of the F(4x4,3x3) path on the res2 trunk (forward and input-gradient
+    # launches, 42 per step), bracketed by HIP events on the launch stream like in the render bench
+    gemm_events = []
+
+    def stage_hook(stage, tkn):
+        if stage == "gemm" and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            gemm_events.append((ev, tkn))
+            return ev
+        return None
+
+    ops.STAGE_HOOK = stage_hook
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = tr.step(vox, poses, targets, patch_size=p, start_point=starts[args.warmup + i])
     barrier()
     elapsed = time.perf_counter() - t0
+    ops.STAGE_HOOK = None
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,6 +165,17 @@ def train_main(args, world, rank, local_rank):
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
         fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2
         sps = B * world * args.steps / elapsed
+        roof = None
+        if gemm_events:
+            kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
+            T = gemm_events[0][1][0]
+            fl = 2.0 * 36 * T * spec.w_res2 * spec.w_res2
+            roof = {"kernel": "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3)) on the res2 3x3 %d->%d conv, forward and input "
+                              "gradient, T = %d tiles" % (spec.w_res2, spec.w_res2, T),
+                    "bound": "mfma", "achieved": round(fl / (kern_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "avg_launch_ms": round(kern_ms, 4), "launches_timed": len(gemm_events), "flop_per_launch": fl,
+                    "flop_basis": "executed MFMA FLOPs = 2*36*T*Cin*Cout", "traffic": None}
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,7 +185,7 @@ def train_main(args, world, rank, local_rank):
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
             "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
-            "final_loss": lossv}), flush=True)
+            "roofline": roof, "final_loss": lossv}), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------
