@@ -315,57 +315,85 @@ void conv_wino_kernel(const WinoArgs a)
         // filter as A: row = 4*(lane>>4) + r = channel within the 16-wide n-tile, col = lane&15 = the tile's tx: a lane
         // holds channels 4kq..4kq+3 of tile (ty, tx) = (wave, l16) -> 16-B loads and stores, 128 contiguous bytes per pixel
         // and workgroup.  Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = acc[4i+j].
+        // vmcnt retires in issue order: a wait for ANY load also waits for every store issued before it.  So all loads (bias,
+        // alpha, residual) come first, then ONE wait (which also publishes the next item's first stage, whose DMAs were issued
+        // during the last step), then the stores, which drain under the next item's first step.  (Measured: no change against
+        // the interleaved load/store order on the 3-D layers -- 0.90 ms either way; kept because it is the order that cannot
+        // serialise.)
         const int ty = wave, tx = l16;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        constexpr int NG = NT > 2 ? 2 : NT;                // n-tiles per pass (NT = 4: two passes, registers)
+        size_t oo[4];
+        bool inb[4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = cur.nb * (16 * NT) + nt * 16 + 4 * kq;
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
-            const f32x4 av = a.alpha ? *reinterpret_cast<const f32x4*>(a.alpha + n) : zero4;
-            f32x4 c_[TP][2];                     // column transform of every xi row: M[i][*] A
+        for (int p4 = 0; p4 < 4; ++p4) {
+            const int oy = cur.by * 16 + 2 * ty + (p4 >> 1), ox = cur.bx * 32 + 2 * tx + (p4 & 1);
+            inb[p4] = oy < a.H && ox < a.W;
+            oo[p4] = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + cur.nb * (16 * NT) + 4 * kq;
+        }
 #pragma unroll
-            for (int i = 0; i < TP; ++i) {
-                if (MODE == 1) {                 // F(2,2): A^T = [[1,1,0],[0,1,-1]]
-                    c_[i][0] = acc[i * 3 + 0][nt] + acc[i * 3 + 1][nt];
-                    c_[i][1] = acc[i * 3 + 1][nt] - acc[i * 3 + 2][nt];
-                } else {
-                    c_[i][0] = (acc[i * TP + 0][nt] + acc[i * TP + 1][nt]) + acc[i * TP + 2][nt];
-                    c_[i][1] = (acc[i * TP + 1][nt] - acc[i * TP + 2][nt]) - acc[i * TP + TP - 1][nt];
-                }
+        for (int n0 = 0; n0 < NT; n0 += NG) {
+            f32x4 bv[NG], av[NG], rv[NG][4], v[NG][4];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int nt = n0 + g;
+                const int n = cur.nb * (16 * NT) + nt * 16 + 4 * kq;
+                bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : zero4;
+                av[g] = a.alpha ? *reinterpret_cast<const f32x4*>(a.alpha + n) : zero4;
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4)
+                    rv[g][p4] = (a.res && inb[p4]) ? *reinterpret_cast<const f32x4*>(a.res + oo[p4] + nt * 16) : zero4;
             }
 #pragma unroll
-            for (int i = 0; i < NXI; ++i) acc[i][nt] = zero4;
+            for (int g = 0; g < NG; ++g) {
+                const int nt = n0 + g;
+                f32x4 c_[TP][2];                     // column transform of every xi row: M[i][*] A
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int oy = cur.by * 16 + 2 * ty + dy, ox = cur.bx * 32 + 2 * tx + dx;
-                    if (oy < a.H && ox < a.W) {
-                        f32x4 v = MODE == 1 ? (dy == 0 ? c_[0][dx] + c_[1][dx] : c_[1][dx] - c_[2][dx])
-                                            : (dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[TP - 1][dx]);
-                        v += bv;
-                        const size_t oo = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + n;
-                        if (a.z) *reinterpret_cast<f32x4*>(a.z + oo) = v;
-                        if (a.act & RN_ACT_PRELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
-                        }
-                        if (a.act & RN_ACT_ELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
-                        }
-                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + oo);
-                        if (a.act & RN_ACT_SIGMOID) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-                        }
-                        *reinterpret_cast<f32x4*>(a.y + oo) = v;
+                for (int i = 0; i < TP; ++i) {
+                    if (MODE == 1) {                 // F(2,2): A^T = [[1,1,0],[0,1,-1]]
+                        c_[i][0] = acc[i * 3 + 0][nt] + acc[i * 3 + 1][nt];
+                        c_[i][1] = acc[i * 3 + 1][nt] - acc[i * 3 + 2][nt];
+                    } else {
+                        c_[i][0] = (acc[i * TP + 0][nt] + acc[i * TP + 1][nt]) + acc[i * TP + 2][nt];
+                        c_[i][1] = (acc[i * TP + 1][nt] - acc[i * TP + 2][nt]) - acc[i * TP + TP - 1][nt];
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < NXI; ++i) acc[i][nt] = zero4;
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int dy = p4 >> 1, dx = p4 & 1;
+                    v[g][p4] = (MODE == 1 ? (dy == 0 ? c_[0][dx] + c_[1][dx] : c_[1][dx] - c_[2][dx])
+                                          : (dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[TP - 1][dx])) + bv[g];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // bias / alpha / residual are in, and so is the next item's first stage
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    if (!inb[p4]) continue;
+                    const int nt = n0 + g;
+                    f32x4 o = v[g][p4];
+                    if (a.z) *reinterpret_cast<f32x4*>(a.z + oo[p4] + nt * 16) = o;
+                    if (a.act & RN_ACT_PRELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f) + av[g][e] * fminf(o[e], 0.f);
+                    }
+                    if (a.act & RN_ACT_ELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : expf(o[e]) - 1.f;
+                    }
+                    if (a.res) o += rv[g][p4];
+                    if (a.act & RN_ACT_SIGMOID) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = 1.f / (1.f + __expf(-o[e]));
+                    }
+                    *reinterpret_cast<f32x4*>(a.y + oo[p4] + nt * 16) = o;
                 }
         }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                                       // every wave waited for its own DMAs above; the stores drain on their own
         stage ^= 1;
         if (!has_next) break;
         id += G;
