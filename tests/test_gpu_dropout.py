@@ -26,7 +26,8 @@ def test_dropout_matches_the_oracle_bit_for_bit(n, kp):
 def test_dropout_statistics_and_backward_mask():
     from rendernet_amd import ops
     kp = 0.75
-    x = torch.rand((8, 64, 64, 32), device="cuda") + 0.5
+    gen = torch.Generator(device="cuda").manual_seed(5)                                 # fixed data: the test is deterministic
+    x = torch.rand((8, 64, 64, 32), device="cuda", generator=gen) + 0.5
     x.requires_grad_(True)
     ops.seed_dropout(99)
     y = ops.dropout(x, kp)
@@ -35,7 +36,7 @@ def test_dropout_statistics_and_backward_mask():
     assert abs(rate - kp) < 4 * np.sqrt(kp * (1 - kp) / x.numel()) + 1e-4            # keep rate = keep_prob
     assert torch.allclose(y[kept], (x / kp)[kept])                                      # survivors scaled by 1/kp
     assert abs(float(y.detach().mean()) / float(x.detach().mean()) - 1.0) < 5e-3                          # E[y] = x
-    g = torch.randn_like(y)
+    g = torch.rand(y.shape, device="cuda", generator=gen) + 0.25                        # never zero: (grad != 0) is the mask
     y.backward(g)
     assert torch.equal(x.grad != 0, kept) and torch.allclose(x.grad[kept], (g / kp)[kept])   # same mask forward / backward
     z = ops.dropout(x.detach(), kp)                                                     # next call: a fresh stream
