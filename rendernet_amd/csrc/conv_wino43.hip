@@ -19,17 +19,18 @@
 // V and M live in a caller-provided workspace (nxi*T*(Cin+Cout) floats: 1.8 GB on the headline res2 shape, against 288 GB).
 //
 // GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), block 256 tiles x 256 channels, K step 32; both operands
-// go global -> LDS by DMA (raw_ptr_buffer_load_lds, 1 KiB per wave instruction), two stages of 64 KiB.  U is the MFMA A
-// operand so that a lane's four accumulator registers are four consecutive output channels (16-byte stores, 64 contiguous
-// bytes per tile row and store instruction).  Persistent grid (one workgroup per CU), items enumerated so that the 32
+// go global -> LDS by DMA (raw_ptr_buffer_load_lds, 1 KiB per wave instruction), two stages of 64 KiB; v_mfma_f32_32x32x2_f32
+// (a wave = 2 x 4 tiles of 32 x 32, 128 accumulators; the 16x16x4 form of the same kernel measured 1-3 % slower and needs 256
+// VGPRs against 209).  U is the MFMA A operand so that accumulator registers come in groups of four consecutive output
+// channels (16-byte stores).  Persistent grid (one workgroup per CU), items enumerated so that the 32
 // workgroups of an XCD share one xi and neighbouring blocks (its L2 then holds their U panel and V panels once).
 #include "rn_common.h"
 #include "wino_mats.h"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -189,8 +190,8 @@ struct W43GemmArgs {
 
 template <int VP> struct W43Item { const float* vplane; const float* upanel; float* mplane; long long m0; int nb; unsigned voff[VP]; };
 
-// WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128, 128 accumulators);
-// 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64); 1 -> block 64 x 256 (waves 1 x 8, wave tile 64 x 32): the launcher
+// WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles,
+// 128 accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64); 1 -> block 64 x 256 (waves 1 x 8, 64 x 32): the launcher
 // runs the last, partial round of a launch as half or quarter items so that it costs half / three quarters of a round.
 // TAG only names the kernel per layer class in profiler tables (0: Cin >= 1024 -- the res2 trunk; 1: narrower 3x3 layers; 2: F(4x4,4x4))
 template <int WM, int TAG>
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512, 1)
 void wino43_gemm_kernel(const W43GemmArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)     // the host pass only needs the stub: the amdgcn builtins below do not instantiate there
-    constexpr int WN = 8 / WM, NT = 16 / WN;                          // 16-channel MFMA tiles per wave along channels (8 | 4)
+    constexpr int WN = 8 / WM, NT = 16 / WN;                          // 16-channel groups per wave along channels (8 | 4 | 2)
     constexpr int BM = WM * 64, VB = BM * GBK * 4, STAGE = VB + G_UB; // V 32 | 16 KiB + U 32 KiB per stage
     constexpr int VP = BM / 8 / 8;                                    // V DMA pieces per wave and stage (4 | 2 | 1)
     constexpr int HALF = 4 / WM;                                      // parts of a 256-row item (1 | 2 | 4)
@@ -206,18 +207,17 @@ void wino43_gemm_kernel(const W43GemmArgs a)
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l16 = lane & 15, kq = lane >> 4;
+    const int l32 = lane & 31, hb = lane >> 5;                       // 32x32x2 MFMA: lane = (row / column, k)
     const int wm = wave / WN, wn = wave % WN;
 
-    // fragment-read offsets inside a stage.  A K step of 32 is consumed as four sub-groups q of 8 k: lane (l16, kq) supplies
-    // k = 8q + 2kq + j to MFMA j = 0, 1 of the sub-group -- one 8-byte LDS read per operand row.  V rows are 128 B (32 k);
-    // their eight 16-B chunks are XOR-swizzled with (row >> 1) & 7 so that the rows of a read spread over all banks.
-    const unsigned vrow = (unsigned)((wm * 64 + l16) * 128 + (kq & 1) * 8);
-    const unsigned vsw = (unsigned)((l16 >> 1) & 7);
+    // fragment-read offsets inside a stage.  A K step of 32 is consumed as four sub-groups q of 8 k: lane (l32, hb) supplies
+    // k = 8q + 4hb + s to MFMA s = 0..3 of the sub-group -- one 16-byte LDS read per operand tile.
+    const unsigned vrow = (unsigned)((wm * 64 + l32) * 128);
+    const unsigned vsw = (unsigned)((l32 >> 1) & 7);
     unsigned vaddr[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vaddr[q] = vrow + (((unsigned)(2 * q + (kq >> 1)) ^ vsw) << 4);
-    const unsigned uaddr = (unsigned)(VB + (((kq >> 1) * 256) + wn * (NT * 16) + l16) * 16 + (kq & 1) * 8);
+    for (int q = 0; q < 4; ++q) vaddr[q] = vrow + (((unsigned)(2 * q + hb) ^ vsw) << 4);
+    const unsigned uaddr = (unsigned)(VB + ((hb * 256) + wn * (NT * 16) + l32) * 16);
 
     // one item: decoded into scalars + the per-lane V offsets of this wave's DMA pieces (piece p = wave + 8i covers rows
     // 8p .. 8p+7 (lane >> 3); chunk slot lane & 7 holds chunk slot ^ swizzle(row))
@@ -257,33 +257,33 @@ void wino43_gemm_kernel(const W43GemmArgs a)
                                                      (unsigned)((wave + 8 * i) * 1024 + lane * 16), s * G_UB, 0, 0);
     };
 
-    f32x4 acc[4][NT];
-    // fragments of sub-group (stage buffer sb, q): 4 tile-row groups of V, NT channel groups of U
-    auto load_frags = [&](const char* sb, int q, f32x2 (&v)[4], f32x2 (&u)[NT]) {
+    constexpr int NT2 = NT / 2;                                       // 32-channel MFMA tiles per wave along channels (4 | 2 | 1)
+    f32x16 acc[2][NT2];
+    auto load_frags = [&](const char* sb, int q, f32x4 (&v)[2], f32x4 (&u)[NT2]) {
         const char* vp = sb + vaddr[q];
         const char* up = sb + uaddr + q * (2 * 256 * 16);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const f32x2*>(vp + mt * (16 * 128));
+        for (int mt = 0; mt < 2; ++mt) v[mt] = *reinterpret_cast<const f32x4*>(vp + mt * (32 * 128));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) u[nt] = *reinterpret_cast<const f32x2*>(up + nt * (16 * 16));
+        for (int nt = 0; nt < NT2; ++nt) u[nt] = *reinterpret_cast<const f32x4*>(up + nt * (32 * 16));
     };
-    auto mfmas = [&](const f32x2 (&v)[4], const f32x2 (&u)[NT]) {
+    auto mfmas = [&](const f32x4 (&v)[2], const f32x4 (&u)[NT2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[nt][j], v[mt][j], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[nt][j], v[mt][j], acc[mt][nt], 0, 0, 0);
     };
 
     Item cur, nxt;
     if (!decode(0, cur)) return;
-    // Software pipeline: the fragments of sub-group q+1 are read from LDS while the 64 (32) MFMAs of sub-group q run, across
+    // Software pipeline: the fragments of sub-group q+1 are read from LDS while the 32 (16, 8) MFMAs of sub-group q run, across
     // K steps and across items -- the one barrier of a step sits before its last sub-group, where the next stage has landed
     // (DMAs issued at the head of the step; in an item's last step they fetch the NEXT item's first stage) and every wave
     // has finished reading the current one.  The epilogue's stores drain under the next item's first step.
-    f32x2 v0[4], u0[NT], v1[4], u1[NT];
+    f32x4 v0[2], u0[NT2], v1[2], u1[NT2];
     issue(cur, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -292,9 +292,11 @@ void wino43_gemm_kernel(const W43GemmArgs a)
     for (int r = 0;; ++r) {
         const bool have_next = decode(r + 1, nxt);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         for (int s = 0; s < a.ksteps; ++s) {
             const char* sb = smem + stage * STAGE;
             const char* sn = smem + (stage ^ 1) * STAGE;
@@ -315,18 +317,21 @@ void wino43_gemm_kernel(const W43GemmArgs a)
             mfmas(v1, u1);
             stage ^= 1;
         }
-        // D = U-tile (rows: channel 4*kq + r of the tile) x V-tile (cols: tile row l16): the lane holds channels
-        // n0 + wn*NT*16 + nt*16 + 4*kq + r of tile row m0 + wm*64 + mt*16 + l16; a store covers 64 contiguous bytes per row.
-        // Buffer stores: rows >= T fall outside m_bytes and are dropped by the hardware.
+        // D (32 x 32) = U-tile (rows: channels) x V-tile (cols: tile rows): register r of lane (l32, hb) is channel
+        // (r & 3) + 8*(r >> 2) + 4*hb of the tile, tile row l32 -> four 16-byte stores per MFMA tile
         if (!(a.probe & 2)) {
             const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
-            const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l16) * a.Cout + cur.nb * GBN + wn * (NT * 16) + kq * 4) * 4);
+            const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l32) * a.Cout + cur.nb * GBN + wn * (NT * 16) + hb * 4) * 4);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), mrsrc,
-                                                           mo + (unsigned)(mt * 16 * a.Cout * 4) + nt * 64, 0, 0);
+                for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), mrsrc,
+                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, 0);
+                    }
         }
         if (!have_next) break;
         cur = nxt;
