@@ -12,8 +12,8 @@
 // 36 multiplies per 4x4 outputs and channel pair instead of 144 (conv_wino_wgrad.hip, F(2x2,3x3): 64).  The GEMM reduces
 // over the tiles (K = T): block 256 ci x 256 co, K step 32 tiles; both operand panels are [tile][channel] rows of 1 KiB that
 // go global -> LDS by DMA, one row per wave instruction, their sixteen 64-byte granules XOR-swizzled with (row & 3) so that
-// the four k-lanes of a fragment read (rows t, t+1, t+2, t+3) hit different banks.  dM is the MFMA A operand: a lane holds
-// four consecutive output channels of one input channel (16-byte stores into dU [ci][co]).  Same persistent, XCD-aware
+// the two k-lanes of a fragment read (rows t, t+1; 32 channels each) hit different banks.  v_mfma_f32_32x32x2_f32 with dM as the A
+// operand: accumulator registers come in groups of four consecutive output channels of one input channel (16-byte stores into dU).  Same persistent, XCD-aware
 // enumeration and one-sub-group-ahead fragment pipeline as the forward GEMM (conv_wino43.hip).
 #include "rn_common.h"
 #include "wino_mats.h"
@@ -21,6 +21,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int WBK = 32;                            // tiles per K step
@@ -167,17 +168,25 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l16 = lane & 15, kq = lane >> 4;
+    const int l32 = lane & 31, hb = lane >> 5;                       // 32x32x2 MFMA: lane = (channel of the tile, k)
     const int wm = wave >> 1, wn = wave & 1;                          // 64-ci group (0..3), 128-co half (0..1)
 
-    // fragment reads: k-group g of a stage = rows 4g + kq; a row's 64-byte granule x sits at granule x ^ (row & 3) = x ^ kq
-    unsigned xk[4];
+    // fragment reads: group g of a stage = rows 4g .. 4g+3, consumed as two MFMA k-steps u = 0, 1 with rows 4g + 2u + hb.
+    // A row's 64-byte granule x sits at granule x ^ swz(row & 3), swz = {0, 2, 1, 3}: the two rows of a k-step differ in
+    // swizzle bit 1, so the 32 channels (two granules) of lanes hb = 0 and hb = 1 land in different banks.
+    unsigned xk[2][2];                                                // [k-step u][tile parity c2] -> byte offset inside the group
 #pragma unroll
-    for (int x = 0; x < 4; ++x) xk[x] = (unsigned)(((x ^ kq) << 6) + kq * 1024 + l16 * 4);
-    const unsigned vbase = (unsigned)(wm * 4 * 64);                   // + xk[mt]
-    const unsigned mbase = (unsigned)(W_OPB + wn * 8 * 64);           // + (nt & 4) * 64 + xk[nt & 3]
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int row = 2 * u + hb, sw = ((row & 1) << 1) | (row >> 1);
+            xk[u][c2] = (unsigned)((((c2 * 2 + (l32 >> 4)) ^ sw) << 6) + row * 1024 + (l32 & 15) * 4);
+        }
+    const unsigned vbase = (unsigned)(wm * 4 * 64);                   // + xk[u][mt]               (ci tile mt = 0, 1)
+    const unsigned mbase = (unsigned)(W_OPB + wn * 8 * 64);           // + (nt >> 1) * 256 + xk[u][nt & 1]   (co tile nt = 0..3)
     // DMA: piece p = wave + 8i is row p of the stage (p & 3 == wave & 3); lane L moves the 16 bytes that land at position L
-    const unsigned dlane = (unsigned)((((lane >> 2) ^ (wave & 3)) << 6) + (lane & 3) * 16);
+    const int dsw = (((wave & 3) & 1) << 1) | ((wave & 3) >> 1);
+    const unsigned dlane = (unsigned)((((lane >> 2) ^ dsw) << 6) + (lane & 3) * 16);
 
     struct Item { const float* vplane; const float* mplane; float* ubase; int upitch, ci0, co0, nsteps; long long t0; };
     const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
@@ -218,25 +227,31 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
         }
     };
 
-    f32x4 acc[4][8];
-    auto load_frags = [&](const char* sb, int g, float (&v)[4], float (&m)[8]) {
+    f32x16 acc[2][4];
+    // fragments of group g: for each of its two k-steps 2 ci tiles of V and 4 co tiles of dM
+    auto load_frags = [&](const char* sb, int g, float (&v)[2][2], float (&m)[2][4]) {
         const char* base = sb + g * 4096;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) v[mt] = *reinterpret_cast<const float*>(base + vbase + xk[mt]);
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) m[nt] = *reinterpret_cast<const float*>(base + mbase + (nt & 4) * 64 + xk[nt & 3]);
+            for (int mt = 0; mt < 2; ++mt) v[u][mt] = *reinterpret_cast<const float*>(base + vbase + xk[u][mt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) m[u][nt] = *reinterpret_cast<const float*>(base + mbase + (nt >> 1) * 256 + xk[u][nt & 1]);
+        }
     };
-    auto mfmas = [&](const float (&v)[4], const float (&m)[8]) {
+    auto mfmas = [&](const float (&v)[2][2], const float (&m)[2][4]) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[nt], v[mt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(m[u][nt], v[u][mt], acc[mt][nt], 0, 0, 0);
     };
 
     Item cur, nxt;
     if (!decode(0, cur)) return;
-    float v0[4], m0[8], v1[4], m1[8];
+    float v0[2][2], m0[2][4], v1[2][2], m1[2][4];
     issue(cur, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -245,16 +260,18 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
     for (int r = 0;; ++r) {
         const bool have_next = decode(r + 1, nxt);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         for (int s = 0; s < cur.nsteps; ++s) {
             const char* sb = smem + stage * W_STAGE;
             const char* sn = smem + (stage ^ 1) * W_STAGE;
             const bool last = s + 1 == cur.nsteps;
             if (!last) issue(cur, s + 1, stage ^ 1);
             else if (have_next) issue(nxt, 0, stage ^ 1);
-            // eight k-groups of 4 tiles; the fragments of group g+1 are read while the 32 MFMAs of group g run
+            // eight groups of 4 tiles (two 32x32x2 k-steps each); the fragments of group g+1 are read while the 16 MFMAs of group g run
             load_frags(sb, 1, v1, m1); mfmas(v0, m0);
             load_frags(sb, 2, v0, m0); mfmas(v1, m1);
             load_frags(sb, 3, v1, m1); mfmas(v0, m0);
@@ -268,14 +285,18 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
             mfmas(v1, m1);
             stage ^= 1;
         }
-        // D = dM-tile (rows: co 4*kq + r of the tile) x V-tile (cols: ci l16): 16-byte stores, 64 contiguous bytes per ci row
+        // D (32 x 32) = dM-tile (rows: co) x V-tile (cols: ci): register r of lane (l32, hb) is co (r & 3) + 8*(r >> 2) + 4*hb of
+        // the tile, ci l32 -> four 16-byte stores per MFMA tile
         {
-            float* ub = cur.ubase + (size_t)(wm * 64 + l16) * cur.upitch + wn * 128 + kq * 4;
+            float* ub = cur.ubase + (size_t)(wm * 64 + l32) * cur.upitch + wn * 128 + hb * 4;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-                    *reinterpret_cast<f32x4*>(ub + (size_t)mt * 16 * cur.upitch + nt * 16) = acc[mt][nt];
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(ub + (size_t)mt * 32 * cur.upitch + nt * 32 + g * 8) =
+                            f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
         }
         if (!have_next) break;
         cur = nxt;
