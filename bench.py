@@ -336,7 +336,7 @@ def render_main(args, world, rank, local_rank):
             kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
             T = gemm_events[0][1][0]
             exec_flop = 2.0 * 36 * T * wtrunk * wtrunk
-            name = "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3): 256x256x32 blocks, 16x16x4 fp32 MFMA, LDS-DMA, persistent)"
+            name = "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3): 256x256x32 blocks, 32x32x2 fp32 MFMA, LDS-DMA, persistent)"
             basis = "executed MFMA FLOPs = 2*36*T*Cin*Cout, T = B*ceil(H/4)*ceil(W/4) tiles"
             tkey = "wino43_gemm_res2"
         else:
