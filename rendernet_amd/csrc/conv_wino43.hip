@@ -507,6 +507,13 @@ int rn_launch_wino_output(int scheme, const float* M, const float* bias, const f
     return rn_check_launch("wino_output");
 }
 
+long long rn_wino43_plane_limit()
+{
+    const char* e = getenv("RN_WINO43_MAX_PLANE");
+    const long long v = e ? atoll(e) : 0;
+    return (v > 0 && v < 0x7fffff00LL) ? v : 0x7fffff00LL;
+}
+
 size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout)
 {
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
@@ -522,10 +529,13 @@ int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const floa
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
-    if ((long long)th * tw * cmax * 4 >= 0x7fffff00LL)
+    // every xi plane must fit a buffer resource (2 GiB); RN_WINO43_MAX_PLANE lowers the limit so that tests can reach the
+    // batch-chunk branch without 150 GB of workspace
+    const long long lim = rn_wino43_plane_limit();
+    if ((long long)th * tw * cmax * 4 >= lim)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: one image's transform plane exceeds the 2 GiB buffer window");
-    if (T * cmax * 4 >= 0x7fffff00LL) {                         // batch chunks: every xi plane must fit a buffer resource
-        const int chunk = (int)(0x7fffff00LL / ((long long)th * tw * cmax * 4));
+    if (T * cmax * 4 >= lim) {                                  // batch chunks
+        const int chunk = (int)((lim - 1) / ((long long)th * tw * cmax * 4));      // >= 1: one image fits (checked above)
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = B - b0 < chunk ? B - b0 : chunk;
             const size_t xo = (size_t)b0 * H * W * Cin, yo = (size_t)b0 * H * W * Cout;

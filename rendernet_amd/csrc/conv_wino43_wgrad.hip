@@ -330,11 +330,11 @@ int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, flo
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
-    if ((long long)th * tw * cmax * 4 >= 0x7fffff00LL)
+    const long long lim = rn_wino43_plane_limit();
+    if ((long long)th * tw * cmax * 4 >= lim)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: one image's transform plane exceeds the 2 GiB buffer window");
-    if ((T + WBK) * cmax * 4 >= 0x7fffff00LL) {                 // batch chunks (dw accumulates)
-        const int chunk = (int)(0x7fffff00LL / ((long long)th * tw * cmax * 4)) - 1;
-        if (chunk < 1) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43_wgrad: transform plane too large");
+    if (T * cmax * 4 >= lim) {                                  // batch chunks (dw accumulates); rows T .. T+31 of a K step lie
+        const int chunk = (int)((lim - 1) / ((long long)th * tw * cmax * 4));   // past the plane: offsets < 2^32, read as zeros
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = B - b0 < chunk ? B - b0 : chunk;
             const int rc = rn_launch_conv_wino43_wgrad(scheme, x + (size_t)b0 * H * W * Cin, dz + (size_t)b0 * H * W * Cout, dw, ws,

@@ -378,6 +378,35 @@ WINO44_CASES = [
 ]
 
 
+def test_conv2d_winograd43_batch_chunks(monkeypatch):
+    """The F(4x4) launchers split the batch when a transform plane would not fit one buffer resource (2 GiB).  Reaching that for
+    real needs ~150 GB of workspace, so RN_WINO43_MAX_PLANE lowers the limit: 7 items in chunks of 2, 2, 2, 1 must equal the
+    unchunked call bit for bit (forward) and to rounding (filter gradient: a different accumulation order)."""
+    from rendernet_amd import ops, _lib as L
+    B, H, W, Cin, Cout = 7, 8, 12, 256, 256
+    rng = np.random.default_rng(21)
+    x, w = _dev(_rand(rng, B, H, W, Cin)), _dev(_xavier(rng, (3, 3, Cin, Cout)))
+    dz = _dev(_rand(rng, B, H, W, Cout))
+    old, ops.WINO43_MIN_PIXELS = ops.WINO43_MIN_PIXELS, 1
+    lib = L.lib()
+
+    def wgrad():
+        dw = torch.zeros(3, 3, Cin, Cout, device="cuda")
+        ws = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+        L.check(lib.rn_conv2d_wino43_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(ws), B, H, W, Cin, Cout, L.stream_ptr()), "wgrad")
+        return dw
+    try:
+        pw = ops.pack_conv(w)
+        whole, dw_whole = ops.conv2d(x, pw), wgrad()
+        plane = 2 * 3 * 256 * 4                                   # tiles per image * channels * 4 B
+        monkeypatch.setenv("RN_WINO43_MAX_PLANE", str(2 * plane + plane // 2))      # two images fit, three do not
+        chunked, dw_chunked = ops.conv2d(x, pw), wgrad()
+        assert torch.equal(whole, chunked)
+        assert float((dw_whole - dw_chunked).abs().max()) <= 1e-5 * float(dw_whole.abs().max())
+    finally:
+        ops.WINO43_MIN_PIXELS = old
+
+
 @pytest.mark.parametrize("case", WINO44_CASES)
 def test_conv2d_winograd44(case):
     """rn_conv2d_wino44_fwd (conv and stride-1 transposed conv) vs the oracle, vs the F(2x2,2x2)x4 kernel on the same filter,
