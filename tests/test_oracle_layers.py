@@ -124,3 +124,27 @@ def test_prelu_projection_sigmoid_bce():
     t = rng.uniform(0, 1, (2, 4, 4, 1)).astype(np.float32)
     want = np.mean(-np.sum(t * np.log(1e-6 + p) + (1 - t) * np.log(1e-6 + 1 - p), axis=(1, 2, 3)))
     assert abs(float(OL.bce_loss(p, t)) - want) < 1e-4
+
+
+@pytest.mark.parametrize("shape,k,s", [((1, 9, 7, 3), 3, (1, 1)), ((2, 8, 8, 2), 4, (1, 1)), ((1, 10, 9, 2), 4, (2, 2)),
+                                       ((1, 6, 7, 5, 2), 3, (1, 1, 2)), ((1, 8, 8, 8, 1), 5, (2, 2, 2))])
+def test_conv_matches_scipy_correlate(shape, k, s):
+    """A third, independent statement of the SAME conv: zero-pad by TF's (pad_before, pad_after) table, full 'valid'
+    cross-correlation with scipy.signal.correlate per channel pair, then keep every s-th output."""
+    from scipy.signal import correlate
+    rng = np.random.default_rng(sum(shape) + k)
+    nd = len(shape) - 2
+    cin, cout = shape[-1], 3
+    x = rng.standard_normal(shape).astype(np.float32)
+    w = rng.standard_normal((k,) * nd + (cin, cout)).astype(np.float32)
+    got = (OL.conv2d if nd == 2 else OL.conv3d)(x, w, None, s).numpy()
+    pads = [OL.same_pads(shape[1 + d], k, s[d]) for d in range(nd)]
+    xp = np.pad(x.astype(np.float64), [(0, 0)] + [tuple(p) for p in pads] + [(0, 0)])
+    want = np.zeros(got.shape, np.float64)
+    for b in range(shape[0]):
+        for n in range(cout):
+            acc = 0.0
+            for c in range(cin):
+                acc = acc + correlate(xp[b, ..., c], w[..., c, n].astype(np.float64), mode="valid")
+            want[b, ..., n] = acc[tuple(slice(None, None, s[d]) for d in range(nd))]
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
