@@ -168,14 +168,15 @@ def train_main(args, world, rank, local_rank):
         roof = None
         if gemm_events:
             kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
-            T = gemm_events[0][1][0]
-            fl = 2.0 * 36 * T * spec.w_res2 * spec.w_res2
-            roof = {"kernel": "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3)) on the res2 3x3 %d->%d conv, forward and input "
-                              "gradient, T = %d tiles" % (spec.w_res2, spec.w_res2, T),
+            T, which = gemm_events[0][1][0], gemm_events[0][1][3]
+            nxi, fname = WINO_SCHEMES[which]
+            fl = 2.0 * nxi * T * spec.w_res2 * spec.w_res2
+            roof = {"kernel": "wino43_gemm_kernel (GEMM stage of Winograd %s) on the res2 3x3 %d->%d conv, forward and input "
+                              "gradient, T = %d tiles" % (fname, spec.w_res2, spec.w_res2, T),
                     "bound": "mfma", "achieved": round(fl / (kern_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(fl / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_ms": round(kern_ms, 4), "launches_timed": len(gemm_events), "flop_per_launch": fl,
-                    "flop_basis": "executed MFMA FLOPs = 2*36*T*Cin*Cout", "traffic": None}
+                    "flop_basis": "executed MFMA FLOPs = 2*%d*T*Cin*Cout" % nxi, "traffic": None}
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,13 +333,15 @@ def render_main(args, world, rank, local_rank):
         direct_flop = 2.0 * M * 9 * wtrunk * wtrunk                    # M*K*N*2
         where = " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc)
         if kind == "wino43" and gemm_events:
-            # three launches per layer; the dominant one is the GEMM stage (36 GEMMs T x Cin x Cout), timed on its own
+            # three launches per layer; the dominant one is the GEMM stage (36 / 64 GEMMs T x Cin x Cout), timed on its own
             kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
-            T = gemm_events[0][1][0]
-            exec_flop = 2.0 * 36 * T * wtrunk * wtrunk
-            name = "wino43_gemm_kernel (GEMM stage of Winograd F(4x4,3x3): 256x256x32 blocks, 32x32x2 fp32 MFMA, LDS-DMA, persistent)"
-            basis = "executed MFMA FLOPs = 2*36*T*Cin*Cout, T = B*ceil(H/4)*ceil(W/4) tiles"
-            tkey = "wino43_gemm_res2"
+            T, which = gemm_events[0][1][0], gemm_events[0][1][3]
+            nxi, fname = WINO_SCHEMES[which]
+            m = 6 if which == "f63" else 4
+            exec_flop = 2.0 * nxi * T * wtrunk * wtrunk
+            name = "wino43_gemm_kernel (GEMM stage of Winograd %s: 256x256x32 blocks, 32x32x2 fp32 MFMA, LDS-DMA, persistent)" % fname
+            basis = "executed MFMA FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles" % (nxi, m, m)
+            tkey = "wino63_gemm_res2" if which == "f63" else "wino43_gemm_res2"
         else:
             kern_ms = layer_ms
             exec_flop = direct_flop * 16.0 / 36.0 if kind == "wino" else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
@@ -382,6 +385,9 @@ def render_main(args, world, rank, local_rank):
             print(json.dumps(res), flush=True)
             raise SystemExit("PARITY FAILURE: max|gpu - oracle| = %g > %g on the benched frames" % (err, PARITY_TOL))
     print(json.dumps(res), flush=True)
+
+
+WINO_SCHEMES = {"f43": (36, "F(4x4,3x3)"), "f44": (49, "F(4x4,4x4)"), "f63": (64, "F(6x6,3x3)")}   # ops._wino_scheme -> (planes, name)
 
 
 def read_traffic(key):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 160            /* 0.1.6: + Winograd F(4x4,3x3) / F(4x4,4x4) three-launch paths, Winograd filter gradient */
+#define RN_VERSION 170            /* 0.1.7: + Winograd F(6x6,3x3) on the three-launch path */
 
 /* error codes */
 #define RN_OK              0
@@ -63,6 +63,10 @@ extern "C" {
                                      Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino44_fwd                            */
 #define RN_PACK_CONVT_S1_WINO44 10 /* TF conv_transpose filter [4,4,Cout,Cin], stride 1, taps flipped, same transform:
                                      rn_conv2d_wino44_fwd with transposed = 1                                          */
+#define RN_PACK_CONV_WINO63     11 /* TF conv filter [3,3,Cin,Cout] -> Winograd F(6x6,3x3) form (64 planes, 64*Cin*Cout floats,
+                                     Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino63_fwd                            */
+#define RN_PACK_CONVT_S1_WINO63 12 /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same transform
+                                     (= the input gradient of a 3x3 conv when fed that conv's filter)               */
 #define RN_PACK_CONV_WINO4      5  /* TF conv filter [4,4,Cin,Cout] as four 2x2 sub-filters, each Winograd F(2x2,2x2)
                                      transformed (9 planes; 36*Cin*Cout floats; Cin % 16 == 0, Cout % 16 == 0) for
                                      rn_conv2d_wino4_fwd                                                          */
@@ -194,10 +198,21 @@ int rn_conv2d_wino_supported(int Cin, int Cout);
  * through F(4x4,4x4): 49 multiplies per 4x4 outputs and channel pair instead of 256 (rn_conv2d_wino4_fwd: 144); same three
  * launches on 7x7 patches.  transposed = 0: SAME conv (one row/column of padding before), filter packed with
  * RN_PACK_CONV_WINO44; transposed = 1: stride-1 conv2d_transpose (two before), RN_PACK_CONVT_S1_WINO44 -- the input
- * gradient of the conv when fed the conv's own filter.  fp32 rounding about 1e-5 of max|y|. */
+ * gradient of the conv when fed the conv's own filter.  fp32 rounding about 1e-5 of max|y|.
+ *
+ * rn_conv2d_wino63_fwd: the 3x3 layers again, through F(6x6,3x3): 64 multiplies per 6x6 outputs and channel pair (1.78 per
+ * output against 2.25) on 8x8 patches, interpolation points 0, +-1, +-2, +-1/2, inf; same three launches, same contract as
+ * rn_conv2d_wino43_fwd.  Pays where the 6-pixel tile grid wastes little (64x64 maps: 11x11 tiles, 0.84 of F(4x4,3x3)'s
+ * multiplies and transform traffic; 32x32 maps: no gain).  fp32 rounding about 2.7e-5 of max|y| at Cin = 1024 -- three times
+ * F(4x4,3x3)'s, still 40 times inside the path's 1e-3 tolerance; RN_NO_WINOGRAD63=1 switches it off. */
 int rn_conv2d_wino43_supported(int Cin, int Cout);
 size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout);
 int rn_conv2d_wino43_fwd(const float* x, const float* w_wino43, const float* bias, const float* alpha,
+                         const float* residual, float* y, float* preact, float* workspace,
+                         int B, int H, int W, int Cin, int Cout, int act, void* stream);
+int rn_conv2d_wino63_supported(int Cin, int Cout);
+size_t rn_conv2d_wino63_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_wino63_fwd(const float* x, const float* w_wino63, const float* bias, const float* alpha,
                          const float* residual, float* y, float* preact, float* workspace,
                          int B, int H, int W, int Cin, int Cout, int act, void* stream);
 int rn_conv2d_wino44_supported(int Cin, int Cout);
@@ -205,12 +220,13 @@ size_t rn_conv2d_wino44_workspace_floats(int B, int H, int W, int Cin, int Cout)
 int rn_conv2d_wino44_fwd(const float* x, const float* w_wino44, const float* bias, const float* alpha,
                          const float* residual, float* y, float* preact, float* workspace,
                          int B, int H, int W, int Cin, int Cout, int transposed, int act, void* stream);
-/* The three stages on their own; scheme = RN_WINO_F43 (6x6 tiles, 36 planes) | RN_WINO_F44 (7x7 tiles, 49 planes).
- * T = B*ceil(H/4)*ceil(W/4) tiles; V [nxi][T][Cin], M [nxi][T][Cout]; every plane of V and M must stay below 2 GiB --
+/* The three stages on their own; scheme = RN_WINO_F43 (6x6 tiles, 36 planes) | RN_WINO_F44 (7x7 tiles, 49 planes) |
+ * RN_WINO_F63 (8x8 tiles, 64 planes).  T = B*ceil(H/m)*ceil(W/m) tiles, m = 4 (F43, F44) or 6 (F63); V [nxi][T][Cin], M [nxi][T][Cout]; every plane of V and M must stay below 2 GiB --
  * the rn_conv2d_wino4x_fwd entries split the batch themselves, these do not.  pad_lo: rows / columns of zero padding
  * before the first pixel (SAME conv: 1; stride-1 transposed conv: filter size - 2). */
 #define RN_WINO_F43 0
 #define RN_WINO_F44 1
+#define RN_WINO_F63 2
 int rn_winograd_input_transform(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, void* stream);
 int rn_winograd_gemm(int scheme, const float* V, const float* w_packed, float* M, long long T, int Cin, int Cout, void* stream);
 int rn_winograd_output_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,

@@ -16,7 +16,8 @@ RN_PACK_CONV, RN_PACK_CONVT_S1, RN_PACK_CONVT_S2, RN_PACK_CONV_WINO, RN_PACK_CON
 RN_PACK_CONV_WINO4, RN_PACK_CONVT_S1_WINO4 = 5, 6
 RN_PACK_CONV_WINO43, RN_PACK_CONVT_S1_WINO43 = 7, 8
 RN_PACK_CONV_WINO44, RN_PACK_CONVT_S1_WINO44 = 9, 10
-RN_WINO_F43, RN_WINO_F44 = 0, 1
+RN_PACK_CONV_WINO63, RN_PACK_CONVT_S1_WINO63 = 11, 12
+RN_WINO_F43, RN_WINO_F44, RN_WINO_F63 = 0, 1, 2
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -64,6 +65,9 @@ SIGNATURES = {
     "rn_conv2d_wino43_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino43_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
     "rn_conv2d_wino43_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 6 + [_c_vp]),
+    "rn_conv2d_wino63_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_wino63_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
+    "rn_conv2d_wino63_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 6 + [_c_vp]),
     "rn_conv2d_wino44_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino44_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
     "rn_conv2d_wino44_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 7 + [_c_vp]),

@@ -371,6 +371,12 @@ extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B
 
 extern "C" int rn_conv2d_wino43_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F43, Cin, Cout) ? 1 : 0; }
 extern "C" int rn_conv2d_wino44_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F44, Cin, Cout) ? 1 : 0; }
+extern "C" int rn_conv2d_wino63_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F63, Cin, Cout) ? 1 : 0; }
+extern "C" size_t rn_conv2d_wino63_workspace_floats(int B, int H, int W, int Cin, int Cout)
+{
+    if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(RN_WINO_F63, Cin, Cout)) return 0;
+    return rn_wino43_workspace_floats(RN_WINO_F63, B, H, W, Cin, Cout);
+}
 extern "C" size_t rn_conv2d_wino43_workspace_floats(int B, int H, int W, int Cin, int Cout)
 {
     if (B < 1 || H < 1 || W < 1 || !rn_wino43_supported(RN_WINO_F43, Cin, Cout)) return 0;
@@ -396,6 +402,12 @@ extern "C" int rn_conv2d_wino43_fwd(const float* x, const float* w, const float*
                                     void* stream)
 {
     return wino4x_fwd(RN_WINO_F43, "rn_conv2d_wino43_fwd", x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, 1, act, stream);
+}
+extern "C" int rn_conv2d_wino63_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* residual,
+                                    float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout, int act,
+                                    void* stream)
+{
+    return wino4x_fwd(RN_WINO_F63, "rn_conv2d_wino63_fwd", x, w, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, 1, act, stream);
 }
 extern "C" int rn_conv2d_wino44_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* residual,
                                     float* y, float* preact, float* workspace, int B, int H, int W, int Cin, int Cout,

@@ -1,10 +1,14 @@
-// Stride-1 2-D convs through Winograd minimal filtering with 4x4 output tiles, in three launches, exact-fp32 MFMA for the
+// Stride-1 2-D convs through Winograd minimal filtering with 4x4 / 6x6 output tiles, in three launches, exact-fp32 MFMA for the
 // multiply stage:
 //   scheme F43 -- F(4x4,3x3), 6x6 input tiles, 36 products per 16 outputs instead of 144 (the fused F(2x2,3x3) kernel: 64):
 //                 the wide res_block_2d / *_skip convs (slim.conv2d [3,3]: tools/layer_util.py:91-105,
 //                 RenderNet_Shader.py:71-84, :91-99);
 //   scheme F44 -- F(4x4,4x4), 7x7 input tiles, 49 products per 16 outputs instead of 256 (the F(2x2,2x2)x4 kernel: 144):
 //                 e_conv5 / e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103);
+//   scheme F63 -- F(6x6,3x3), 8x8 input tiles, 64 products per 36 outputs instead of 324 (1.78 per output against F43's 2.25):
+//                 the same 3x3 layers where the map is large enough for the 6-pixel tile grid to pay (ops.py picks per shape;
+//                 on the 64x64 res2 maps 11x11 tiles of 64 products replace 16x16 tiles of 36: 0.84 of the multiplies and
+//                 0.84 of the V / M traffic; fp32 error 2.7e-5 of max|y| against F43's 9e-6 -- wino_mats.h);
 // forward and, with the transposed pack (taps flipped, channel roles swapped, pad_lo = R - 2), the input gradient.
 //
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A          matrices: wino_mats.h (generated, scripts/gen_wino_mats.py)
@@ -46,7 +50,7 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8)
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 1. input transform V = B^T d B.  thread = (tile, VW channels); S = WinoF43 | WinoF44 (wino_mats.h).  The matrix entries
+// 1. input transform V = B^T d B.  thread = (tile, VW channels); S = WinoF43 | WinoF44 | WinoF63 (wino_mats.h).  The matrix entries
 // are compile-time constants of fully unrolled loops: zero entries cost nothing, the rest become FMAs.
 template <class S, int VW>
 __global__ __launch_bounds__(256)
@@ -63,7 +67,7 @@ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H
     if (t >= T) return;
     const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
     const long long b = t / ((long long)tw * th);
-    const int y0 = 4 * ty - pad_lo, x0 = 4 * tx - pad_lo;
+    const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
     const float* xb = x + ((size_t)b * H * W) * C + cv * VW;
     vec tt[A][A];                                              // (B^T d)[i][col]
 #pragma unroll
@@ -123,14 +127,15 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
     const long long b = t / ((long long)tw * th);
     const float* mb = M + (size_t)t * C + cv * VW;
     const size_t plane = (size_t)T * C;
-    vec s[4][A];                                               // (A^T m)[p][j]
+    constexpr int MO = S::M;                                   // output pixels per tile side
+    vec s[MO][A];                                              // (A^T m)[p][j]
 #pragma unroll
     for (int j = 0; j < A; ++j) {
         vec m[A];
 #pragma unroll
         for (int i = 0; i < A; ++i) m[i] = *reinterpret_cast<const vec*>(mb + (size_t)(i * A + j) * plane);
 #pragma unroll
-        for (int p_ = 0; p_ < 4; ++p_) {
+        for (int p_ = 0; p_ < MO; ++p_) {
             vec acc = vec(0.f);
 #pragma unroll
             for (int i = 0; i < A; ++i) {
@@ -143,12 +148,12 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
     const vec bv = bias ? *reinterpret_cast<const vec*>(bias + cv * VW) : vec(0.f);
     const vec av = (act & RN_ACT_PRELU) ? *reinterpret_cast<const vec*>(alpha + cv * VW) : vec(0.f);
 #pragma unroll
-    for (int p_ = 0; p_ < 4; ++p_) {
-        const int oy = 4 * ty + p_;
+    for (int p_ = 0; p_ < MO; ++p_) {
+        const int oy = MO * ty + p_;
         if (oy >= H) continue;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ox = 4 * tx + q;
+        for (int q = 0; q < MO; ++q) {
+            const int ox = MO * tx + q;
             if (ox >= W) continue;
             vec v = bv;
 #pragma unroll
@@ -182,8 +187,9 @@ struct W43GemmArgs {
     const float* V; const float* U; float* M;
     long long T;
     int Cin, Cout;
-    int mblocks, nblocks, ksteps;   // 256-row blocks of T, 256-channel blocks, K steps of 32
-    int item_begin, item_end;       // this launch's range of the items L = (xi*mblocks + mb)*nblocks + nb
+    int mblocks, nblocks, ksteps;   // 256-row blocks of T this launch walks (from mb_begin), 256-channel blocks, K steps of 32
+    int mb_begin, parts;            // parts: BM-row parts of a block that are enumerated (4 / WM; fewer for the ragged last block)
+    int item_begin, item_end;       // this launch's range of the items L = (xi*mblocks + mb - mb_begin)*nblocks + nb
     unsigned v_bytes, u_bytes, m_bytes;  // one xi plane of V; one (xi, n-block) panel of U; one xi plane of M
     int probe;                      // RN_WINO43_PROBE (timing experiments; results are wrong when set): 1 no DMA in the loop, 2 no stores, 4 no barrier
 };
@@ -193,7 +199,8 @@ template <int VP> struct W43Item { const float* vplane; const float* upanel; flo
 // WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles,
 // 128 accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64); 1 -> block 64 x 256 (waves 1 x 8, 64 x 32): the launcher
 // runs the last, partial round of a launch as half or quarter items so that it costs half / three quarters of a round.
-// TAG only names the kernel per layer class in profiler tables (0: Cin >= 1024 -- the res2 trunk; 1: narrower 3x3 layers; 2: F(4x4,4x4))
+// TAG only names the kernel per layer class in profiler tables (0: F43, Cin >= 1024 -- the res2 trunk; 1: narrower F43 layers;
+// 2: F(4x4,4x4); 3: F63, Cin >= 1024; 4: narrower F63 layers)
 template <int WM, int TAG>
 __global__ __launch_bounds__(512, 1)
 void wino43_gemm_kernel(const W43GemmArgs a)
@@ -202,7 +209,6 @@ void wino43_gemm_kernel(const W43GemmArgs a)
     constexpr int WN = 8 / WM, NT = 16 / WN;                          // 16-channel groups per wave along channels (8 | 4 | 2)
     constexpr int BM = WM * 64, VB = BM * GBK * 4, STAGE = VB + G_UB; // V 32 | 16 KiB + U 32 KiB per stage
     constexpr int VP = BM / 8 / 8;                                    // V DMA pieces per wave and stage (4 | 2 | 1)
-    constexpr int HALF = 4 / WM;                                      // parts of a 256-row item (1 | 2 | 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V BM x 32 | U 8 x 256 x 4]
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
@@ -222,15 +228,15 @@ void wino43_gemm_kernel(const W43GemmArgs a)
     // one item: decoded into scalars + the per-lane V offsets of this wave's DMA pieces (piece p = wave + 8i covers rows
     // 8p .. 8p+7 (lane >> 3); chunk slot lane & 7 holds chunk slot ^ swizzle(row))
     typedef W43Item<VP> Item;
-    const int rounds_total = (a.item_end - a.item_begin) * HALF;
+    const int rounds_total = (a.item_end - a.item_begin) * a.parts;
     const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // XCD-contiguous slot in a round
     auto decode = [&](int r, Item& it) -> bool {
         const int id = r * (int)gridDim.x + perm;                     // gridDim.x is a multiple of 8
         if (id >= rounds_total) return false;
-        const int L = a.item_begin + id / HALF, h = id % HALF;
+        const int L = a.item_begin + id / a.parts, h = id % a.parts;
         const int nb = L % a.nblocks;
         const int mbx = L / a.nblocks;
-        const int mb = mbx % a.mblocks, xi = mbx / a.mblocks;
+        const int mb = a.mb_begin + mbx % a.mblocks, xi = mbx / a.mblocks;
         it.nb = nb;
         it.m0 = (long long)mb * GBM + h * BM;
         it.vplane = a.V + (size_t)xi * a.T * a.Cin;
@@ -400,14 +406,16 @@ void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int
     }
 }
 
-int rn_wino_scheme_nxi(int scheme) { return scheme == RN_WINO_F43 ? WinoF43::NXI : scheme == RN_WINO_F44 ? WinoF44::NXI : 0; }
-int rn_wino_scheme_r(int scheme) { return scheme == RN_WINO_F43 ? 3 : scheme == RN_WINO_F44 ? 4 : 0; }
+int rn_wino_scheme_nxi(int scheme) { return scheme == RN_WINO_F43 ? WinoF43::NXI : scheme == RN_WINO_F44 ? WinoF44::NXI : scheme == RN_WINO_F63 ? WinoF63::NXI : 0; }
+int rn_wino_scheme_r(int scheme) { return scheme == RN_WINO_F43 ? WinoF43::R : scheme == RN_WINO_F44 ? WinoF44::R : scheme == RN_WINO_F63 ? WinoF63::R : 0; }
+int rn_wino_scheme_m(int scheme) { return scheme == RN_WINO_F43 ? WinoF43::M : scheme == RN_WINO_F44 ? WinoF44::M : scheme == RN_WINO_F63 ? WinoF63::M : 0; }
 
 bool rn_wino43_supported(int scheme, int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD43") != nullptr || getenv("RN_NO_WINOGRAD") != nullptr;
     static const bool off44 = getenv("RN_NO_WINOGRAD44") != nullptr;
-    if (off || (scheme == RN_WINO_F44 && off44) || rn_wino_scheme_nxi(scheme) == 0) return false;
+    static const bool off63 = getenv("RN_NO_WINOGRAD63") != nullptr;
+    if (off || (scheme == RN_WINO_F44 && off44) || (scheme == RN_WINO_F63 && off63) || rn_wino_scheme_nxi(scheme) == 0) return false;
     return Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
 }
 
@@ -416,44 +424,60 @@ int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Co
     const size_t tot = (size_t)(Cin / 4) * Cout;
     const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
     if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
-    else hipLaunchKernelGGL(wino_pack_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    else if (scheme == RN_WINO_F63) hipLaunchKernelGGL(wino_pack_kernel<WinoF63>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    else return rn_set_error(RN_E_INVALID, "wino_pack: unknown scheme %d", scheme);
     return rn_check_launch("wino_pack");
 }
 
 // the three stages on their own (the C ABI exposes them: a caller can keep V / M, or time the stages separately)
 int rn_launch_wino_input(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, hipStream_t st)
 {
-    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const int m = rn_wino_scheme_m(scheme);
+    if (m == 0) return rn_set_error(RN_E_INVALID, "wino_input: unknown scheme %d", scheme);
+    const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
-    if (scheme == RN_WINO_F43) {
-        const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    const int vw = scheme == RN_WINO_F43 ? 4 : 2;                       // channels per thread: 36 x 4 | 49 x 2 | 64 x 2 registers of patch
+    const unsigned long long n = ((unsigned long long)T * (C / vw) + 255) / 256;
+    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_input_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8, pad_lo);
-    } else {
-        const unsigned long long n = ((unsigned long long)T * (C / 2) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    else if (scheme == RN_WINO_F44)
         hipLaunchKernelGGL((wino_input_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8, pad_lo);
-    }
+    else
+        hipLaunchKernelGGL((wino_input_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, x, V, H, W, C, th, tw, T, nblk8, pad_lo);
     return rn_check_launch("wino_input");
 }
 
+// items [begin, end) of the block range the args name, `parts` BM-row parts of each (0: all 4 / WM of them)
 template <int WM, int TAG>
-static int wino43_gemm_launch_t(W43GemmArgs a, int begin, int end, hipStream_t st)
+static int wino43_gemm_launch_t(W43GemmArgs a, int begin, int end, int parts, hipStream_t st)
 {
-    a.item_begin = begin; a.item_end = end;
+    a.item_begin = begin; a.item_end = end; a.parts = parts > 0 ? parts : 4 / WM;
     const size_t lds = (size_t)2 * (WM * 64 * GBK * 4 + G_UB);
     auto kern = wino43_gemm_kernel<WM, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
-    const int n = (end - begin) * (4 / WM);
+    const int n = (end - begin) * a.parts;
     hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
     return rn_check_launch("wino43_gemm");
 }
 
 template <int WM>
-static int wino43_gemm_launch(int tag, const W43GemmArgs& a, int begin, int end, hipStream_t st)
+static int wino43_gemm_launch_w(int tag, const W43GemmArgs& a, int begin, int end, int parts, hipStream_t st)
 {
-    return tag == 0 ? wino43_gemm_launch_t<WM, 0>(a, begin, end, st) : tag == 1 ? wino43_gemm_launch_t<WM, 1>(a, begin, end, st)
-                                                                                  : wino43_gemm_launch_t<WM, 2>(a, begin, end, st);
+    switch (tag) {
+    case 0: return wino43_gemm_launch_t<WM, 0>(a, begin, end, parts, st);
+    case 1: return wino43_gemm_launch_t<WM, 1>(a, begin, end, parts, st);
+    case 2: return wino43_gemm_launch_t<WM, 2>(a, begin, end, parts, st);
+    case 3: return wino43_gemm_launch_t<WM, 3>(a, begin, end, parts, st);
+    default: return wino43_gemm_launch_t<WM, 4>(a, begin, end, parts, st);
+    }
+}
+
+static int wino43_gemm_launch(int wm, int tag, const W43GemmArgs& a, int begin, int end, int parts, hipStream_t st)
+{
+    return wm == 4 ? wino43_gemm_launch_w<4>(tag, a, begin, end, parts, st)
+         : wm == 2 ? wino43_gemm_launch_w<2>(tag, a, begin, end, parts, st) : wino43_gemm_launch_w<1>(tag, a, begin, end, parts, st);
 }
 
 int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st)
@@ -463,47 +487,71 @@ int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, lo
         return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm: a transform plane must stay below the 2 GiB buffer window");
     W43GemmArgs a;
     a.V = V; a.U = u; a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
-    a.mblocks = (int)((T + GBM - 1) / GBM); a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
-    const int nitems = rn_wino_scheme_nxi(scheme) * a.mblocks * a.nblocks;
+    a.nblocks = Cout / GBN; a.ksteps = Cin / GBK;
+    const int nxi = rn_wino_scheme_nxi(scheme);
+    const int full = (int)(T / GBM), ragged = (int)(T % GBM);          // whole 256-row blocks; rows of the last, partial one
     a.v_bytes = (unsigned)(T * Cin * 4); a.u_bytes = (unsigned)((size_t)Cin * GBN * 4); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO43_PROBE") ? atoi(getenv("RN_WINO43_PROBE")) : 0; a.probe = probe; }
     // one workgroup per CU takes items id, id + 256, ...: the items of a last, partial round run as half items (128 rows:
     // rounds of half the length) or quarter items (64 rows) when that fills the machine better -- rem = 128: 256 half items =
     // half a round; rem = 176: 704 quarter items = 3 quarter rounds instead of a whole one
     static const bool notail = getenv("RN_WINO43_NOTAIL") != nullptr;
-    const int tag = scheme == RN_WINO_F44 ? 2 : Cin >= 1024 ? 0 : 1;
-    const int rem = nitems % 256;
-    int tail_wm = 4;
-    if (!notail && rem != 0) {
-        const int half = (2 * rem + 255) / 256 * 2, quarter = (4 * rem + 255) / 256;       // cost in quarter rounds (whole: 4)
-        if (half < 4) tail_wm = 2;
-        if (quarter < (tail_wm == 2 ? half : 4)) tail_wm = 1;
+    const int tag = scheme == RN_WINO_F44 ? 2 : scheme == RN_WINO_F63 ? (Cin >= 1024 ? 3 : 4) : Cin >= 1024 ? 0 : 1;
+    if (full > 0) {
+        a.mb_begin = 0; a.mblocks = full;
+        const int nitems = nxi * full * a.nblocks;
+        const int rem = nitems % 256;
+        int tail_wm = 4;
+        if (!notail && rem != 0) {
+            const int half = (2 * rem + 255) / 256 * 2, quarter = (4 * rem + 255) / 256;       // cost in quarter rounds (whole: 4)
+            if (half < 4) tail_wm = 2;
+            if (quarter < (tail_wm == 2 ? half : 4)) tail_wm = 1;
+        }
+        const int tail = tail_wm == 4 ? 0 : rem;
+        if (nitems - tail > 0) {
+            const int rc = wino43_gemm_launch(4, tag, a, 0, nitems - tail, 0, st);
+            if (rc != RN_OK) return rc;
+        }
+        if (tail > 0) {
+            const int rc = wino43_gemm_launch(tail_wm, tag, a, nitems - tail, nitems, 0, st);
+            if (rc != RN_OK) return rc;
+        }
     }
-    const int tail = tail_wm == 4 ? 0 : rem;
-    if (nitems - tail > 0) {
-        const int rc = wino43_gemm_launch<4>(tag, a, 0, nitems - tail, st);
-        if (rc != RN_OK) return rc;
+    if (ragged > 0) {
+        // the last block's rows (T = 2904 tiles of the F63 res2 maps: 88) as the cheapest of whole / half / quarter items that
+        // cover them: 256 (xi, n-block) pairs x one 128-row part = half a round instead of a whole one
+        a.mb_begin = full; a.mblocks = 1;
+        const int nitems = nxi * a.nblocks;
+        int best_wm = 4, best_parts = 1, best_cost = (nitems + 255) / 256 * 4;
+        for (int wm = 2; wm >= 1 && !notail; --wm) {
+            const int parts = (ragged + wm * 64 - 1) / (wm * 64);
+            const int cost = (nitems * parts + 255) / 256 * wm;
+            if (cost < best_cost) { best_wm = wm; best_parts = parts; best_cost = cost; }
+        }
+        return wino43_gemm_launch(best_wm, tag, a, 0, nitems, best_parts, st);
     }
-    if (tail > 0) return tail_wm == 2 ? wino43_gemm_launch<2>(tag, a, nitems - tail, nitems, st) : wino43_gemm_launch<1>(tag, a, nitems - tail, nitems, st);
     return RN_OK;
 }
 
 int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
                           float* preact, int B, int H, int W, int C, int act, hipStream_t st)
 {
-    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const int m = rn_wino_scheme_m(scheme);
+    if (m == 0) return rn_set_error(RN_E_INVALID, "wino_output: unknown scheme %d", scheme);
+    const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
-    if (scheme == RN_WINO_F43) {
-        const unsigned long long n = ((unsigned long long)T * (C / 4) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    const int vw = scheme == RN_WINO_F43 ? 4 : 2;
+    const unsigned long long n = ((unsigned long long)T * (C / vw) + 255) / 256;
+    const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_output_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
                            H, W, C, th, tw, T, act, nblk8);
-    } else {
-        const unsigned long long n = ((unsigned long long)T * (C / 2) + 255) / 256;
-        const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
+    else if (scheme == RN_WINO_F44)
         hipLaunchKernelGGL((wino_output_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
                            H, W, C, th, tw, T, act, nblk8);
-    }
+    else
+        hipLaunchKernelGGL((wino_output_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                           H, W, C, th, tw, T, act, nblk8);
     return rn_check_launch("wino_output");
 }
 
@@ -516,7 +564,9 @@ long long rn_wino43_plane_limit()
 
 size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout)
 {
-    const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    const int m = rn_wino_scheme_m(scheme);
+    if (m == 0) return 0;
+    const size_t T = (size_t)B * ((H + m - 1) / m) * ((W + m - 1) / m);
     return (size_t)rn_wino_scheme_nxi(scheme) * T * ((size_t)Cin + Cout);
 }
 
@@ -526,7 +576,8 @@ int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const floa
                           float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st)
 {
     if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino43: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
-    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const int m = rn_wino_scheme_m(scheme);
+    const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
     // every xi plane must fit a buffer resource (2 GiB); RN_WINO43_MAX_PLANE lowers the limit so that tests can reach the

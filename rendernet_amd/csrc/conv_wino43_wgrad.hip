@@ -307,7 +307,7 @@ void wino43_wgrad_gemm_kernel(const W43WgradArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 bool rn_wino43_wgrad_supported(int scheme, int Cin, int Cout)
 {
-    if (rn_wino_scheme_nxi(scheme) == 0 || !rn_wino43_supported(scheme, 256, 256)) return false;
+    if ((scheme != RN_WINO_F43 && scheme != RN_WINO_F44) || !rn_wino43_supported(scheme, 256, 256)) return false;   // 4x4-output schemes only
     static const bool off = getenv("RN_NO_WINOGRAD43_WGRAD") != nullptr || getenv("RN_NO_WINOGRAD43") != nullptr ||
                             getenv("RN_NO_WINOGRAD") != nullptr;
     return !off && Cin >= 256 && Cin % 256 == 0 && Cout >= 256 && Cout % 256 == 0;

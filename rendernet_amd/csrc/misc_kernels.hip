@@ -130,8 +130,16 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w_tf, float* __restr
     }
 }
 
-static bool is_wino43_kind(int kind) { return kind == RN_PACK_CONV_WINO43 || kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44; }
-static int wino43_scheme(int kind) { return (kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44) ? RN_WINO_F44 : RN_WINO_F43; }
+static bool is_wino43_kind(int kind)
+{
+    return kind == RN_PACK_CONV_WINO43 || kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44 ||
+           kind == RN_PACK_CONV_WINO63 || kind == RN_PACK_CONVT_S1_WINO63;
+}
+static int wino43_scheme(int kind)
+{
+    return (kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44) ? RN_WINO_F44
+         : (kind == RN_PACK_CONV_WINO63 || kind == RN_PACK_CONVT_S1_WINO63) ? RN_WINO_F63 : RN_WINO_F43;
+}
 static bool is_wino_kind(int kind) { return kind == RN_PACK_CONV_WINO || kind == RN_PACK_CONVT_S1_WINO; }
 static bool is_wino4_kind(int kind) { return kind == RN_PACK_CONV_WINO4 || kind == RN_PACK_CONVT_S1_WINO4; }
 
@@ -150,7 +158,7 @@ static int wino43_pack_check(int kind, int ndim, const int* kdims, int Cin, int 
     if (!kdims || ndim != 2 || kdims[0] != r || kdims[1] != r)
         return rn_set_error(RN_E_UNSUPPORTED, "pack: this Winograd pack needs a 2-D %dx%d filter", r, r);
     if (Cin < 32 || Cin % 32 != 0 || Cout < 256 || Cout % 256 != 0)
-        return rn_set_error(RN_E_UNSUPPORTED, "pack: the F(4x4,RxR) Winograd packs need Cin %% 32 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
+        return rn_set_error(RN_E_UNSUPPORTED, "pack: the three-launch Winograd packs need Cin %% 32 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
     return RN_OK;
 }
 
@@ -222,7 +230,8 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
         if (rcw != RN_OK) return rcw;
         if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
         return rn_launch_wino_pack(wino43_scheme(kind), w_tf, w_packed, Cin, Cout,
-                                   (kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONVT_S1_WINO44) ? 1 : 0, (hipStream_t)stream);
+                                   (kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONVT_S1_WINO44 || kind == RN_PACK_CONVT_S1_WINO63) ? 1 : 0,
+                                   (hipStream_t)stream);
     }
     PackArgs a;
     int rc = pack_geometry(kind, ndim, kdims, Cin, Cout, a);

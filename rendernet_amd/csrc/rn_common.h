@@ -49,6 +49,7 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
 bool rn_wino43_supported(int scheme, int Cin, int Cout);                                                  // conv_wino43.hip
 int rn_wino_scheme_nxi(int scheme);
 int rn_wino_scheme_r(int scheme);
+int rn_wino_scheme_m(int scheme);                     // output pixels per tile side (4 | 4 | 6)
 long long rn_wino43_plane_limit();                    // 2 GiB, or RN_WINO43_MAX_PLANE (tests)
 size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout);
 int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Cout, int transposed, hipStream_t st);

@@ -51,8 +51,8 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None}
-        self._dirty = {"data": True, "wino": True, "wino4": True, "wino43": True}
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None}
+        self._dirty = {"data": True, "wino": True, "wino4": True, "wino43": True, "wino63": True}
         # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
         # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
         wkind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO}.get(kind)
@@ -71,6 +71,10 @@ class PackedWeight:
             self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO43, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO43}.get(kind)
         elif ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_wino44_supported(self.cin, self.cout):
             self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO44, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO44}.get(kind)
+        # ... and F(6x6,3x3) for the same 3x3 layers on maps where the 6-pixel tile grid pays (_wino_scheme picks per launch)
+        self._wino63_kind = None
+        if self._wino43_kind is not None and self.kdims == [3, 3] and lib.rn_conv2d_wino63_supported(self.cin, self.cout):
+            self._wino63_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO63, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO63}.get(kind)
 
     def _packed(self, which, kind):
         if self._dirty[which]:
@@ -110,7 +114,19 @@ class PackedWeight:
     def wino43(self, value):
         if value is not None:
             raise ValueError("the F(4x4,3x3) Winograd pack can only be switched off (set to None)")
-        self._wino43_kind = None
+        self._wino43_kind = None          # the three-launch path as a whole
+        self._wino63_kind = None
+
+    @property
+    def wino63(self):
+        """The Winograd F(6x6,3x3) pack (3x3 filters), or None."""
+        return None if self._wino63_kind is None else self._packed("wino63", self._wino63_kind)
+
+    @wino63.setter
+    def wino63(self, value):
+        if value is not None:
+            raise ValueError("the F(6x6,3x3) Winograd pack can only be switched off (set to None)")
+        self._wino63_kind = None
 
     @property
     def wino4(self):
@@ -343,24 +359,46 @@ def training(ctx):
 STAGE_HOOK = None      # bench.py: callable(stage, (T, Cin, Cout)) -> (start_event, end_event) | None, brackets the GEMM stage
 
 
+def _wino_scheme(pw, H, W):
+    """Which three-launch scheme a stride-1 launch of this filter on an H x W map takes: "f44" (4x4 filters), "f63" where
+    ceil(H/6)*ceil(W/6) tiles of 64 products undercut ceil(H/4)*ceil(W/4) tiles of 36 by at least WINO63_MIN_GAIN (64x64:
+    7744 against 9216; 32x32 and 16x16: equal, so the more accurate F(4x4,3x3) keeps them), else "f43"."""
+    if pw.kdims == [4, 4]:
+        return "f44"
+    if pw._wino63_kind is not None:
+        c63 = -(-H // 6) * -(-W // 6) * 64
+        c43 = -(-H // 4) * -(-W // 4) * 36
+        if c63 <= (1.0 - WINO63_MIN_GAIN) * c43:
+            return "f63"
+    return "f43"
+
+
+WINO63_MIN_GAIN = float(os.environ.get("RN_WINO63_MIN_GAIN", "0.08"))
+
+
 def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act):
-    """rn_conv2d_wino43_fwd / rn_conv2d_wino44_fwd with the workspace (V and M planes) from torch's caching allocator.
-    pw: the PackedWeight whose .wino43 form the launch reads (a stride-1 transposed-conv pack pads two pixels before)."""
+    """rn_conv2d_wino43_fwd / _wino63_fwd / _wino44_fwd with the workspace (V and M planes) from torch's caching allocator.
+    pw: the PackedWeight whose .wino43 / .wino63 form the launch reads (a stride-1 transposed 4x4 pack pads two pixels before)."""
     lib = L.lib()
-    u = pw.wino43
-    f44 = pw.kdims == [4, 4]
+    which = _wino_scheme(pw, H, W)
+    f44, f63 = which == "f44", which == "f63"
+    u = pw.wino63 if f63 else pw.wino43
     transposed = 1 if pw.kind == L.RN_PACK_CONVT_S1 else 0
-    n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
+    n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino63_workspace_floats if f63
+         else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
-    T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    ev = STAGE_HOOK("gemm", (T, Cin, Cout)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
+    m = 6 if f63 else 4
+    T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
+    ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
     if ev is None:
         if f44:
             return lib.rn_conv2d_wino44_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, transposed, act, L.stream_ptr())
+        if f63:
+            return lib.rn_conv2d_wino63_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
         return lib.rn_conv2d_wino43_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
     # the same three launches through the stage entry points, the GEMM bracketed by the caller's events
     st = L.stream_ptr()
-    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F43, 36)
+    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
     V, M = L.ptr(ws), ctypes.c_void_p(ws.data_ptr() + 4 * nxi * T * Cin)
     rc = lib.rn_winograd_input_transform(scheme, L.ptr(x), V, B, H, W, Cin, 2 if (f44 and transposed) else 1, st)
     if rc != 0:

@@ -325,6 +325,7 @@ def test_conv2d_winograd43(case):
     old, ops.WINO43_MIN_PIXELS = ops.WINO43_MIN_PIXELS, 1
     try:
         pw = ops.pack_conv(_dev(w))
+        pw.wino63 = None                                    # this test is about F(4x4,3x3): keep ops from picking F(6x6,3x3) on the larger maps
         assert pw.wino43 is not None
         want_u = _pack_wino43_numpy(w)
         assert np.abs(pw.wino43.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
@@ -363,6 +364,82 @@ def test_conv2d_winograd43(case):
             assert dp.wino43 is None
     finally:
         ops.WINO43_MIN_PIXELS = old
+
+
+# Winograd F(6x6,3x3) (same three launches on 8x8 tiles, 64 planes): planes that are not multiples of 6, and tile counts T that
+# walk every branch of the GEMM launcher -- no whole 256-row block (T = 1, 18, 100, 150, 242), whole blocks + a ragged last block
+# run as quarter (T = 363: 107 rows), half (T = 100 with 256 (xi, n-block) pairs) and whole items (T = 726: 214 rows), a main
+# launch that is itself a half-item tail (T = 363, Cout = 512), deep K (Cin = 1024).
+WINO63_CASES = [
+    (1, 6, 6, 32, 256),
+    (1, 1, 1, 32, 256),
+    (3, 33, 5, 96, 256),
+    (1, 13, 16, 1024, 512),
+    (5, 30, 34, 128, 1024),
+    (1, 60, 60, 64, 1024),
+    (2, 64, 64, 64, 256),
+    (3, 64, 64, 256, 512),
+    (6, 64, 64, 32, 1024),
+]
+
+
+@pytest.mark.parametrize("case", WINO63_CASES)
+def test_conv2d_winograd63(case):
+    """rn_conv2d_wino63_fwd vs the oracle conv (epilogue flavours, pre-activation), vs F(4x4,3x3) on the same filter, its packed
+    filter vs the NumPy statement, the input gradient through the transposed pack, and the routing rule of ops._wino_scheme."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (3, 3, Cin, Cout))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    lib = L.lib()
+    pw = ops.pack_conv(_dev(w))
+    assert pw.wino63 is not None
+    want_u = _pack_wino43_numpy(w, "F63")
+    assert np.abs(pw.wino63.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    c63, c43 = -(-H // 6) * -(-W // 6) * 64, -(-H // 4) * -(-W // 4) * 36
+    assert ops._wino_scheme(pw, H, W) == ("f63" if c63 <= (1.0 - ops.WINO63_MIN_GAIN) * c43 else "f43")
+    assert ops._wino_scheme(pw, 64, 64) == "f63" and ops._wino_scheme(pw, 32, 32) == "f43"
+    y0 = OL.conv2d(x, w, b, (1, 1))
+    res = _rand(rng, *y0.shape)
+
+    def run(xd, u, bias, al, rs, cin, cout, act, preact=False):
+        yy = torch.empty((B, H, W, cout), device="cuda")
+        zz = torch.empty((B, H, W, cout), device="cuda") if preact else None
+        ws = torch.empty(lib.rn_conv2d_wino63_workspace_floats(B, H, W, cin, cout), device="cuda")
+        L.check(lib.rn_conv2d_wino63_fwd(L.ptr(xd), L.ptr(u), L.ptr(bias) if bias is not None else None, L.ptr(al) if al is not None else None,
+                                         L.ptr(rs) if rs is not None else None, L.ptr(yy), L.ptr(zz) if preact else None, L.ptr(ws),
+                                         B, H, W, cin, cout, act, L.stream_ptr()), "rn_conv2d_wino63_fwd")
+        return yy, zz
+    xd, bd, ad, rd = _dev(x), _dev(b), _dev(alpha), _dev(res)
+    yy, zz = run(xd, pw.wino63, bd, ad, None, Cin, Cout, 1, preact=True)
+    _close(zz, y0, "wino63 preact")
+    _close(yy, OL.prelu(y0, alpha), "wino63 prelu")
+    got, _ = run(xd, pw.wino63, bd, ad, rd, Cin, Cout, 1)
+    _close(got, OL.prelu(y0, alpha) + torch.from_numpy(res), "wino63+prelu+res")
+    # A/B against F(4x4,3x3) on the same filter: the two differ by their fp32 rounding only
+    p2 = ops.pack_conv(_dev(w))
+    p2.wino63 = None
+    old, ops.WINO43_MIN_PIXELS = ops.WINO43_MIN_PIXELS, 1
+    try:
+        ref2 = ops.conv2d(xd, p2, bd, ad, rd)
+        if ops._wino_scheme(pw, H, W) == "f63":            # and through the dispatcher when it picks F(6x6,3x3) itself
+            assert torch.equal(ops.conv2d(xd, pw, bd, ad, rd), got)
+    finally:
+        ops.WINO43_MIN_PIXELS = old
+    assert float((got - ref2).abs().max()) <= 1e-4 * float(ref2.abs().max())
+    # input gradient through the transposed pack (channel roles swap: needs Cin % 256 == 0)
+    dp = pw.dgrad_pack(True)
+    if Cin % 256 == 0:
+        assert dp.wino63 is not None
+        dz = _dev(_rand(rng, B, H, W, Cout))
+        dx, _ = run(dz, dp.wino63, None, None, None, Cout, Cin, 0)
+        _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino63 dgrad vs oracle")
+    else:
+        assert dp.wino63 is None
 
 
 # Winograd F(4x4,4x4) for the wide 4x4 stride-1 layers (same three launches on 7x7 tiles): SAME conv (pad 1 before, 2

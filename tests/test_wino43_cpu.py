@@ -1,4 +1,4 @@
-"""CPU checks of the Winograd F(4x4,3x3) / F(4x4,4x4) path's host-side statements (no GPU):
+"""CPU checks of the Winograd F(4x4,3x3) / F(4x4,4x4) / F(6x6,3x3) path's host-side statements (no GPU):
 the generated matrices (scripts/gen_wino_mats.py -> rendernet_amd/csrc/wino_mats.h) satisfy the minimal-filtering identity
 exactly, the committed header is what the script prints, and a NumPy emulation of the three launches -- input transform,
 one GEMM per xi over the PACKED filter layout, output transform -- reproduces the oracle conv (forward, stride-1 transposed
@@ -26,7 +26,7 @@ def _mats(scheme):
     return m, r, f(AT), f(G), f(BT), (AT, G, BT)
 
 
-@pytest.mark.parametrize("scheme", ["F43", "F44"])
+@pytest.mark.parametrize("scheme", ["F43", "F44", "F63"])
 def test_identity_is_exact_in_rational_arithmetic(scheme):
     m, r, _, _, _, (AT, G, BT) = _mats(scheme)
     a = m + r - 1
@@ -59,14 +59,14 @@ def _pack(w, G, transposed=False):
 
 
 def _three_launches(x, packed, AT, BT, pad_lo, Cout):
-    """NumPy statement of conv_wino43.hip: V = B^T d B per 4x4-output tile, M[xi] = V[xi] . U[xi] read from the packed panels,
+    """NumPy statement of conv_wino43.hip: V = B^T d B per m x m-output tile (m = A^T's rows), M[xi] = V[xi] . U[xi] read from the packed panels,
     Y = A^T m A.  x [B,H,W,Cin] -> [B,H,W,Cout] (float64)."""
     B, H, W, Cin = x.shape
-    a = BT.shape[0]
-    th, tw = (H + 3) // 4, (W + 3) // 4
-    xp = np.zeros((B, 4 * th + a - 4 + 8, 4 * tw + a - 4 + 8, Cin))
+    a, m = BT.shape[0], AT.shape[0]
+    th, tw = (H + m - 1) // m, (W + m - 1) // m
+    xp = np.zeros((B, m * th + a - m + 8, m * tw + a - m + 8, Cin))
     xp[:, pad_lo:pad_lo + H, pad_lo:pad_lo + W] = x
-    tiles = np.stack([xp[b, 4 * ty:4 * ty + a, 4 * tx:4 * tx + a] for b in range(B) for ty in range(th) for tx in range(tw)])
+    tiles = np.stack([xp[b, m * ty:m * ty + a, m * tx:m * tx + a] for b in range(B) for ty in range(th) for tx in range(tw)])
     V = np.einsum("ia,tabc,jb->ijtc", BT, tiles, BT).reshape(a * a, -1, Cin)                 # [nxi][T][Cin]
     nxi, T = V.shape[0], V.shape[1]
     M = np.empty((nxi, T, Cout))
@@ -74,12 +74,12 @@ def _three_launches(x, packed, AT, BT, pad_lo, Cout):
         panel = packed[:, nb]                                                                  # [nxi][Cin/4][256][4]
         Ublk = panel.transpose(0, 1, 3, 2).reshape(nxi, Cin, 256)                              # k = 4*kg + r
         M[:, :, nb * 256:(nb + 1) * 256] = np.einsum("xtc,xcn->xtn", V, Ublk)
-    Y = np.einsum("pi,ijtn,qj->tpqn", AT, M.reshape(a, a, T, Cout), AT)                        # [T][4][4][Cout]
-    y = Y.reshape(B, th, tw, 4, 4, Cout).transpose(0, 1, 3, 2, 4, 5).reshape(B, 4 * th, 4 * tw, Cout)
+    Y = np.einsum("pi,ijtn,qj->tpqn", AT, M.reshape(a, a, T, Cout), AT)                        # [T][m][m][Cout]
+    y = Y.reshape(B, th, tw, m, m, Cout).transpose(0, 1, 3, 2, 4, 5).reshape(B, m * th, m * tw, Cout)
     return y[:, :H, :W]
 
 
-@pytest.mark.parametrize("scheme,shape", [("F43", (2, 9, 6, 8, 256)), ("F44", (1, 7, 10, 4, 256))])
+@pytest.mark.parametrize("scheme,shape", [("F43", (2, 9, 6, 8, 256)), ("F44", (1, 7, 10, 4, 256)), ("F63", (2, 13, 7, 8, 256))])
 def test_three_launch_emulation_matches_the_oracle_conv(scheme, shape):
     m, r, AT, G, BT, _ = _mats(scheme)
     B, H, W, Cin, Cout = shape
@@ -98,7 +98,7 @@ def test_three_launch_emulation_matches_the_oracle_conv(scheme, shape):
         assert np.abs(got_t - want_t).max() <= 2e-5 * np.abs(want_t).max()
 
 
-@pytest.mark.parametrize("scheme", ["F43", "F44"])
+@pytest.mark.parametrize("scheme", ["F43", "F44", "F63"])
 def test_wgrad_identity_matches_autograd(scheme):
     """dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G  (conv_wino43_wgrad.hip) vs torch autograd over the oracle conv."""
     m, r, AT, G, BT, _ = _mats(scheme)
@@ -109,15 +109,15 @@ def test_wgrad_identity_matches_autograd(scheme):
     wt = torch.zeros(r, r, Cin, Cout, requires_grad=True)
     OL.conv2d(torch.from_numpy(x), wt).backward(torch.from_numpy(dz))
     a = BT.shape[0]
-    th, tw = (H + 3) // 4, (W + 3) // 4
-    xp = np.zeros((B, 4 * th + a, 4 * tw + a, Cin)); xp[:, 1:1 + H, 1:1 + W] = x
-    zp = np.zeros((B, 4 * th, 4 * tw, Cout)); zp[:, :H, :W] = dz
+    th, tw = (H + m - 1) // m, (W + m - 1) // m
+    xp = np.zeros((B, m * th + a, m * tw + a, Cin)); xp[:, 1:1 + H, 1:1 + W] = x
+    zp = np.zeros((B, m * th, m * tw, Cout)); zp[:, :H, :W] = dz
     dU = np.zeros((a, a, Cin, Cout))
     for b in range(B):
         for ty in range(th):
             for tx in range(tw):
-                V = np.einsum("ia,abc,jb->ijc", BT, xp[b, 4 * ty:4 * ty + a, 4 * tx:4 * tx + a], BT)
-                dM = np.einsum("pi,pqn,qj->ijn", AT, zp[b, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4], AT)
+                V = np.einsum("ia,abc,jb->ijc", BT, xp[b, m * ty:m * ty + a, m * tx:m * tx + a], BT)
+                dM = np.einsum("pi,pqn,qj->ijn", AT, zp[b, m * ty:m * ty + m, m * tx:m * tx + m], AT)
                 dU += V[:, :, :, None] * dM[:, :, None, :]
     dw = np.einsum("ia,ijcn,jb->abcn", G, dU, G)
     want = wt.grad.numpy()
