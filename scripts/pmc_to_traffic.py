@@ -16,10 +16,13 @@ csv.field_size_limit(1 << 30)
 
 KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s), algorithmic bytes per launch at B=24)
     # the GEMM stage runs as two launches: full rounds with 256-row blocks (<4, .>) and the last partial round as 128-row blocks (<2, .>)
+    # F(6x6,3x3): T = 24 * 11 * 11 = 2904 tiles, 64 planes; 11 whole rounds of 256-row blocks (<4, 3>) + the ragged last block as 128-row items (<2, 3>)
+    "wino63_gemm_res2": ("wino63", ["wino43_gemm_kernel<4, 3>", "wino43_gemm_kernel<2, 3>"], 64 * 2904 * (1024 + 1024) * 4 + 64 * 1024 * 1024 * 4),
+    "wino63_input_res2": ("wino63", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 4),
+    "wino63_output_res2": ("wino63", ["wino_output_kernel"], 64 * 2904 * 1024 * 4 + 24 * 64 * 64 * 1024 * 4),
     "wino43_gemm_res2": ("wino43", ["wino43_gemm_kernel<4, 0>", "wino43_gemm_kernel<2, 0>"], 36 * 6144 * (1024 + 1024) * 4 + 36 * 1024 * 1024 * 4),
     "wino43_input_res2": ("wino43", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 36 * 6144 * 1024 * 4),
     "wino43_output_res2": ("wino43", ["wino_output_kernel"], 36 * 6144 * 1024 * 4 + 2 * 24 * 64 * 64 * 1024 * 4),
-    "conv_wino_res2": ("wino", ["conv_wino_kernel"], 24 * 64 * 64 * 1024 * 4 * 2 + 16 * 1024 * 1024 * 4),
     "conv3d_drun_res1": ("res1", ["conv3d_k3_drun"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 27 * 32 * 32 * 4),
     "conv_wino_res1": ("res1w", ["conv_wino_kernel"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 16 * 3 * 32 * 32 * 4),
     "resampler": ("resample", ["resample_prepare", "resample_classify", "resample_main"], 24 * 9437184),

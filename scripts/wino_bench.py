@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--shapes", type=str, default="64x1024,64x512")
     ap.add_argument("--wino-only", action="store_true")
-    ap.add_argument("--only", choices=["f43", "f23", "direct"], default=None, help="time just one implementation")
+    ap.add_argument("--only", choices=["f63", "f43", "f23", "direct"], default=None, help="time just one implementation")
     args = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
     for sh in args.shapes.split(","):
@@ -36,6 +36,21 @@ def main():
             pw.wino43 = None
         if args.only == "direct":
             pw.wino = None
+        if args.only == "f43":
+            pw.wino63 = None
+        if pw._wino63_kind is not None and ops._wino_scheme(pw, hw, hw) == "f63":
+            ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
+            y63 = ops.conv2d(x, pw, b, al)
+            T = B * (-(-hw // 6)) ** 2
+            print("%s B=%d  F(6x6,3x3) %8.3f ms  %7.2f TFLOP/s direct-equivalent, %7.2f TFLOP/s executed (GEMM stage FLOPs / whole time)"
+                  % (sh, B, ms, flop / ms / 1e9, 2.0 * 64 * T * c * c / ms / 1e9), flush=True)
+            if args.only == "f63":
+                continue
+            pw.wino63 = None
+            y43 = ops.conv2d(x, pw, b, al)
+            print("   max|F63-F43| = %.3g (max|y| %.3g)" % (float((y63 - y43).abs().max()), float(y43.abs().max())), flush=True)
+        elif args.only == "f63":
+            continue
         if pw.wino43 is not None:
             ms = timeit(lambda: ops.conv2d(x, pw, b, al), args.iters)
             y43 = ops.conv2d(x, pw, b, al)
