@@ -67,6 +67,7 @@ LAYER_CASES = [
     ("conv3d", 1, (6, 6, 32), 32, 32, 3, (1, 1, 1), False, False),     # depth-run wgrad: one full 32-deep chunk per column
     ("conv2d", 2, (16, 16), 256, 256, 3, (1, 1), True, False),         # res2-like: 128x128 wgrad tiles
     ("conv2d", 1, (9, 11), 128, 64, 3, (1, 1), False, True),           # ragged, 128x128 tile with channel tail
+    ("conv2d", 1, (64, 60), 256, 256, 3, (1, 1), True, True),          # full-size map: F(6x6,3x3) forward + input gradient, F(4x4,3x3) filter gradient
     ("conv2d", 2, (8, 8), 256, 128, 4, (1, 1), True, False),           # e_conv5-like 4x4 (pad 1,2)
     ("conv2d", 2, (6, 6), 64, 64, 1, (1, 1), True, False),             # projection-like 1x1
     ("conv2d", 1, (8, 8), 32, 128, 3, (1, 1), False, False),           # 32x128 wgrad tile
