@@ -472,13 +472,21 @@ def test_conv2d_winograd43_batch_chunks(monkeypatch):
         ws = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, Cout), device="cuda")
         L.check(lib.rn_conv2d_wino43_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(ws), B, H, W, Cin, Cout, L.stream_ptr()), "wgrad")
         return dw
+    def f63():                                                    # the F(6x6,3x3) entry: 2 x 2 tiles per image, chunks of 3, 3, 1
+        y = torch.empty((B, H, W, Cout), device="cuda")
+        ws = torch.empty(lib.rn_conv2d_wino63_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+        L.check(lib.rn_conv2d_wino63_fwd(L.ptr(x), L.ptr(pw.wino63), None, None, None, L.ptr(y), None, L.ptr(ws), B, H, W, Cin, Cout, 0,
+                                         L.stream_ptr()), "rn_conv2d_wino63_fwd")
+        return y
     try:
         pw = ops.pack_conv(w)
-        whole, dw_whole = ops.conv2d(x, pw), wgrad()
+        whole, dw_whole, whole63 = ops.conv2d(x, pw), wgrad(), f63()
         plane = 2 * 3 * 256 * 4                                   # tiles per image * channels * 4 B
         monkeypatch.setenv("RN_WINO43_MAX_PLANE", str(2 * plane + plane // 2))      # two images fit, three do not
-        chunked, dw_chunked = ops.conv2d(x, pw), wgrad()
+        chunked, dw_chunked, chunked63 = ops.conv2d(x, pw), wgrad(), f63()
         assert torch.equal(whole, chunked)
+        assert torch.equal(whole63, chunked63)
+        assert float((whole63 - whole).abs().max()) <= 1e-4 * float(whole.abs().max())
         assert float((dw_whole - dw_chunked).abs().max()) <= 1e-5 * float(dw_whole.abs().max())
     finally:
         ops.WINO43_MIN_PIXELS = old
