@@ -75,7 +75,7 @@ def train(cfg, argv):
     max_steps = int(argv[argv.index("--max-steps") + 1]) if "--max-steps" in argv else None
     ckpt_secs = float(cfg.get('checkpoint_secs', 7200))
     last_ckpt = time.time()
-    l1_all = []
+    l1_all = [float(v) for v in np.ravel(tr.checkpoint_extra.get("l1_all", []))]     # the validation history survives a restart
     for epoch in range(first_epoch, int(cfg['max_epochs'])):
         patch = new_res // 4 if epoch < 5 else new_res // 2                           # :204-207
         for images, models, params, names in data_loader(cfg, img_path=cfg['image_path'], model_path=cfg['model_path'],
@@ -94,7 +94,7 @@ def train(cfg, argv):
                 if rank == 0:
                     print("Step {0} Loss {1}".format(step, float(loss.item())))
                 if rank == 0 and time.time() - last_ckpt >= ckpt_secs:                  # Supervisor(save_model_secs=checkpoint_secs)
-                    tr.save_checkpoint(wpath, epoch)
+                    tr.save_checkpoint(wpath, epoch, {"l1_all": l1_all})
                     last_ckpt = time.time()
                 if step % 600 == 0 and rank == 0:                                       # :242-253
                     with torch.no_grad():
@@ -109,7 +109,7 @@ def train(cfg, argv):
             if max_steps is not None and tr.global_step >= max_steps:
                 break
         if rank == 0:
-            tr.save_checkpoint(wpath, epoch + 1)                                        # :257 sess_saver.save (atomic)
+            tr.save_checkpoint(wpath, epoch + 1, {"l1_all": l1_all})                                        # :257 sess_saver.save (atomic)
             last_ckpt = time.time()
         # validation (:258-301): full-resolution render with is_training False (dropout off), mean absolute error; on
         # rank 0 while the other ranks wait at the barrier below (a generous timeout: torch's default is 10 min for nccl)

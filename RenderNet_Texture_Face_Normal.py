@@ -75,7 +75,7 @@ def train(cfg, argv):
     max_steps = int(argv[argv.index("--max-steps") + 1]) if "--max-steps" in argv else None
     ckpt_secs = float(cfg.get('checkpoint_secs', 7200))
     last_ckpt = time.time()
-    l1_all = []
+    l1_all = [float(v) for v in np.ravel(tr.checkpoint_extra.get("l1_all", []))]     # the validation history survives a restart
     lo, hi = shard_range(bs, rank, world)
     for epoch in range(first_epoch, int(cfg['max_epochs'])):
         patch = new_res // 4 if epoch < 4 else new_res // 2                            # :226-229
@@ -105,14 +105,14 @@ def train(cfg, argv):
                     _save_png(os.path.join(sample_save, "{0}_train_{1}_patch.png".format(nm, step)), img[i].cpu().numpy())
                     _save_png(os.path.join(sample_save, "{0}_train_{1}_patch_normal.png".format(nm, step)), nrm[i].cpu().numpy())
                 if rank == 0 and time.time() - last_ckpt >= ckpt_secs:                  # Supervisor(save_model_secs=checkpoint_secs)
-                    tr.save_checkpoint(wpath, epoch)
+                    tr.save_checkpoint(wpath, epoch, {"l1_all": l1_all})
                     last_ckpt = time.time()
                 if max_steps is not None and step >= max_steps:
                     break
             if max_steps is not None and tr.global_step >= max_steps:
                 break
         if rank == 0:
-            tr.save_checkpoint(wpath, epoch + 1)                                        # :285 sess_saver.save
+            tr.save_checkpoint(wpath, epoch + 1, {"l1_all": l1_all})                                        # :285 sess_saver.save
             last_ckpt = time.time()
         # validation (:287-331), on rank 0 while the others wait at the barrier below
         if rank == 0 and cfg.get('image_path_valid') and os.path.exists(cfg['image_path_valid']):

@@ -402,7 +402,8 @@ int rn_resample_affine_bwd_strided(const float* vox, const float* m_inv, const f
  * with tools/layer_util.py:124-131; README default keep_prob 0.75 for training).  The uniforms come from a counter-based
  * generator: element e uses word e%4 of Philox4x32-10(counter = (e/4, stream_id), key = seed), u = (word >> 8) * 2^-24.
  * No mask is stored: calling it again with the same (seed, stream_id) on the output gradient IS the backward pass.
- * y may alias x.  keep_prob in (0, 1]; pointers 16-byte aligned. */
+ * y may alias x.  keep_prob in (0, 1].  Any float-aligned pointers (16-byte aligned ones take the vector path); n = 0 is a
+ * no-op.  The mask of element e is the same whatever the alignment. */
 int rn_dropout(const float* x, float* y, size_t n, float keep_prob, unsigned long long seed,
                unsigned long long stream_id, void* stream);
 

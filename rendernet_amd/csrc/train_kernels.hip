@@ -306,6 +306,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
     return c;
 }
 
+// keep = floor(keep_prob + u) as TF writes it, clamped to {0, 1}: for fp32 keep_prob < 1 and u a multiple of 2^-24 below 1 the
+// sum cannot round up to 2 (it is at most 2 - 2^-23, which is representable), the clamp makes that independent of the argument.
+__device__ __forceinline__ float dropout_keep(float keep_prob, unsigned word)
+{
+    return fminf(floorf(keep_prob + (float)(word >> 8) * 5.9604644775390625e-08f), 1.0f);
+}
+
+// VEC: x and y are 16-byte aligned (whole float4 groups by vector loads/stores); otherwise every element goes through scalar
+// accesses (an offset view of a larger gradient buffer).  The mask is the same function of the ELEMENT index either way.
+template <bool VEC>
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float keep_prob, float inv_keep,
                                unsigned long long seed, unsigned long long stream)
 {
@@ -314,15 +324,15 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
         const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)(q >> 32), (unsigned)stream, (unsigned)(stream >> 32)),
                                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
         const unsigned w[4] = {r.x, r.y, r.z, r.w};
-        if (q * 4 + 3 < n) {
+        if (VEC && q * 4 + 3 < n) {
             float4 v = *reinterpret_cast<const float4*>(x + q * 4);
             float* e = reinterpret_cast<float*>(&v);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = e[i] * inv_keep * floorf(keep_prob + (float)(w[i] >> 8) * 5.9604644775390625e-08f);
+            for (int i = 0; i < 4; ++i) e[i] = e[i] * inv_keep * dropout_keep(keep_prob, w[i]);
             *reinterpret_cast<float4*>(y + q * 4) = v;
         } else {
             for (int i = 0; i < 4 && q * 4 + i < n; ++i)
-                y[q * 4 + i] = x[q * 4 + i] * inv_keep * floorf(keep_prob + (float)(w[i] >> 8) * 5.9604644775390625e-08f);
+                y[q * 4 + i] = x[q * 4 + i] * inv_keep * dropout_keep(keep_prob, w[i]);
         }
     }
 }
@@ -330,13 +340,19 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 extern "C" int rn_dropout(const float* x, float* y, size_t n, float keep_prob, unsigned long long seed,
                           unsigned long long stream_id, void* stream)
 {
-    if (!x || !y || n < 1) return rn_set_error(RN_E_INVALID, "rn_dropout: bad arguments");
+    if (n == 0) return RN_OK;                                   // an empty tensor: nothing to do
+    if (!x || !y) return rn_set_error(RN_E_INVALID, "rn_dropout: null pointer");
     if (!(keep_prob > 0.f) || keep_prob > 1.f) return rn_set_error(RN_E_INVALID, "rn_dropout: keep_prob %g not in (0, 1]", keep_prob);
-    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return rn_set_error(RN_E_INVALID, "rn_dropout: pointers must be 16-byte aligned");
+    if ((((uintptr_t)x | (uintptr_t)y) & 3) != 0) return rn_set_error(RN_E_INVALID, "rn_dropout: pointers must be float-aligned");
+    const bool vec = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     size_t nb = ((n + 3) / 4 + 255) / 256;
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob, 1.0f / keep_prob,
-                       seed, stream_id);
+    if (vec)
+        hipLaunchKernelGGL(dropout_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob,
+                           1.0f / keep_prob, seed, stream_id);
+    else
+        hipLaunchKernelGGL(dropout_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob,
+                           1.0f / keep_prob, seed, stream_id);
     return rn_check_launch("rn_dropout");
 }
 

@@ -287,6 +287,19 @@ class Renderer:
         finally:
             V._default = old
 
+    def validate_winograd(self, voxels, poses, tol=2e-4):
+        """One render with the F(6x6,3x3) self-check on (ops.WINO63_CHECK_TOL): every filter that takes that route is also run
+        through F(4x4,3x3) on the activations this input produces, and demoted if the two differ by more than tol * max|y|.
+        Call it once after loading weights of unknown provenance, on a representative input; returns the demotions."""
+        from . import ops
+        old, ops.WINO63_CHECK_TOL = ops.WINO63_CHECK_TOL, float(tol)
+        n0 = len(ops.WINO63_DEMOTED)
+        try:
+            self.render(voxels, poses)
+        finally:
+            ops.WINO63_CHECK_TOL = old
+        return ops.WINO63_DEMOTED[n0:]
+
     # -- hipGraph replay for small batches ----------------------------------------------------
     def capture(self, batch, in_ch=1):
         """Capture one inference render of `batch` frames into a hipGraph (torch.cuda.CUDAGraph over the HIP stream

@@ -131,7 +131,13 @@ class _TrainerBase:
         self.e_eta, self.decay_steps = float(e_eta), int(decay_steps)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
         self.keep_prob = float(keep_prob)
+        # dropout masks are a pure function of (seed, rank, global step, position of the dropout site): ranks of a
+        # data-parallel job draw different masks for their shards (tf.nn.dropout draws per sample), every step draws new
+        # ones, and a resumed run (global_step comes back from the checkpoint) continues the sequence instead of replaying it
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dropout_seed = ops.mix_seed(seed, self.rank)
         self.global_step = 0
+        self.checkpoint_extra = {}        # what load_checkpoint found beside the weights and the optimiser state
         self.loss_buf = torch.zeros(1, dtype=torch.float64, device=self.device)
 
     def _loss_grad(self, pred, target, global_batch, mse):
@@ -151,6 +157,12 @@ class _TrainerBase:
         L.check(L.lib().rn_adam_step(L.ptr(self.param), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.param.numel(),
                                      lr_t, self.beta1, self.beta2, self.epsilon, 1.0, L.stream_ptr()), "rn_adam_step")
         self.store.repack_all()
+
+    def _seed_dropout(self):
+        """Called at the start of every forward through the trainer's graph: stream ids (global_step << 16) + k for the k-th
+        dropout site, so an extra forward between two steps (the sample render every 600 steps) re-draws the masks of the
+        coming step instead of shifting every later one."""
+        ops.seed_dropout(self.dropout_seed, self.global_step << 16)
 
     def _begin_step(self):
         self.grad.zero_()
@@ -172,36 +184,73 @@ class _TrainerBase:
     # The reference's tf.train.Supervisor saves the whole graph state -- variables, the Adam slots `m` / `v` and
     # global_step (RenderNet_Shader.py:171-185, save_model_secs = checkpoint_secs) -- and restores it on restart, so the
     # learning-rate staircase, Adam's bias correction and the patch-size schedule continue where they stopped.
-    def checkpoint(self, epoch=0):
+    def checkpoint(self, epoch=0, extra=None):
         """Everything a restart needs: weights + '__adam_m__' / '__adam_v__' (the flat moment buffers, layout = creation
-        order of the variables, each 16-byte aligned) + '__global_step__' + '__epoch__'."""
+        order of the variables, each 16-byte aligned) + '__global_step__' + '__epoch__', plus `extra` ({name: array}, stored
+        as '__name__': the training scripts keep their validation history 'l1_all' there).  A checkpoint written in the
+        middle of an epoch resumes at the START of that epoch (the tar stream's position is not part of the state) with the
+        advanced global_step: the first batches of the epoch are seen again -- the reference restarts its epoch loop from 0
+        after a Supervisor restore (RenderNet_Shader.py:193-202), so this replays less than it does."""
         sd = self.store.state_dict()
+        for k, v in (extra or {}).items():
+            sd["__%s__" % k] = np.asarray(v)
         sd["__adam_m__"] = self.m.cpu().numpy()
         sd["__adam_v__"] = self.v.cpu().numpy()
         sd["__global_step__"] = np.int64(self.global_step)
         sd["__epoch__"] = np.int64(epoch)
         return sd
 
-    def save_checkpoint(self, path, epoch=0):
+    def save_checkpoint(self, path, epoch=0, extra=None):
         """Atomic: written next to `path` and renamed over it, so a kill mid-write leaves the previous file intact."""
         import os
         tmp = path + ".tmp.npz"
-        np.savez(tmp, **self.checkpoint(epoch))
+        np.savez(tmp, **self.checkpoint(epoch, extra))
         os.replace(tmp, path)
 
-    def load_checkpoint(self, sd):
-        """Restore weights and, when present, the optimiser state; returns the epoch to resume at."""
-        extra = {k: sd[k] for k in ("__adam_m__", "__adam_v__", "__global_step__", "__epoch__") if k in sd}
+    def load_checkpoint(self, sd, strict=True):
+        """Restore weights and the optimiser state; returns the epoch to resume at.  Everything is validated BEFORE anything
+        is overwritten: a variable missing from `sd` or of another shape, moment buffers of another length, or only part of
+        (m, v, global_step) present raise ValueError and leave the trainer untouched.  A weights-only file (no optimiser
+        state at all, e.g. the per-epoch inference save) is accepted: moments and global_step restart from zero and so
+        does the epoch -- the patch-size schedule must not resume late while the learning-rate schedule restarts.
+        strict=False downgrades missing variables to a warning (they keep their current values)."""
+        import warnings
+        missing = [n for n in self.names if n not in sd]
+        if missing:
+            msg = "checkpoint lacks %d of %d variables (first: %s)" % (len(missing), len(self.names), missing[0])
+            if strict:
+                raise ValueError(msg)
+            warnings.warn(msg)
+        for n in self.names:
+            if n in sd and int(np.asarray(sd[n]).size) != self.store.vars[n].numel():
+                raise ValueError("checkpoint variable %s has %d elements, the net's has %d"
+                                 % (n, np.asarray(sd[n]).size, self.store.vars[n].numel()))
+        opt_keys = ("__adam_m__", "__adam_v__", "__global_step__")
+        have = [k for k in opt_keys if k in sd]
+        if have and len(have) != len(opt_keys):
+            raise ValueError("checkpoint holds only part of the optimiser state (%s of %s)" % (have, list(opt_keys)))
+        if have:
+            for k in ("__adam_m__", "__adam_v__"):
+                if int(np.asarray(sd[k]).size) != self.m.numel():
+                    raise ValueError("checkpoint %s has %d floats, this net's flat buffer has %d (another spec?)"
+                                     % (k, np.asarray(sd[k]).size, self.m.numel()))
         with torch.no_grad():
             for n in self.names:
                 if n in sd:
                     self.store.vars[n].copy_(torch.as_tensor(np.asarray(sd[n], np.float32)).reshape(self.store.vars[n].shape))
-            if "__adam_m__" in extra and extra["__adam_m__"].size == self.m.numel():
-                self.m.copy_(torch.as_tensor(np.asarray(extra["__adam_m__"], np.float32)))
-                self.v.copy_(torch.as_tensor(np.asarray(extra["__adam_v__"], np.float32)))
-                self.global_step = int(extra.get("__global_step__", 0))
+            if have:
+                self.m.copy_(torch.as_tensor(np.asarray(sd["__adam_m__"], np.float32)))
+                self.v.copy_(torch.as_tensor(np.asarray(sd["__adam_v__"], np.float32)))
+                self.global_step = int(sd["__global_step__"])
+            else:
+                self.m.zero_()
+                self.v.zero_()
+                self.global_step = 0
         self.store.repack_all()
-        return int(extra.get("__epoch__", 0))
+        known = set(opt_keys) | {"__epoch__"}
+        self.checkpoint_extra = {k[2:-2]: np.asarray(sd[k]) for k in sd if str(k).startswith("__") and str(k).endswith("__")
+                                 and k not in known}
+        return int(sd["__epoch__"]) if (have and "__epoch__" in sd) else 0
 
 
 class Trainer(_TrainerBase):
@@ -231,6 +280,7 @@ class Trainer(_TrainerBase):
         window = (int(start_point[0]), int(start_point[1]), p, p)
         old = V._default
         V.set_default_store(self.store)
+        self._seed_dropout()
         try:
             with ops.training(self.ctx):
                 if net_in is None:
@@ -284,6 +334,7 @@ class TextureTrainer(_TrainerBase):
         window = (int(start_point[0]), int(start_point[1]), p, p)
         old = V._default
         V.set_default_store(self.store)
+        self._seed_dropout()
         try:
             with ops.training(self.ctx):
                 tex_vol = decoder_texture(tex, s, taps)

@@ -94,8 +94,13 @@ class VariableStore:
         return {k: v.detach().cpu().numpy() for k, v in self.vars.items()}
 
     def load_state_dict(self, sd):
+        """Keys starting with "__" are not variables (a training checkpoint also holds '__adam_m__', '__adam_v__',
+        '__global_step__', '__epoch__' ... -- rendernet_amd/train.py): they are skipped, so the same .npz serves the
+        inference entry points without uploading two parameter-sized moment buffers as if they were weights."""
         self._packed.clear()
         for k, v in sd.items():
+            if str(k).startswith("__"):
+                continue
             self.vars[k] = torch.as_tensor(np.asarray(v, np.float32)).to(self.device).contiguous()
 
     def num_parameters(self):

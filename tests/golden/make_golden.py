@@ -8,6 +8,12 @@ oracle restatement, not to TF outputs -- "parity unpinned" in the sense of oracl
                               (RenderNet_demo.py:81-98), 128x128 centre crop of logits and output
   bench_frames.npz            (`make_golden.py bench_frames`) five frames of bench.py's batch, one per fixture
   stress_bench_frames.npz     (`make_golden.py stress8`) the 8 frames of `bench.py --mode stress`, one crop each
+  texture_bench_frames.npz    (`make_golden.py texture_bench`) frames 0-3 of `bench.py --mode texture` (BASELINE configs[2]):
+                              centre crops of both heads' images and logits
+  train_step_golden.npz       (`make_golden.py train_step`) BASELINE configs[3] at full width: the first two samples of
+                              `bench.py --mode train` (crop 64 at (31, 17), BCE): loss, a crop of the prediction, and four
+                              sampled entries + the max of every one of the 166 parameter gradients (torch-CPU autograd
+                              over the oracle graph, oracle/train.py), plus the resampled + cropped grid they were computed on
 """
 import os
 import sys
@@ -127,7 +133,71 @@ def stress8():
         np.savez_compressed(os.path.join(HERE, "stress_bench_frames.npz"), **out)
 
 
+TEXTURE_FRAMES = [0, 1, 2, 3]            # of the texture bench batch (strong scaling over 8 ranks still leaves rank 0 three of them)
+TRAIN_START, TRAIN_PATCH, TRAIN_B = (31, 17), 64, 2
+
+
+def texture_bench():
+    """Frames 0-3 of `bench.py --mode texture` (geometry = the bench batch, texture codes ~N(0,1) seed 7, bench poses)
+    through oracle/texture_net.py: the 128x128 centre crop of both heads' images and logits."""
+    from oracle import texture_net as OT
+    from rendernet_amd.texture import TextureSpec, init_texture_weights
+    spec = TextureSpec().check()
+    w = init_texture_weights(spec, seed=1234, perturb=True)
+    vox, poses = _bench_inputs(24)
+    z = np.random.default_rng(7).standard_normal((24, spec.z_dim)).astype(np.float32)      # bench.texture_codes
+    out = {"frames": np.array(TEXTURE_FRAMES), "crop": np.array([192, 320])}
+    for k, i in enumerate(TEXTURE_FRAMES):
+        taps = {}
+        img, nrm = OT.render_texture(vox[i:i + 1], z[i:i + 1], poses[i:i + 1], w, taps=taps)
+        out["image_%d" % k] = img[0, 192:320, 192:320]
+        out["normal_%d" % k] = nrm[0, 192:320, 192:320]
+        out["image_logits_%d" % k] = taps["image_logits"][0, 192:320, 192:320]
+        out["normal_logits_%d" % k] = taps["normal_logits"][0, 192:320, 192:320]
+        print("texture frame", i, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "texture_bench_frames.npz"), **out)
+
+
+def train_step():
+    """The full-width Phong-shader net's training gradient (RenderNet_Shader.py:154-167) on the first TRAIN_B samples of
+    `bench.py --mode train`'s batch: loss + sampled gradient entries of every variable (a full gradient is 949 MB)."""
+    from oracle import train as OTR
+    spec = ShaderSpec().check()
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox, poses = _bench_inputs(TRAIN_B)
+    target = np.random.default_rng(11).uniform(0, 1, (TRAIN_B, 512, 512, 1)).astype(np.float32)
+    full = OR.net_input(vox, poses, 64, 128, mode="tf")
+    net_in, tgt = OTR.crop_voxel_image(full, target, TRAIN_START, TRAIN_PATCH)
+    net_in, tgt = np.ascontiguousarray(net_in), np.ascontiguousarray(tgt)
+    # float64: bias / PReLU-slope gradients are sums of ~10^5 mixed-sign terms -- in float32 the REFERENCE's own summation
+    # noise (2e-3 of the largest entry, measured) would be what the comparison sees
+    loss, grads, pred = OTR.loss_and_grads(net_in, tgt, w, dtype=np.float64)
+    pred = pred.astype(np.float32)
+    rng = np.random.default_rng(5)
+    names = sorted(grads.keys())
+    idx = np.zeros((len(names), 4), np.int64)
+    val = np.zeros((len(names), 4), np.float32)
+    gmax = np.zeros(len(names), np.float32)
+    for k, n in enumerate(names):
+        g = grads[n].reshape(-1)
+        # two random entries and the two largest ones (random entries of a 9.4M-entry filter gradient are mostly tiny)
+        top = np.resize(np.argsort(np.abs(g))[-2:], 2)          # (a 1-element bias: the same entry twice)
+        idx[k] = np.concatenate([rng.integers(0, g.size, 2), top])
+        val[k] = g[idx[k]].astype(np.float32)
+        gmax[k] = np.abs(g).max()
+    np.savez_compressed(os.path.join(HERE, "train_step_golden.npz"), names=np.array(names), idx=idx, val=val, gmax=gmax,
+                        loss=np.float64(loss), pred_crop=pred[:, 64:192, 64:192, 0], net_in=net_in, target=tgt,
+                        start=np.array(TRAIN_START), patch=np.int64(TRAIN_PATCH))
+    print("train step golden: loss %.6f, %d variables" % (loss, len(names)))
+
+
 if __name__ == "__main__":
+    if "texture_bench" in sys.argv:
+        texture_bench()
+        sys.exit(0)
+    if "train_step" in sys.argv:
+        train_step()
+        sys.exit(0)
     if "stress" in sys.argv:
         stress()
         sys.exit(0)

@@ -39,6 +39,9 @@ def test_render_line_has_the_contract_keys_roofline_parity_and_cpu_baseline():
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str) and c["unit"] == "frames/s"
     p = d["parity"]
     assert p["ok"] is True and p["frames"] == 4 and p["max_abs_err"] <= p["tol"] == 1e-3
+    assert d["parity_golden"]["ok"] is True and d["parity_golden"]["frames"] == [0]     # + the committed render of frame 0
+    assert c["protocol"]["batched_pass_frames"] == 4 and c["protocol"]["single_frame_passes"] == 1
+    _check_per_rank(d, 1, [4])
     assert d["roofline_resampler"]["bound"] == "hbm"
 
 
@@ -50,7 +53,61 @@ def test_self_spawned_two_rank_line_and_refusal_without_devices():
              {"RN_SHARE_GPU": "1", "RN_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    _check_per_rank(d, 2, [2, 2])
+    # N > 1 lines check themselves against the committed oracle renders: rank 0 holds frame 0 of the golden set
+    assert d["parity"]["ok"] is True and d["parity"]["frames"] == [0] and d["parity"]["max_abs_err"] <= 1e-3
+    assert "cpu_baseline" not in d                                        # rank 0 at N = 1 only
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, timeout=300, cwd=ROOT)
         assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _check_per_rank(d, world, units):
+    pr, agg = d["per_rank"], d["ms_per_step_per_rank"]
+    assert len(pr["ms_per_step"]) == world and pr["units_per_step"] == units
+    assert agg["min"] <= agg["mean"] <= agg["max"] and abs(agg["max"] - d["ms_per_step"]) <= 1e-2 * d["ms_per_step"] + 1e-3
+    assert abs(agg["max"] - max(pr["ms_per_step"])) < 1e-6 and abs(agg["min"] - min(pr["ms_per_step"])) < 1e-6
+
+
+def test_strong_scaling_two_ranks_split_one_batch():
+    """--scaling strong: ONE batch of 8 split 4 + 4; value = the batch's frames over the slowest rank."""
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--scaling", "strong", "--no-cpu-baseline"],
+             {"RN_SHARE_GPU": "1", "RN_DIST_BACKEND": "gloo"})
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 8 and d["n_gpus"] == 2
+    _check_per_rank(d, 2, [4, 4])
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    assert d["parity"]["ok"] is True and d["parity"]["frames"] == [0]
+
+
+def test_two_rank_training_line_checks_itself():
+    """BASELINE configs[3] over two ranks (one shared device, gloo): the parity block (loss + sampled gradients of all 166
+    variables of the full-width net vs the committed torch-CPU autograd values, through the bucketed all-reduce), the per-rank
+    fields, samples/s of the whole job."""
+    d = _run(["--gpus", "2", "--mode", "train", "--steps", "1", "--warmup", "1", "--batch", "2", "--patch", "32"],
+             {"RN_SHARE_GPU": "1", "RN_DIST_BACKEND": "gloo"})
+    assert d["unit"] == "samples/s" and d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
+    p = d["parity"]
+    assert p["ok"] is True and p["variables"] == 166 and p["grad_entries"] == 664
+    assert p["loss_rel_err"] <= 1e-4 and p["filter_grad_max_rel_err"] <= 1e-3 and p["bias_alpha_grad_max_rel_err"] <= 5e-3
+    _check_per_rank(d, 2, [2, 2])
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+
+
+def test_texture_line_has_parity_and_cpu_baseline():
+    """BASELINE configs[2]: live oracle on the first two frames (cpu_baseline + parity) and the committed renders of frames 0-3."""
+    d = _run(["--mode", "texture", "--steps", "2", "--warmup", "1", "--batch", "4"])
+    assert d["parity"]["ok"] is True and d["parity"]["frames"] == 2 and d["parity"]["max_abs_err"] <= 1e-3
+    g = d["parity_golden"]
+    assert g["ok"] is True and g["frames"] == [0, 1, 2, 3] and g["max_abs_err"] <= 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["protocol"]["batched_pass_frames"] == 2
+    _check_per_rank(d, 1, [4])
+
+
+def test_stress_line_checks_against_committed_renders():
+    """BASELINE configs[4] (128^3 -> 1024^2): the oracle needs minutes per frame, so the line compares with the committed
+    renders of its own batch."""
+    d = _run(["--mode", "stress", "--steps", "1", "--warmup", "1", "--batch", "2"])
+    assert "cpu_baseline" not in d
+    assert d["parity"]["ok"] is True and d["parity"]["frames"] == [0, 1] and d["parity"]["max_abs_err"] <= 1e-3

@@ -60,11 +60,42 @@ def test_training_step_with_dropout_runs_and_eval_is_deterministic():
     a, _ = tr.forward(vox, poses, is_training=False)
     b, _ = tr.forward(vox, poses, is_training=False)
     assert torch.equal(a, b)
+    # masks are a pure function of (trainer seed, rank, global step, dropout site): an extra forward between two steps (the
+    # sample render every 600 steps) re-draws the coming step's masks instead of shifting every later one ...
     c, _ = tr.forward(vox, poses, is_training=True)
     d, _ = tr.forward(vox, poses, is_training=True)
-    assert not torch.equal(c, d)
+    assert torch.equal(c, d) and not torch.equal(c, a)
     loss = tr.step(vox, poses, tgt, patch_size=16, start_point=(3, 5))
     assert np.isfinite(float(loss.item())) and bool(torch.isfinite(tr.grad).all()) and float(tr.grad.abs().max()) > 0
+    # ... every step draws new ones (global_step went 0 -> 1) ...
+    from rendernet_amd import ops
+    assert ops.dropout_state() [1] >> 16 == 0                           # the step's forward drew streams (0 << 16) + k
+    tr.forward(vox, poses, is_training=True)
+    assert ops.dropout_state()[1] >> 16 == 1 and ops.dropout_state()[0] == tr.dropout_seed
+    # ... and another rank of the same job draws different ones for its shard (one process-global constant seed
+    # gave every rank the same mask sequence)
+    assert tr.dropout_seed == ops.mix_seed(1234, 0) != ops.mix_seed(1234, 1)
+    e1, _ = tr.forward(vox, poses, is_training=True)
+    tr.dropout_seed = ops.mix_seed(1234, 1)
+    e2, _ = tr.forward(vox, poses, is_training=True)
+    assert not torch.equal(e1, e2)
+
+
+def test_dropout_takes_unaligned_views_and_empty_tensors():
+    """rn_dropout on a float-aligned (not 16-byte aligned) pointer -- the gradient of an offset view -- draws the same mask per
+    ELEMENT as the aligned call, and an empty tensor is a no-op."""
+    from rendernet_amd import ops
+    base = torch.randn(4099, device="cuda")
+    x = base[1:]                                                        # contiguous, 4 bytes off the 16-byte grid
+    assert x.data_ptr() % 16 != 0
+    y = ops.dropout(x, 0.6, seed=77, stream_id=3)
+    assert np.array_equal(y.cpu().numpy(), OD.dropout(x.cpu().numpy(), 0.6, 77, 3))
+    xg = x.clone().requires_grad_(True)
+    g = torch.randn(4102, device="cuda")[3:3 + 4098]                     # an offset view as the incoming gradient
+    ops.dropout(xg, 0.6, seed=77, stream_id=3).backward(g)
+    assert np.array_equal(xg.grad.cpu().numpy(), OD.dropout(g.cpu().numpy(), 0.6, 77, 3))
+    e = torch.empty(0, device="cuda")
+    assert ops.dropout(e, 0.5).numel() == 0
 
 
 def test_checkpoint_resume_continues_the_trajectory(tmp_path):

@@ -380,3 +380,38 @@ def test_inference_render_unchanged_by_training_mode():
     tr = Trainer(spec, w, device="cuda:0")
     b, _ = tr.forward(vox, poses)
     assert torch.equal(a, b.detach())
+
+
+def test_load_checkpoint_validates_before_it_mutates(tmp_path):
+    """a checkpoint that lacks variables, holds moment buffers of another length or only part of the optimiser
+    state raises and leaves the trainer untouched; a weights-only file restarts moments, global_step AND the epoch; extras
+    (the scripts' validation history) come back through checkpoint_extra."""
+    from rendernet_amd.shader import tiny_spec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    spec = tiny_spec(1)
+    w = init_shader_weights(spec, seed=3, perturb=True)
+    a = Trainer(spec, w)
+    rng = np.random.default_rng(0)
+    vox = (rng.random((2, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    poses = np.array([[1.0, 0.6, 1.0], [4.0, 0.4, 0.9]], np.float32)
+    a.step(vox, poses, rng.random((2, 128, 128, 1)).astype(np.float32), patch_size=16, start_point=(3, 5))
+    good = a.checkpoint(epoch=4, extra={"l1_all": [0.5, 0.25]})
+    b = Trainer(spec, init_shader_weights(spec, seed=99))
+    before = (b.param.clone(), b.m.clone(), b.global_step)
+
+    def untouched():
+        return torch.equal(b.param, before[0]) and torch.equal(b.m, before[1]) and b.global_step == before[2]
+
+    some = next(iter(w))
+    for bad, what in (({k: v for k, v in good.items() if k != some}, "lacks"),
+                      ({**good, "__adam_m__": good["__adam_m__"][:-4]}, "flat buffer"),
+                      ({k: v for k, v in good.items() if k != "__adam_v__"}, "only part"),
+                      ({**good, some: np.zeros(3, np.float32)}, "elements")):
+        with pytest.raises(ValueError, match=what):
+            b.load_checkpoint(bad)
+        assert untouched(), what
+    assert b.load_checkpoint(good) == 4 and b.global_step == 1 and torch.equal(b.param, a.param) and torch.equal(b.v, a.v)
+    assert list(b.checkpoint_extra["l1_all"]) == [0.5, 0.25]
+    assert b.load_checkpoint(a.state_dict()) == 0 and b.global_step == 0 and float(b.m.abs().max()) == 0.0   # weights only
+    with pytest.warns(UserWarning):
+        b.load_checkpoint({k: v for k, v in good.items() if k != some}, strict=False)

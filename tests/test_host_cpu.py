@@ -315,3 +315,21 @@ def test_texture_face_loader_parses_names_and_pads(tmp_path):
     assert np.array_equal(texs[0], code) and float(nrms.max()) == 77.0 and mods.sum() > 0
     assert np.allclose(params[0], [250 * np.pi / 180, 60 * np.pi / 180, 1.0]) and np.allclose(params[1][2], 3.3 / 2.5)
     assert list(chunks[1][5]) == [names[2], names[2]]
+
+
+def test_state_dict_loading_skips_optimizer_state_and_seeds_mix():
+    """A training checkpoint also holds '__adam_m__', '__adam_v__', '__global_step__', '__epoch__' (train.py): the inference
+    entry points must not upload them as variables.  ops.mix_seed: deterministic, rank-separating."""
+    from rendernet_amd import ops
+    from rendernet_amd.variables import VariableStore
+    st = VariableStore("cpu")
+    st.load_state_dict({"encoder/e_conv1/e_conv1/weights": np.ones((5, 5, 5, 1, 8), np.float32), "__adam_m__": np.zeros(1000, np.float32),
+                        "__adam_v__": np.zeros(1000, np.float32), "__global_step__": np.int64(7), "__epoch__": np.int64(2),
+                        "__l1_all__": np.zeros(3)})
+    assert list(st.vars) == ["encoder/e_conv1/e_conv1/weights"] and st.num_parameters() == 1000
+    seeds = {ops.mix_seed(1234, r) for r in range(64)}
+    assert len(seeds) == 64 and all(0 <= s < 2 ** 64 for s in seeds)
+    assert ops.mix_seed(1234, 3) == ops.mix_seed(1234, 3) != ops.mix_seed(1235, 3)
+    ops.seed_dropout(5, 9 << 16)
+    assert ops.dropout_state() == (5, 9 << 16)
+    ops.seed_dropout(0x5EED0FD50)
