@@ -55,6 +55,9 @@ extern "C" {
                                      transform: the input gradient of a stride-1 3x3(x3) conv through
                                      rn_conv2d_wino_fwd / rn_conv3d_wino_fwd                                     */
 
+#define RN_PACK_CONVT_S2_WINO   13 /* TF conv_transpose filter [4,4,Cout,Cin], STRIDE 2 (slim.conv2d_transpose, RenderNet_Shader.py:
+                                    * 105-119: e_conv7 / e_conv8 / e_conv9): the four output phases as four 2x2 sub-filters, each in
+                                    * Winograd F(2x2,2x2) form; 36*Cin*Cout floats; Cin, Cout multiples of 16 (rn_conv2d_transpose_s2_wino_fwd) */
 #define RN_PACK_CONV_WINO43     7  /* TF conv filter [3,3,Cin,Cout] -> Winograd F(4x4,3x3) form U = G g G^T (36 planes,
                                      36*Cin*Cout floats, Cin % 32 == 0, Cout % 256 == 0): rn_conv2d_wino43_fwd      */
 #define RN_PACK_CONVT_S1_WINO43 8  /* TF conv_transpose filter [3,3,Cout,Cin], stride 1, taps flipped, same transform
@@ -241,6 +244,15 @@ int rn_conv2d_wino4_supported(int Cin, int Cout);
 int rn_conv2d_wino4_fwd(const float* x, const float* w_wino4, const float* bias, const float* alpha,
                         const float* residual, float* y, float* preact,
                         int B, int H, int W, int Cin, int Cout, int transposed, int act, void* stream);
+
+/* 4x4 STRIDE-2 SAME transposed conv (slim.conv2d_transpose, RenderNet_Shader.py:105-119; tools/layer_util.py:186-226) through
+ * Winograd F(2x2,2x2) per output phase: y[2m+pa, 2n+pb] is a 2x2 conv of the input, 9 multiplies per 4 outputs instead of 16,
+ * exact fp32 MFMA; the four phases are items of ONE launch.  x [B,H,W,Cin] -> y [B,2H,2W,Cout]; w_wino_s2 from
+ * rn_pack_weights(RN_PACK_CONVT_S2_WINO); epilogue as rn_conv2d_fwd_train (bias, preact, PReLU / ELU, residual, sigmoid). */
+int rn_conv2d_transpose_s2_wino_supported(int Cin, int Cout);
+int rn_conv2d_transpose_s2_wino_fwd(const float* x, const float* w_wino_s2, const float* bias, const float* alpha,
+                                    const float* residual, float* y, float* preact,
+                                    int B, int H, int W, int Cin, int Cout, int act, void* stream);
 int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,
                        const float* residual, float* y, float* preact,
                        int B, int H, int W, int D, int Cin, int Cout, int act, void* stream);

@@ -17,6 +17,7 @@ RN_PACK_CONV_WINO4, RN_PACK_CONVT_S1_WINO4 = 5, 6
 RN_PACK_CONV_WINO43, RN_PACK_CONVT_S1_WINO43 = 7, 8
 RN_PACK_CONV_WINO44, RN_PACK_CONVT_S1_WINO44 = 9, 10
 RN_PACK_CONV_WINO63, RN_PACK_CONVT_S1_WINO63 = 11, 12
+RN_PACK_CONVT_S2_WINO = 13
 RN_WINO_F43, RN_WINO_F44, RN_WINO_F63 = 0, 1, 2
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
@@ -43,6 +44,8 @@ SIGNATURES = {
     "rn_conv2d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
     "rn_conv2d_wino4_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino4_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
+    "rn_conv2d_transpose_s2_wino_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv2d_transpose_s2_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
     "rn_conv3d_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv3d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),

@@ -132,6 +132,22 @@ extern "C" int rn_conv2d_wino4_fwd(const float* x, const float* w_wino4, const f
                                (hipStream_t)stream);
 }
 
+extern "C" int rn_conv2d_transpose_s2_wino_supported(int Cin, int Cout)
+{
+    static const bool off = getenv("RN_NO_WINOGRAD_S2") != nullptr;
+    return (!off && rn_wino4_supported(Cin, Cout)) ? 1 : 0;
+}
+
+extern "C" int rn_conv2d_transpose_s2_wino_fwd(const float* x, const float* w_wino_s2, const float* bias, const float* alpha,
+                                               const float* residual, float* y, float* preact,
+                                               int B, int H, int W, int Cin, int Cout, int act, void* stream)
+{
+    if (!x || !w_wino_s2 || !y) return rn_set_error(RN_E_INVALID, "rn_conv2d_transpose_s2_wino_fwd: null pointer");
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_transpose_s2_wino_fwd: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_transpose_s2_wino_fwd: PReLU needs alpha");
+    return rn_launch_conv_wino(x, w_wino_s2, bias, alpha, residual, y, preact, B, H, W, 1, 1, Cin, Cout, act, 2, 1, (hipStream_t)stream);
+}
+
 extern "C" int rn_conv3d_wino_supported(int Cin, int Cout) { return rn_wino3d_supported(Cin, Cout) ? 1 : 0; }
 
 extern "C" int rn_conv3d_wino_fwd(const float* x, const float* w_wino, const float* bias, const float* alpha,

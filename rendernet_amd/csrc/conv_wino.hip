@@ -48,6 +48,10 @@ constexpr int WRAW_B = WRAW_PIECES * 1024;   // bytes per raw stage (40 960)
 constexpr unsigned WOOB = 0x80000000u;
 // MODE 0: F(2x2,3x3), 16 xi planes, 4x4 input tiles.  MODE 1: a 4x4 filter as four 2x2 sub-filters, each F(2x2,2x2): 9 xi
 // planes, 3x3 input tiles, the sub-filters are four consecutive K steps that read the patch shifted by (2a, 2b) pixels.
+// MODE 2: a 4x4 STRIDE-2 transposed conv (slim.conv2d_transpose, RenderNet_Shader.py:105-119: e_conv7, e_conv8, e_conv9): output
+// phase (pa, pb) = pixels (2m+pa, 2n+pb) is a 2x2 conv of the input, y[2m+pa] = x[m-1+pa] w[3-pa] + x[m+pa] w[1-pa] per axis, so
+// every phase is one F(2x2,2x2) conv (9 multiplies per 4 outputs instead of 16) with its own sub-filter and its own output
+// pixels: the four phases are four ITEMS of one launch (the phase rides in WinoBlock::dz), each with Cin/16 K steps.
 constexpr int wino_nxi(int mode) { return mode ? 9 : 16; }
 constexpr int wino_upieces(int mode, int nt) { return wino_nxi(mode) * nt; }          // 1-KiB filter pieces per step
 constexpr int wino_upw(int mode, int nt) { return (wino_upieces(mode, nt) + 7) / 8; }   // ... per wave
@@ -92,7 +96,7 @@ struct WinoBlock {
 template <int NT, int MODE>
 __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, int lane, WinoBlock& k)
 {
-    constexpr int NSUB = MODE ? 4 : 1;
+    constexpr int NSUB = MODE == 1 ? 4 : 1;
     const int T = a.mblocks * a.nblocks;
     int e = id;
     if (id < (T & ~255)) { const int s = id >> 3; e = (s >> 5) * 256 + (id & 7) * 32 + (s & 31); }
@@ -108,8 +112,10 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
     // volume (SAME padding) is a run of `spt` whole steps of zeros: those steps are skipped.
     k.s_begin = (a.KD == 3 && k.dz == 0) ? a.spt : 0;
     k.s_end = a.KD * a.spt * NSUB - ((a.KD == 3 && k.dz == a.D - 1) ? a.spt : 0);
-    const unsigned pix_bytes = (unsigned)a.D * (unsigned)a.Cin * 4u;
-    const unsigned win_off = (unsigned)((k.dz - (a.KD == 3 ? 1 : 0)) * a.Cin * 4);   // may wrap below 0: only used with s >= s_begin
+    // (MODE 2: D = 4 output phases, the input has no such axis; phase (pa, pb) reads from pixel (m - 1 + pa, n - 1 + pb))
+    const unsigned pix_bytes = (MODE == 2 ? 1u : (unsigned)a.D) * (unsigned)a.Cin * 4u;
+    const unsigned win_off = MODE == 2 ? 0u : (unsigned)((k.dz - (a.KD == 3 ? 1 : 0)) * a.Cin * 4);   // may wrap below 0: only used with s >= s_begin
+    const int pady = MODE == 2 ? 1 - (k.dz >> 1) : a.pad, padx = MODE == 2 ? 1 - (k.dz & 1) : a.pad;
     // raw-patch DMA: piece p = wave + 8 i (i < 5) holds pixels q = 16 p + lane/4 (q = py*34 + px); the lane fetches
     // LOGICAL chunk (lane%4) ^ swz(px) into physical slot lane%4, swz(px) = (px>>1)&3 (two lanes of a ds_read_b128
     // group at most share a 16-B slot)
@@ -119,9 +125,9 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
         const int p = wave + 8 * i;
         const int q = p * 16 + (lane >> 2);
         const int py = q / WPW, px = q - py * WPW;
-        const int iy = k.by * 16 - a.pad + py, ix = k.bx * 32 - a.pad + px;
+        const int iy = k.by * 16 - pady + py, ix = k.bx * 32 - padx + px;
         const unsigned o = (unsigned)((k.b * a.H + iy) * a.W + ix) * pix_bytes + win_off + (unsigned)(((lane & 3) ^ ((px >> 1) & 3)) * 16);
-        if (MODE == 0) {
+        if (MODE != 1) {
             const bool ok = q < WNPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             k.roff[i] = ok ? o : WOOB;
         } else {
@@ -134,8 +140,8 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
         }
     }
     // filter DMA: the piece of (nb, step) is lane-linear, 1 KiB per instruction; wave w moves pieces w, w + 8, ...
-    k.uoff = ((unsigned)k.nb * (unsigned)(a.KD * a.spt * NSUB)) * (1024u * wino_upieces(MODE, NT)) + (unsigned)wave * 1024u +
-             (unsigned)lane * 16u;
+    k.uoff = ((unsigned)(MODE == 2 ? k.dz * a.nblocks + k.nb : k.nb) * (unsigned)(a.KD * a.spt * NSUB)) * (1024u * wino_upieces(MODE, NT)) +
+             (unsigned)wave * 1024u + (unsigned)lane * 16u;
 }
 
 // PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
@@ -176,7 +182,7 @@ void conv_wino_kernel(const WinoArgs a)
         raddr0[hj] = (unsigned)((2 * wave * WPW + 2 * l16) * 64 + ((kq ^ ((l16 + hj) & 3)) << 4));
     const unsigned uaddr0 = (unsigned)(2 * WRAW_B + kq * (256 * NT) + l16 * 16);
 
-    constexpr int NXI = wino_nxi(MODE), TP = MODE ? 3 : 4, NSUB = MODE ? 4 : 1;
+    constexpr int NXI = wino_nxi(MODE), TP = MODE ? 3 : 4, NSUB = MODE == 1 ? 4 : 1;
     constexpr int UPW = wino_upw(MODE, NT), UPIECES = wino_upieces(MODE, NT), WU_B = wino_ustage(MODE, NT);
     constexpr int NDMA = 5 + UPW;                  // DMA instructions per wave and step: 5 raw-patch + UPW filter pieces
     constexpr unsigned USTEP = 1024u * UPIECES;    // filter bytes per step and n-block
@@ -208,7 +214,7 @@ void conv_wino_kernel(const WinoArgs a)
             f32x4 t_[TP], v_[TP];                                                                         \
             if (PROBE & 1) {                                                                              \
                 _Pragma("unroll") for (int bi = 0; bi < TP; ++bi) v_[bi] = d_[i][bi];                     \
-            } else if (MODE == 1) {                                                                       \
+            } else if (MODE != 0) {                                                                       \
                 _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                                          \
                     t_[bi] = i == 0 ? pk_sub(d_[0][bi], d_[1][bi]) : i == 1 ? d_[1][bi] : pk_sub(d_[1][bi], d_[2][bi]); \
                 v_[0] = pk_sub(t_[0], t_[1]); v_[1] = t_[1]; v_[2] = pk_sub(t_[1], t_[2]);                \
@@ -236,7 +242,7 @@ void conv_wino_kernel(const WinoArgs a)
         unsigned ro_[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-            ro_[i] = (MODE == 0 || ((cur.vmask >> i) & 1u)) ? cur.roff[i] + (unsigned)(cur.s_begin / NSUB) * 64u : WOOB;
+            ro_[i] = (MODE != 1 || ((cur.vmask >> i) & 1u)) ? cur.roff[i] + (unsigned)(cur.s_begin / NSUB) * 64u : WOOB;
         const unsigned uo_ = cur.uoff, us_ = (unsigned)cur.s_begin * USTEP;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) WINO_DMA_ONE(0, i);
@@ -254,8 +260,8 @@ void conv_wino_kernel(const WinoArgs a)
             unsigned ro_[5];
             const int sn = s + 1;                 // the item's next step: sub-filter sn % NSUB of channel step sn / NSUB
             // MODE 1: sub-filter sn & 3 = (a, b) reads the patch shifted by (2a, 2b) pixels
-            const unsigned sd_ = MODE == 0 ? 0u : (unsigned)((((sn >> 1) & 1) * 2 * a.W + (sn & 1) * 2) * a.Cin * 4);
-            const unsigned vm_ = MODE == 0 ? ~0u : last ? nxt.vmask : cur.vmask >> ((sn & 3) * 5);
+            const unsigned sd_ = MODE != 1 ? 0u : (unsigned)((((sn >> 1) & 1) * 2 * a.W + (sn & 1) * 2) * a.Cin * 4);
+            const unsigned vm_ = MODE != 1 ? ~0u : last ? nxt.vmask : cur.vmask >> ((sn & 3) * 5);
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const unsigned o_ = last ? nxt.roff[i] + (unsigned)(nxt.s_begin / NSUB) * 64u : cur.roff[i] + sd_ + (unsigned)(sn / NSUB) * 64u;
@@ -329,7 +335,10 @@ void conv_wino_kernel(const WinoArgs a)
         for (int p4 = 0; p4 < 4; ++p4) {
             const int oy = cur.by * 16 + 2 * ty + (p4 >> 1), ox = cur.bx * 32 + 2 * tx + (p4 & 1);
             inb[p4] = oy < a.H && ox < a.W;
-            oo[p4] = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + cur.nb * (16 * NT) + 4 * kq;
+            if (MODE == 2)          // phase (pa, pb) = cur.dz of the 2H x 2W output image
+                oo[p4] = ((size_t)(cur.b * 2 * a.H + 2 * oy + (cur.dz >> 1)) * (2 * a.W) + 2 * ox + (cur.dz & 1)) * a.Cout + cur.nb * (16 * NT) + 4 * kq;
+            else
+                oo[p4] = (((size_t)(cur.b * a.H + oy) * a.W + ox) * a.D + cur.dz) * a.Cout + cur.nb * (16 * NT) + 4 * kq;
         }
 #pragma unroll
         for (int n0 = 0; n0 < NT; n0 += NG) {
@@ -350,7 +359,7 @@ void conv_wino_kernel(const WinoArgs a)
                 f32x4 c_[TP][2];                     // column transform of every xi row: M[i][*] A
 #pragma unroll
                 for (int i = 0; i < TP; ++i) {
-                    if (MODE == 1) {                 // F(2,2): A^T = [[1,1,0],[0,1,-1]]
+                    if (MODE != 0) {                 // F(2,2): A^T = [[1,1,0],[0,1,-1]]
                         c_[i][0] = acc[i * 3 + 0][nt] + acc[i * 3 + 1][nt];
                         c_[i][1] = acc[i * 3 + 1][nt] - acc[i * 3 + 2][nt];
                     } else {
@@ -363,7 +372,7 @@ void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
                 for (int p4 = 0; p4 < 4; ++p4) {
                     const int dy = p4 >> 1, dx = p4 & 1;
-                    v[g][p4] = (MODE == 1 ? (dy == 0 ? c_[0][dx] + c_[1][dx] : c_[1][dx] - c_[2][dx])
+                    v[g][p4] = (MODE != 0 ? (dy == 0 ? c_[0][dx] + c_[1][dx] : c_[1][dx] - c_[2][dx])
                                           : (dy == 0 ? (c_[0][dx] + c_[1][dx]) + c_[2][dx] : (c_[1][dx] - c_[2][dx]) - c_[TP - 1][dx])) + bv[g];
                 }
             }
@@ -450,21 +459,23 @@ static int wino_launch(const WinoArgs& a, unsigned grid, hipStream_t st)
 //           D = 1, KD = 1: 2-D.  KD = 3: 3-D (D >= 1).
 //   mode 1: 4x4 2-D conv with pad_lo = pad (1: SAME conv; 2: the flipped conv of a stride-1 transposed conv), u from
 //           rn_pack_weights(RN_PACK_CONV_WINO4 | RN_PACK_CONVT_S1_WINO4).
+//   mode 2: 4x4 stride-2 SAME transposed conv, x [B,H,W,Cin] -> y [B,2H,2W,Cout], u from rn_pack_weights(RN_PACK_CONVT_S2_WINO).
 int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
                         int mode, int pad, hipStream_t st)
 {
     if (Cin % 16 != 0 || Cout % 16 != 0)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: Cin=%d Cout=%d (both must be multiples of 16)", Cin, Cout);
-    if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1) || (mode && KD != 1) || (mode != 0 && mode != 1))
+    if (D < 1 || (KD != 1 && KD != 3) || (KD == 1 && D != 1) || (mode && KD != 1) || mode < 0 || mode > 2)
         return rn_set_error(RN_E_INVALID, "conv_wino: D=%d KD=%d mode=%d", D, KD, mode);
+    const int Dout = mode == 2 ? 4 : D;                 // mode 2: the four output phases of a stride-2 transposed conv
     const long long per_item = (long long)H * W * D * Cin * 4;
     if (per_item >= 0x80000000LL)
         return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: one batch item of %lld bytes exceeds the 2 GiB buffer window", per_item);
     if (per_item * B >= 0x80000000LL) {
         // 32-bit byte offsets with the upper half reserved for the hardware zero fill: batch chunks that fit the window
         const int chunk = (int)(0x7fffffffLL / per_item);
-        const size_t ostep = (size_t)H * W * D * Cout;
+        const size_t ostep = (size_t)H * W * Dout * Cout;
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nbi = B - b0 < chunk ? B - b0 : chunk;
             const int rc = rn_launch_conv_wino(x + (size_t)b0 * (per_item / 4), u, bias, alpha,
@@ -482,9 +493,9 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     const long long ub = (mode ? 36LL : 16LL * KD) * Cin * Cout * 4;
     if (ub >= 0x80000000LL) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino: transformed filter of %lld bytes exceeds 2 GiB", ub);
     a.u_bytes = (unsigned)ub;
-    a.B = B; a.H = H; a.W = W; a.D = D; a.KD = KD; a.Cin = Cin; a.Cout = Cout;
+    a.B = B; a.H = H; a.W = W; a.D = Dout; a.KD = KD; a.Cin = Cin; a.Cout = Cout;
     a.bh = (H + 15) / 16; a.bw = (W + 31) / 32;
-    const long long mbl = (long long)B * D * a.bh * a.bw;
+    const long long mbl = (long long)B * Dout * a.bh * a.bw;
     const int NTv = rn_wino_ntiles(mode, Cout);
     a.nblocks = Cout / (16 * NTv);
     if (mbl * a.nblocks > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_wino: grid too large");
@@ -508,6 +519,8 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
     const unsigned grid = (unsigned)(total < want ? total : want);
     if (mode == 1)
         return NTv == 4 ? wino_launch<0, 4, 1>(a, grid, st) : NTv == 2 ? wino_launch<0, 2, 1>(a, grid, st) : wino_launch<0, 1, 1>(a, grid, st);
+    if (mode == 2)
+        return NTv == 4 ? wino_launch<0, 4, 2>(a, grid, st) : NTv == 2 ? wino_launch<0, 2, 2>(a, grid, st) : wino_launch<0, 1, 2>(a, grid, st);
     if (NTv == 1) return wino_launch<0, 1, 0>(a, grid, st);
     switch (probe) {
         case 1: return wino_launch<1, 2, 0>(a, grid, st);

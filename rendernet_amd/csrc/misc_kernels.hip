@@ -130,6 +130,38 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w_tf, float* __restr
     }
 }
 
+// Stride-2 4x4 transposed conv as four F(2x2,2x2) phase convs (conv_wino.hip MODE 2).  Per axis y[2m+pa] = x[m-1+pa] w[3-pa] +
+// x[m+pa] w[1-pa] (TF SAME: crop 1), i.e. phase pa is the correlation of the input window starting at m-1+pa with the 2-tap
+// filter h[p] = w[3 - pa - 2p].  Packed [4 phases][Cout/NB][Cin/16][9 xi][4 kq][NB n][4 r], U = G2 h G2^T with
+// G2 = [[1,0],[1,1],[0,1]]; reads the TF conv_transpose filter w_tf[4,4,Cout,Cin]; channel c = cstep*16 + kq*4 + r.
+__global__ void pack_wino_s2_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int Cin, int Cout, int NB)
+{
+    const size_t total = (size_t)36 * Cin * Cout;
+    const int nstep = Cin / 16, nblocks = Cout / NB;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t rem = idx;
+        const int r = (int)(rem & 3); rem >>= 2;
+        const int n = (int)(rem % NB); rem /= NB;
+        const int kq = (int)(rem & 3); rem >>= 2;
+        const int xi = (int)(rem % 9); rem /= 9;
+        const int step = (int)(rem % nstep); rem /= nstep;
+        const int nb = (int)(rem % nblocks);
+        const int ph = (int)(rem / nblocks);
+        const int c = step * 16 + kq * 4 + r, co = nb * NB + n;
+        const int pa = ph >> 1, pb = ph & 1, i = xi / 3, j = xi % 3;
+        float h[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                h[p][q] = w_tf[((size_t)((3 - pa - 2 * p) * 4 + (3 - pb - 2 * q)) * Cout + co) * Cin + c];
+        float row[2];                               // (G2 h)[i][q]
+#pragma unroll
+        for (int q = 0; q < 2; ++q) row[q] = i == 0 ? h[0][q] : i == 1 ? h[0][q] + h[1][q] : h[1][q];
+        u[idx] = j == 0 ? row[0] : j == 1 ? row[0] + row[1] : row[1];
+    }
+}
+
 static bool is_wino43_kind(int kind)
 {
     return kind == RN_PACK_CONV_WINO43 || kind == RN_PACK_CONVT_S1_WINO43 || kind == RN_PACK_CONV_WINO44 || kind == RN_PACK_CONVT_S1_WINO44 ||
@@ -141,7 +173,7 @@ static int wino43_scheme(int kind)
          : (kind == RN_PACK_CONV_WINO63 || kind == RN_PACK_CONVT_S1_WINO63) ? RN_WINO_F63 : RN_WINO_F43;
 }
 static bool is_wino_kind(int kind) { return kind == RN_PACK_CONV_WINO || kind == RN_PACK_CONVT_S1_WINO; }
-static bool is_wino4_kind(int kind) { return kind == RN_PACK_CONV_WINO4 || kind == RN_PACK_CONVT_S1_WINO4; }
+static bool is_wino4_kind(int kind) { return kind == RN_PACK_CONV_WINO4 || kind == RN_PACK_CONVT_S1_WINO4 || kind == RN_PACK_CONVT_S2_WINO; }
 
 static int wino4_pack_check(int ndim, const int* kdims, int Cin, int Cout)
 {
@@ -221,8 +253,12 @@ extern "C" int rn_pack_weights(int kind, int ndim, const int* kdims, int Cin, in
         if (!w_tf || !w_packed) return rn_set_error(RN_E_INVALID, "pack: null pointer");
         const size_t tot = (size_t)36 * Cin * Cout;
         const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
-        hipLaunchKernelGGL(pack_wino4_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
-                           16 * rn_wino_ntiles(1, Cout), kind == RN_PACK_CONVT_S1_WINO4 ? 1 : 0);
+        if (kind == RN_PACK_CONVT_S2_WINO)
+            hipLaunchKernelGGL(pack_wino_s2_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
+                               16 * rn_wino_ntiles(2, Cout));
+        else
+            hipLaunchKernelGGL(pack_wino4_kernel, dim3(nbw), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, Cin, Cout,
+                               16 * rn_wino_ntiles(1, Cout), kind == RN_PACK_CONVT_S1_WINO4 ? 1 : 0);
         return rn_check_launch("pack_wino4");
     }
     if (is_wino43_kind(kind)) {

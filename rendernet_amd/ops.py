@@ -64,6 +64,10 @@ class PackedWeight:
         w4kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO4, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO4}.get(kind)
         self._wino4_kind = w4kind if (w4kind is not None and ndim == 2 and self.kdims == [4, 4]
                                       and lib.rn_conv2d_wino4_supported(self.cin, self.cout)) else None
+        # 4x4 STRIDE-2 transposed filters (e_conv7, e_conv8, e_conv9 and the texture net's heads): every output phase is a 2x2
+        # conv, each F(2x2,2x2); the four phases run as one launch (rides in the "wino4" slot: a filter is one or the other)
+        if kind == L.RN_PACK_CONVT_S2 and ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_transpose_s2_wino_supported(self.cin, self.cout):
+            self._wino4_kind = L.RN_PACK_CONVT_S2_WINO
 
         # Winograd with 4x4 output tiles in three launches (csrc/conv_wino43.hip): F(4x4,3x3) for the wide 3x3 2-D layers
         # (res2, res3 and their skips), F(4x4,4x4) for the wide 4x4 ones (e_conv5, e_conv6)
@@ -493,6 +497,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
             return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act)
         if unit and pw.wino4 is not None:
             return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, 1, act, st)
+        if (not unit) and int(stride[0]) == 2 and pw.kind == L.RN_PACK_CONVT_S2 and pw.wino4 is not None:
+            return lib.rn_conv2d_transpose_s2_wino_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, act, st)
         return lib.rn_conv2d_transpose_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, Cin, pw.cout, ksize[0], stride[0], act, st)
     if mode == "conv3d_transpose":
         B, H, W, D, Cin = x.shape

@@ -709,3 +709,63 @@ def test_conv2d_winograd_4x4(case):
         L.check(L.lib().rn_conv2d_wino4_fwd(L.ptr(dz), L.ptr(dp.wino4), None, None, None, L.ptr(dx), None, B, H, W, Cout, Cin, 1, 0,
                                             L.stream_ptr()), "rn_conv2d_wino4_fwd (dgrad)")
         _close(dx, OL.conv2d_transpose(dz.cpu().numpy(), w, None, (1, 1)), "wino4 dgrad vs oracle")
+
+
+# Stride-2 4x4 transposed convs through Winograd F(2x2,2x2) per output phase (conv_wino.hip MODE 2): the decoder's e_conv7 /
+# e_conv8 / e_conv9 widths (RenderNet_Shader.py:105-119), the texture heads' (RenderNet_Texture_Face_Normal.py:117-140), every
+# n-tile count (Cout 16 / 32 / 64 / 128 -> NT 1 / 2 / 4 / 4 x 2 n-blocks), planes that are not multiples of the 32 x 16 block,
+# more items than the persistent grid (B = 3 at 64 x 64 x 4 phases), 1 x 1 planes.
+CONVT_S2_WINO_CASES = [
+    (2, 8, 8, 256, 128),
+    (1, 16, 16, 128, 64),
+    (1, 9, 7, 64, 32),
+    (1, 33, 17, 32, 16),
+    (3, 64, 64, 64, 32),
+    (1, 1, 1, 16, 16),
+    (2, 5, 40, 48, 96),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_S2_WINO_CASES)
+def test_conv2d_transpose_s2_winograd(case):
+    """rn_conv2d_transpose_s2_wino_fwd vs the oracle's tf.nn.conv2d_transpose restatement (every epilogue flavour, the
+    pre-activation output), vs the direct phase kernels on the same filter, the packed filter vs its NumPy statement, and the
+    dispatcher's routing."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _rand(rng, B, H, W, Cin)
+    w = _xavier(rng, (4, 4, Cout, Cin))
+    b = _rand(rng, Cout) * 0.1
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    lib = L.lib()
+    pw = ops.pack_conv_transpose(_dev(w), 2)
+    assert pw._wino4_kind == L.RN_PACK_CONVT_S2_WINO and pw.wino4 is not None
+    # packed filter: [4 ph][Cout/NB][Cin/16][9 xi][4 kq][NB][4 r], U = G2 h G2^T, h[p][q] = w[3-pa-2p, 3-pb-2q]
+    NB = 64 if Cout % 64 == 0 else 32 if Cout % 32 == 0 else 16
+    G2 = np.array([[1, 0], [1, 1], [0, 1]], np.float64)
+    want_u = np.zeros((4, Cout // NB, Cin // 16, 9, 4, NB, 4), np.float32)
+    for ph in range(4):
+        pa, pb = ph >> 1, ph & 1
+        h = np.stack([np.stack([w[3 - pa - 2 * p, 3 - pb - 2 * q] for q in range(2)]) for p in range(2)]).astype(np.float64)   # [p,q,Cout,Cin]
+        U = np.einsum("ip,pqoc,jq->ijoc", G2, h, G2).reshape(9, Cout // NB, NB, Cin // 16, 4, 4)    # [xi, nb, n, step, kq, r]
+        want_u[ph] = U.transpose(1, 3, 0, 4, 2, 5)
+    assert np.abs(pw.wino4.cpu().numpy().reshape(want_u.shape) - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    y0 = OL.conv2d_transpose(x, w, b, (2, 2))
+    res = _rand(rng, *y0.shape)
+    xd, bd, ad, rd = _dev(x), _dev(b), _dev(alpha), _dev(res)
+    _close(ops.conv2d_transpose(xd, pw, bd, stride=(2, 2)), y0, "convT s2 wino")
+    got = ops.conv2d_transpose(xd, pw, bd, ad, rd, stride=(2, 2))
+    _close(got, OL.prelu(y0, alpha) + torch.from_numpy(res), "convT s2 wino+prelu+res")
+    _close(ops.conv2d_transpose(xd, pw, None, stride=(2, 2), sigmoid=True), torch.sigmoid(OL.conv2d_transpose(x, w, None, (2, 2))), "convT s2 wino+sigmoid")
+    yy, zz = torch.empty((B, 2 * H, 2 * W, Cout), device="cuda"), torch.empty((B, 2 * H, 2 * W, Cout), device="cuda")
+    L.check(lib.rn_conv2d_transpose_s2_wino_fwd(L.ptr(xd), L.ptr(pw.wino4), L.ptr(bd), L.ptr(ad), None, L.ptr(yy), L.ptr(zz),
+                                                B, H, W, Cin, Cout, 1, L.stream_ptr()), "rn_conv2d_transpose_s2_wino_fwd")
+    _close(zz, y0, "convT s2 wino preact")
+    _close(yy, OL.prelu(y0, alpha), "convT s2 wino prelu")
+    # A/B against the direct phase kernels on the same filter
+    p2 = ops.pack_conv_transpose(_dev(w), 2)
+    p2.wino4 = None
+    ref2 = ops.conv2d_transpose(xd, p2, bd, ad, rd, stride=(2, 2))
+    assert float((got - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
