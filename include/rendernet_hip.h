@@ -234,6 +234,16 @@ int rn_winograd_input_transform(int scheme, const float* x, float* V, int B, int
 int rn_winograd_gemm(int scheme, const float* V, const float* w_packed, float* M, long long T, int Cin, int Cout, void* stream);
 int rn_winograd_output_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
                                  float* y, float* preact, int B, int H, int W, int C, int act, void* stream);
+/* Output transform of one conv FUSED with the input transform of the next (stride-1 3x3, same channel count C on both sides --
+ * the convs of a res_block_2d stack, tools/layer_util.py:91-105, RenderNet_Shader.py:71-84,91-99): M [nxi][T][C] of conv a ->
+ * epilogue (bias, PReLU, residual) -> V [nxi][T][C] of conv b, the activation staying in LDS.  y (may be NULL) additionally
+ * receives the activation [B,H,W,C] -- pass it when something else reads it later (a block's output is the next block's
+ * residual).  V and y are bit-identical to rn_winograd_output_transform followed by rn_winograd_input_transform(pad_lo = 1).
+ * scheme RN_WINO_F43 | RN_WINO_F63; act: 0 | RN_ACT_PRELU.  rn_winograd_output_input_supported says whether the tiling applies
+ * (C % 16 == 0, at most 32 tiles per row, ring of 3*m rows within the CU's LDS); otherwise run the two launches. */
+int rn_winograd_output_input_supported(int scheme, int H, int W, int C, int act);
+int rn_winograd_output_input_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                       float* y, float* V_next, int B, int H, int W, int C, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

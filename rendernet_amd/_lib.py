@@ -46,6 +46,8 @@ SIGNATURES = {
     "rn_conv2d_wino4_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_conv2d_transpose_s2_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_transpose_s2_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
+    "rn_winograd_output_input_supported": (_c_int, [_c_int] * 5),
+    "rn_winograd_output_input_transform": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 5 + [_c_vp]),
     "rn_conv3d_wino_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv3d_wino_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),
     "rn_fully_connected_fwd": (_c_int, [_c_vp] * 5 + [_c_int] * 4 + [_c_vp]),

@@ -455,6 +455,27 @@ extern "C" int rn_winograd_output_transform(int scheme, const float* M, const fl
     return rn_launch_wino_output(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, (hipStream_t)stream);
 }
 
+extern "C" int rn_winograd_output_input_supported(int scheme, int H, int W, int C, int act)
+{
+    static const bool off = getenv("RN_NO_WINO_OUTIN") != nullptr;
+    const int m = rn_wino_scheme_m(scheme);
+    if (off || m == 0 || scheme == RN_WINO_F44 || H < 1 || W < 1) return 0;
+    const int tw = (W + m - 1) / m;
+    return (C >= 16 && C % 16 == 0 && tw * 8 <= 256 && (size_t)3 * m * (tw * m + 2) * 16 * sizeof(float) <= (size_t)160 * 1024 &&
+            (act & ~RN_ACT_PRELU) == 0) ? 1 : 0;
+}
+extern "C" int rn_winograd_output_input_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                                  float* y, float* V_next, int B, int H, int W, int C, int act, void* stream)
+{
+    if (!M || !V_next) return rn_set_error(RN_E_INVALID, "rn_winograd_output_input_transform: null pointer");
+    if (B < 1 || !rn_winograd_output_input_supported(scheme, H, W, C, act))
+        return rn_set_error(RN_E_UNSUPPORTED, "rn_winograd_output_input_transform: scheme=%d H=%d W=%d C=%d act=%d does not fit the fused tiling",
+                            scheme, H, W, C, act);
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_winograd_output_input_transform: PReLU needs alpha");
+    const int rc = rn_launch_wino_outin(scheme, M, bias, alpha, residual, y, V_next, B, H, W, C, act, (hipStream_t)stream);
+    return rc == RN_E_UNSUPPORTED ? rn_set_error(RN_E_UNSUPPORTED, "rn_winograd_output_input_transform: not applicable") : rc;
+}
+
 extern "C" int rn_conv2d_wino43_wgrad_supported(int Cin, int Cout) { return rn_wino43_wgrad_supported(RN_WINO_F43, Cin, Cout) ? 1 : 0; }
 extern "C" int rn_conv2d_wino44_wgrad_supported(int Cin, int Cout) { return rn_wino43_wgrad_supported(RN_WINO_F44, Cin, Cout) ? 1 : 0; }
 static size_t wino4x_wgrad_ws(int scheme, int B, int H, int W, int Cin, int Cout)

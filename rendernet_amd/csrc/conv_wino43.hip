@@ -182,6 +182,136 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 3+1. output transform of one conv FUSED with the input transform of the NEXT conv of a res-block stack (inference):
+//     M_a [nxi][T][C]  ->  y = epilogue(A^T m A)  ->  V_b = B^T y B [nxi][T][C]        (res_block_2d, tools/layer_util.py:91-105:
+//     x + conv(prelu(conv(x))): conv1 -> conv2 inside a block, conv2 -> conv1 of the next block, ... -> the *_skip conv).
+// In the three-launch path the activation y is written by one launch and read straight back (with 1.45x halo re-reads) by
+// the next; here it stays in LDS: a workgroup owns (image, CG channels) and walks the tile rows of the image top to bottom;
+// per step it output-transforms tile row `it` into a ring of 3*M pixel rows (zero where the map ends: SAME padding), then
+// input-transforms tile row `it - 1`, whose (M+2)-row patches are now complete (last row of tile row it-2, tile row it-1,
+// first row of tile row it).  thread = (tile of the row, 2 channels), exactly the arithmetic of wino_output_kernel and
+// wino_input_kernel per element, so V_b and y are bit-identical to the unfused launches.  y goes to HBM only when the
+// caller needs it (the block output: the next block's residual); conv1 -> conv2 writes nothing but V_b.
+// Traffic per res-block (two convs, F63 on the 64x64x1024 maps at B=24): 3.85 GB instead of 5.42 GB.
+template <class S, int CG>
+__global__ __launch_bounds__(256)
+void wino_outin_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
+                       const float* __restrict__ res, float* __restrict__ y, float* __restrict__ V,
+                       int H, int W, int C, int th, int tw, long long T, int act, unsigned nwg, unsigned nblk8)
+{
+    typedef float vec __attribute__((ext_vector_type(2)));
+    constexpr int A = S::TA, MO = S::M, VW = 2, TPT = CG / VW, NR = 3 * MO;
+    extern __shared__ __attribute__((aligned(16))) float ysh[];           // [NR rows][cols][CG]
+    const int cols = tw * MO + 2;                                          // pixel columns -1 .. tw*MO
+    const unsigned L = xcd_contiguous(blockIdx.x, nblk8);                  // consecutive channel groups of an image share M lines: same XCD
+    const int ng = C / CG;
+    if (L >= nwg) return;
+    const int g = (int)(L % (unsigned)ng);
+    const long long b = L / (unsigned)ng;
+    const int tx = threadIdx.x / TPT, cv = threadIdx.x % TPT;
+    const bool active = tx < tw;
+    const int c0 = g * CG + cv * VW;
+    for (int i = threadIdx.x; i < NR * cols * CG / 4; i += blockDim.x) reinterpret_cast<f32x4*>(ysh)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)T * C;
+    const vec bv = bias ? *reinterpret_cast<const vec*>(bias + c0) : vec(0.f);
+    const vec av = (act & RN_ACT_PRELU) ? *reinterpret_cast<const vec*>(alpha + c0) : vec(0.f);
+    __syncthreads();
+    for (int it = 0; it <= th; ++it) {
+        if (it < th && active) {
+            // ---- output transform of tile (b, it, tx) -> ring rows (MO*it .. MO*it+MO-1) % NR
+            const long long t = (b * th + it) * tw + tx;
+            const float* mb = M + (size_t)t * C + c0;
+            vec s[MO][A];                                                   // (A^T m)[p][j]
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                vec m[A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) m[i] = *reinterpret_cast<const vec*>(mb + (size_t)(i * A + j) * plane);
+#pragma unroll
+                for (int p_ = 0; p_ < MO; ++p_) {
+                    vec acc = vec(0.f);
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        const float c = S::AT(p_, i);
+                        if (c != 0.f) acc += c * m[i];
+                    }
+                    s[p_][j] = acc;
+                }
+            }
+#pragma unroll
+            for (int p_ = 0; p_ < MO; ++p_) {
+                const int oy = MO * it + p_;
+                float* yrow = ysh + ((size_t)(oy % NR) * cols + MO * tx + 1) * CG + cv * VW;
+#pragma unroll
+                for (int q = 0; q < MO; ++q) {
+                    const int ox = MO * tx + q;
+                    vec v = bv;
+#pragma unroll
+                    for (int j = 0; j < A; ++j) {
+                        const float c = S::AT(q, j);
+                        if (c != 0.f) v += c * s[p_][j];
+                    }
+                    const bool inimg = oy < H && ox < W;
+                    if (act & RN_ACT_PRELU) {
+#pragma unroll
+                        for (int e = 0; e < VW; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
+                    }
+                    if (inimg) {
+                        const size_t off = (((size_t)b * H + oy) * W + ox) * C + c0;
+                        if (res) v += *reinterpret_cast<const vec*>(res + off);
+                        if (y) *reinterpret_cast<vec*>(y + off) = v;
+                    } else {
+                        v = vec(0.f);                                       // beyond the map: the next conv's SAME padding
+                    }
+                    *reinterpret_cast<vec*>(yrow + q * CG) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (it >= 1 && active) {
+            // ---- input transform of tile (b, it-1, tx): pixel rows MO*(it-1)-1 .. +A-1, columns MO*tx-1 .. (ring column MO*tx ..)
+            const int r = it - 1;
+            const long long t = (b * th + r) * tw + tx;
+            vec tt[A][A];                                                   // (B^T d)[i][col]
+#pragma unroll
+            for (int col = 0; col < A; ++col) {
+                vec d[A];
+#pragma unroll
+                for (int k = 0; k < A; ++k) {
+                    const int oy = MO * r - 1 + k;
+                    d[k] = (oy >= 0 && oy < MO * th)
+                         ? *reinterpret_cast<const vec*>(ysh + ((size_t)(oy % NR) * cols + MO * tx + col) * CG + cv * VW) : vec(0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    vec acc = vec(0.f);
+#pragma unroll
+                    for (int k = 0; k < A; ++k) {
+                        const float c = S::BT(i, k);
+                        if (c != 0.f) acc += c * d[k];
+                    }
+                    tt[i][col] = acc;
+                }
+            }
+            float* vb = V + (size_t)t * C + c0;
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+#pragma unroll
+                for (int j = 0; j < A; ++j) {
+                    vec acc = vec(0.f);
+#pragma unroll
+                    for (int k = 0; k < A; ++k) {
+                        const float c = S::BT(j, k);
+                        if (c != 0.f) acc += c * tt[i][k];
+                    }
+                    *reinterpret_cast<vec*>(vb + (size_t)(i * A + j) * plane) = acc;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 2. the GEMMs  M[xi] = V[xi] (T x Cin) . U[xi] (Cin x Cout), xi = 0 .. nxi-1
 struct W43GemmArgs {
     const float* V; const float* U; float* M;
@@ -553,6 +683,36 @@ int rn_launch_wino_output(int scheme, const float* M, const float* bias, const f
         hipLaunchKernelGGL((wino_output_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
                            H, W, C, th, tw, T, act, nblk8);
     return rn_check_launch("wino_output");
+}
+
+// The fused transform (wino_outin_kernel).  Returns RN_E_UNSUPPORTED without setting an error when the shape does not fit its
+// tiling (the caller then runs the two separate launches): channels not a multiple of 16, more than 32 tiles per row, a ring
+// beyond the CU's LDS, an epilogue other than bias / PReLU / residual.
+int rn_launch_wino_outin(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                         float* V, int B, int H, int W, int C, int act, hipStream_t st)
+{
+    static const bool off = getenv("RN_NO_WINO_OUTIN") != nullptr;
+    const int m = rn_wino_scheme_m(scheme);
+    if (off || m == 0 || scheme == RN_WINO_F44) return RN_E_UNSUPPORTED;
+    constexpr int CG = 16;
+    const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+    const long long T = (long long)B * th * tw;
+    const size_t lds = (size_t)3 * m * (tw * m + 2) * CG * sizeof(float);
+    if (C % CG != 0 || tw * (CG / 2) > 256 || lds > (size_t)160 * 1024 || (act & ~RN_ACT_PRELU) != 0) return RN_E_UNSUPPORTED;
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "wino_outin: PReLU needs alpha");
+    const unsigned nwg = (unsigned)((long long)B * (C / CG));
+    const unsigned nblk8 = (nwg + 7) / 8 * 8;
+    const unsigned threads = tw * (CG / 2) <= 128 ? 128u : 256u;
+    if (scheme == RN_WINO_F43) {
+        auto kern = wino_outin_kernel<WinoF43, CG>;
+        { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+        hipLaunchKernelGGL(kern, dim3(nblk8), dim3(threads), lds, st, M, bias, alpha, residual, y, V, H, W, C, th, tw, T, act, nwg, nblk8);
+    } else {
+        auto kern = wino_outin_kernel<WinoF63, CG>;
+        { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+        hipLaunchKernelGGL(kern, dim3(nblk8), dim3(threads), lds, st, M, bias, alpha, residual, y, V, H, W, C, th, tw, T, act, nwg, nblk8);
+    }
+    return rn_check_launch("wino_outin");
 }
 
 long long rn_wino43_plane_limit()

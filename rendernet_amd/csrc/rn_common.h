@@ -55,6 +55,8 @@ size_t rn_wino43_workspace_floats(int scheme, int B, int H, int W, int Cin, int 
 int rn_launch_wino_pack(int scheme, const float* w_tf, float* u, int Cin, int Cout, int transposed, hipStream_t st);
 int rn_launch_wino_input(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, hipStream_t st);
 int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, long long T, int Cin, int Cout, hipStream_t st);
+int rn_launch_wino_outin(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                         float* V, int B, int H, int W, int C, int act, hipStream_t st);   // RN_E_UNSUPPORTED (no message) = does not apply
 int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
                           float* preact, int B, int H, int W, int C, int act, hipStream_t st);
 int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const float* bias, const float* alpha, const float* residual,

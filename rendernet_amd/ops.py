@@ -660,6 +660,103 @@ def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 
     return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d_transpose", elu)
 
 
+def _res_stack_unfused(x, blocks, skip):
+    net = x
+    for pw1, b1, a1, pw2, b2 in blocks:
+        h = conv2d(net, pw1, b1, a1)
+        net = conv2d(h, pw2, b2, None, net)
+    if skip is not None:
+        net = conv2d(net, skip[0], skip[1], None, skip[2])
+    return net
+
+
+# Measured on MI355X (scripts/outin_bench.py, res2 shape, B=24, profiles/r03b_outin_bench.txt): conv1 -> conv2 fused 0.457 ms against
+# 0.202 + 0.210 ms for the two launches, conv2 -> conv1 (+ residual, + y) 1.106 against 0.315 + 0.210; whole step 114.5 against
+# 105.4 ms.  The ring of 18 pixel rows x 16 channels (78 KB) leaves two 128-thread workgroups per CU, i.e. one wave per SIMD:
+# the fused kernel is latency-bound at 2.1-3.3 TB/s where the separate launches stream at 5-5.8 TB/s with ~6 waves per SIMD.
+# Off by default (RN_RES_STACK_FUSION=1 turns it on); kept because it is bit-exact and tested, and for the measurement.
+RES_STACK_FUSED = bool(os.environ.get("RN_RES_STACK_FUSION"))
+RES_STACK_STATS = {"fused": 0, "unfused": 0}          # how many stacks took which path (tests; diagnostics)
+
+
+def res_stack_2d(x, blocks, skip=None):
+    """A stack of res_block_2d (tools/layer_util.py:91-105: x + conv(prelu(conv(x)))) and, optionally, the *_skip conv behind
+    it (conv(x_n) + skip residual; RenderNet_Shader.py:71-84, :91-99), 3x3 stride 1, C -> C throughout.
+        blocks: [(pw1, bias1, alpha1, pw2, bias2), ...]    skip: (pw, bias, residual tensor) | None
+    By default this is the loop over the per-layer launches.  With RES_STACK_FUSED (opt-in, see above: measured slower) inference
+    on the three-launch Winograd path runs the 2n+1 convs as ONE chain: input transform, then per conv the GEMM stage and --
+    instead of an output transform followed by the next conv's input transform -- the fused transform
+    (rn_winograd_output_input_transform): the activation between two convs never goes to HBM unless it is a block's output
+    (the next block's residual).  Values are bit-identical to the per-layer path."""
+    x = x.contiguous().float()
+    pws = [p for blk in blocks for p in (blk[0], blk[3])] + ([skip[0]] if skip is not None else [])
+    B, H, W, C = x.shape
+    lib = L.lib()
+    fused = (RES_STACK_FUSED and len(blocks) > 0 and not (TRAIN is not None and torch.is_grad_enabled()) and not torch.is_grad_enabled()
+             and WINO63_CHECK_TOL is None
+             and all(p.kind == L.RN_PACK_CONV and p.kdims == [3, 3] and p.cin == C and p.cout == C and _use_wino43(p, H, W) for p in pws))
+    which = None
+    if fused:
+        schemes = {_wino_scheme(p, H, W) for p in pws}
+        which = schemes.pop() if len(schemes) == 1 else None
+        scheme, nxi, m = {"f43": (L.RN_WINO_F43, 36, 4), "f63": (L.RN_WINO_F63, 64, 6)}.get(which, (None, 0, 1))
+        T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
+        fused = (scheme is not None and T * C * 4 < 0x7fffff00 and
+                 bool(lib.rn_winograd_output_input_supported(scheme, H, W, C, L.RN_ACT_PRELU)))
+    RES_STACK_STATS["fused" if fused else "unfused"] += 1
+    if not fused:
+        return _res_stack_unfused(x, blocks, skip)
+    _chk_dev(x)
+    st = L.stream_ptr()
+    ws = torch.empty(2 * nxi * T * C, dtype=torch.float32, device=x.device)
+    V, M = L.ptr(ws), ctypes.c_void_p(ws.data_ptr() + 4 * nxi * T * C)
+    u = (lambda p: p.wino63) if which == "f63" else (lambda p: p.wino43)
+
+    def layer(pw, first, fn):
+        """GEMM stage of `pw` + the transform behind it (fn), bracketed for bench.py like a per-layer launch."""
+        ev = LAUNCH_HOOK("conv2d", (B, H, W, C), pw) if LAUNCH_HOOK is not None else None
+        if ev is not None:
+            ev[0].record()
+        if first:
+            L.check(lib.rn_winograd_input_transform(scheme, L.ptr(x), V, B, H, W, C, 1, st), "rn_winograd_input_transform")
+        sev = STAGE_HOOK("gemm", (T, C, C, which)) if STAGE_HOOK is not None else None
+        if sev is not None:
+            sev[0].record()
+        L.check(lib.rn_winograd_gemm(scheme, V, L.ptr(u(pw)), M, T, C, C, st), "rn_winograd_gemm")
+        if sev is not None:
+            sev[1].record()
+        out = fn()
+        if ev is not None:
+            ev[1].record()
+        return out
+
+    def outin(bias, alpha, res, y, act):
+        L.check(lib.rn_winograd_output_input_transform(scheme, M, L.ptr(bias), L.ptr(alpha), L.ptr(res), L.ptr(y), V,
+                                                       B, H, W, C, act, st), "rn_winograd_output_input_transform")
+        return y
+
+    def out(bias, res):
+        y = torch.empty_like(x)
+        L.check(lib.rn_winograd_output_transform(scheme, M, L.ptr(bias), None, L.ptr(res), L.ptr(y), None, B, H, W, C, 0, st),
+                "rn_winograd_output_transform")
+        return y
+
+    cur = x                                   # the current block's input = its residual
+    for k, (pw1, b1, a1, pw2, b2) in enumerate(blocks):
+        _chk_dev(pw1.w_tf, b1, a1, pw2.w_tf, b2)
+        layer(pw1, k == 0, lambda: outin(b1, a1, None, None, L.RN_ACT_PRELU if a1 is not None else 0))
+        last = k == len(blocks) - 1
+        if last and skip is None:
+            return layer(pw2, False, lambda: out(b2, cur))
+        # a block's output is the next block's residual: it goes to HBM as well; the last block's (input of the skip conv only) does not
+        ynew = None if last else torch.empty_like(x)
+        layer(pw2, False, lambda: outin(b2, None, cur, ynew, 0))
+        cur = ynew
+    if skip[2] is not None and skip[2].shape != x.shape:
+        raise L.RenderNetHipError("res_stack_2d: skip residual shape %s != %s" % (tuple(skip[2].shape), tuple(x.shape)))
+    return layer(skip[0], False, lambda: out(skip[1], skip[2]))
+
+
 class _Projection(_ForwardOnly):
     @staticmethod
     def forward(ctx, x, pw, bias, alpha):

@@ -200,12 +200,8 @@ def RenderNet(models_in, is_training, prob=0.75, reuse=False, spec=None, taps=No
 
         enc4 = tap("enc4", projection_unit(enc3_skip))                                              # :67
 
-        net = enc4
-        for k in range(1, s.n_res2 + 1):                                                            # :71-80
-            net = res_block_2d(net, s.w_res2, scope='res2_%d' % k)
-        with st.variable_scope('res2_skip'):                                                        # :82-84
-            enc4_skip = LU.conv2d(net, s.w_res2, kernel_size=[3, 3], stride=[1, 1], scope="con1_3X3",
-                                  weight_initializer_type=xav(), residual=enc4, default_bias=0.0)
+        # :71-84 -- ten res_block_2d and the res2_skip conv + shortcut, as one Winograd chain at inference (ops.res_stack_2d)
+        enc4_skip = LU.res_stack_2d(enc4, s.w_res2, s.n_res2, 'res2_%d', skip_scope='res2_skip', skip_residual=enc4)
         tap("enc4_skip", enc4_skip)
 
         a5 = alpha_in('e_conv5', s.w5)
@@ -215,12 +211,7 @@ def RenderNet(models_in, is_training, prob=0.75, reuse=False, spec=None, taps=No
             enc5 = _dropout(enc5, kp)
         tap("enc5", enc5)
 
-        net = enc5
-        for k in range(1, s.n_res3 + 1):                                                            # :91-95
-            net = res_block_2d(net, s.w5, scope='res3_%d' % k)
-        with st.variable_scope('res3_skip'):                                                        # :97-99
-            enc5_skip = LU.conv2d(net, s.w5, kernel_size=[3, 3], stride=[1, 1], scope="con1_3X3",
-                                  weight_initializer_type=xav(), residual=enc5, default_bias=0.0)
+        enc5_skip = LU.res_stack_2d(enc5, s.w5, s.n_res3, 'res3_%d', skip_scope='res3_skip', skip_residual=enc5)   # :91-99
         tap("enc5_skip", enc5_skip)
 
         a6 = alpha_in('e_conv6', s.w6)

@@ -210,12 +210,8 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None, is
                                   weight_initializer_type=xav(), residual=enc3)
         tap("enc3_skip", enc3_skip)
         enc4 = tap("enc4", projection_unit(enc3_skip))
-        net = enc4
-        for i in range(1, s.n_res2 + 1):
-            net = res_block_2d(net, s.w_res2, scope='res2_%d' % i)
-        with st.variable_scope('res2_skip'):
-            enc4_skip = LU.conv2d(net, s.w_res2, kernel_size=[3, 3], stride=[1, 1], scope="con1_3X3",
-                                  weight_initializer_type=xav(), residual=enc4)
+        enc4_skip = LU.res_stack_2d(enc4, s.w_res2, s.n_res2, 'res2_%d', skip_scope='res2_skip', skip_residual=enc4,
+                                    skip_default_bias=0.001)
         tap("enc4_skip", enc4_skip)
         a5 = _alpha(st, 'e_conv5', s.w5)
         with st.variable_scope('e_conv5'):
@@ -223,12 +219,8 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None, is
                              weight_initializer_type=xav(), activation_alpha=a5)
             enc5 = _dropout(enc5, kp)
         tap("enc5", enc5)
-        net = enc5
-        for i in range(1, s.n_res3 + 1):
-            net = res_block_2d(net, s.w5, scope='res3_%d' % i)
-        with st.variable_scope('res3_skip'):
-            enc5_skip = LU.conv2d(net, s.w5, kernel_size=[3, 3], stride=[1, 1], scope="con1_3X3",
-                                  weight_initializer_type=xav(), residual=enc5)
+        enc5_skip = LU.res_stack_2d(enc5, s.w5, s.n_res3, 'res3_%d', skip_scope='res3_skip', skip_residual=enc5,
+                                    skip_default_bias=0.001)
         tap("enc5_skip", enc5_skip)
 
         outs = []

@@ -157,6 +157,35 @@ def res_block_2d(input, out_channels=64, scope='res_block', kernel=[3, 3], strid
     return net
 
 
+def res_stack_2d(input, out_channels, n_blocks, scope_fmt='res_%d', kernel=[3, 3], skip_scope=None, skip_residual=None,
+                 skip_default_bias=0.0, weight_dict=None):
+    """`n_blocks` res_block_2d in a row (scopes scope_fmt % 1 .. n_blocks) and, with `skip_scope`, the conv
+    `<skip_scope>/con1_3X3` + `skip_residual` behind them -- the loop of RenderNet_Shader.py:71-84 / :91-99 as one call, so that
+    the whole stack can run as one Winograd chain (ops.res_stack_2d).  Variables, names, initialisers and creation order are
+    exactly those of the loop over res_block_2d (tools/layer_util.py:91-121) followed by the skip conv."""
+    wd = weight_dict
+    st = _store()
+    blocks = []
+    for k in range(1, n_blocks + 1):
+        scope = scope_fmt % k
+        with st.variable_scope(scope):
+            alpha = _alpha_var(out_channels)
+            packs = []
+            for cs in ("con1_3X3", "conv2_3x3"):
+                w, wname, b = _conv_vars(cs, list(kernel) + [input.shape[-1], out_channels], True,
+                                         get_weight(scope + '_' + cs + '_weights', wd), get_weight(scope + '_' + cs + '_biases', wd),
+                                         xavier_initializer(), out_channels, 0.0)
+                packs.append((st.packed(wname, lambda w=w: ops.pack_conv(w)), b))
+            blocks.append((packs[0][0], packs[0][1], alpha, packs[1][0], packs[1][1]))
+    skip = None
+    if skip_scope is not None:
+        with st.variable_scope(skip_scope):
+            w, wname, b = _conv_vars("con1_3X3", list(kernel) + [input.shape[-1], out_channels], True, None, None,
+                                     xavier_initializer(), out_channels, skip_default_bias)
+            skip = (st.packed(wname, lambda: ops.pack_conv(w)), b, skip_residual)
+    return ops.res_stack_2d(input, blocks, skip)
+
+
 def projection_unit(input, n_features=18, scope='projection_unit'):
     """tools/layer_util.py:8-22: depth-flatten + 1x1 conv + PReLU as ONE kernel reading the 3-D
     tensor in place (rn_projection_fwd).  Variables: <scope>/Conv/{weights,biases}, <scope>/alpha."""

@@ -769,3 +769,78 @@ def test_conv2d_transpose_s2_winograd(case):
     p2.wino4 = None
     ref2 = ops.conv2d_transpose(xd, p2, bd, ad, rd, stride=(2, 2))
     assert float((got - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
+
+
+# The res_block_2d stack as one Winograd chain (ops.res_stack_2d; rn_winograd_output_input_transform): bit-equal to the per-layer
+# launches.  (B, H, W, C, blocks, with_skip): F(6x6,3x3) on 64x64 and on a ragged map, F(4x4,3x3) on the training crops' 32x32
+# and 16x16 maps, one block without a skip conv, wide tile rows (W = 100: 17 tiles -> 256-thread workgroups).
+RES_STACK_CASES = [
+    (2, 64, 64, 256, 2, True),
+    (1, 50, 38, 256, 1, True),
+    (3, 32, 32, 256, 2, True),
+    (2, 16, 16, 512, 1, False),
+    (1, 20, 100, 256, 1, True),
+    (1, 7, 5, 256, 2, True),
+]
+
+
+@pytest.mark.parametrize("case", RES_STACK_CASES)
+def test_res_stack_chain_is_bit_equal_to_the_layers(case, monkeypatch):
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, C, nb, with_skip = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = _dev(_rand(rng, B, H, W, C))
+    blocks = []
+    for _ in range(nb):
+        blocks.append((ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1), _dev(rng.uniform(0, 0.25, C).astype(np.float32)),
+                       ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1)))
+    skip = (ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1), x) if with_skip else None
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "RES_STACK_FUSED", False)
+        want = ops.res_stack_2d(x, blocks, skip)
+        monkeypatch.setattr(ops, "RES_STACK_FUSED", True)
+        n0 = ops.RES_STACK_STATS["fused"]
+        got = ops.res_stack_2d(x, blocks, skip)
+        assert ops.RES_STACK_STATS["fused"] == n0 + (1 if H * W >= ops.WINO43_MIN_PIXELS else 0)     # the chain really ran
+    assert torch.equal(got, want), float((got - want).abs().max())
+    # ... and against the oracle, so that "equal" is not "equally wrong"
+    ref = torch.from_numpy(x.cpu().numpy())
+    for pw1, b1, a1, pw2, b2 in blocks:
+        h = OL.prelu(OL.conv2d(ref, pw1.w_tf.cpu(), b1.cpu()), a1.cpu())
+        ref = ref + OL.conv2d(h, pw2.w_tf.cpu(), b2.cpu())
+    if with_skip:
+        ref = OL.conv2d(ref, skip[0].w_tf.cpu(), skip[1].cpu()) + torch.from_numpy(x.cpu().numpy())
+    _close(got, ref, "res stack vs oracle")
+
+
+def test_fused_transform_entry_matches_the_two_launches():
+    """rn_winograd_output_input_transform vs rn_winograd_output_transform + rn_winograd_input_transform on the same M: V and y
+    bit for bit (with / without PReLU, residual, y), and the `supported` predicate."""
+    import ctypes
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    for scheme, nxi, m in ((L.RN_WINO_F63, 64, 6), (L.RN_WINO_F43, 36, 4)):
+        for (B, H, W, C) in ((2, 64, 64, 64), (1, 13, 29, 32)):
+            th, tw = -(-H // m), -(-W // m)
+            T = B * th * tw
+            assert lib.rn_winograd_output_input_supported(scheme, H, W, C, 1) == 1
+            Mp = _dev(_rand(rng, nxi, T, C))
+            bias, alpha, res = _dev(_rand(rng, C) * 0.1), _dev(rng.uniform(0, 0.25, C).astype(np.float32)), _dev(_rand(rng, B, H, W, C))
+            for act, rs, want_y in ((1, None, False), (0, res, True), (1, res, True), (0, None, False)):
+                y1 = torch.empty((B, H, W, C), device="cuda")
+                V1 = torch.empty((nxi, T, C), device="cuda")
+                L.check(lib.rn_winograd_output_transform(scheme, L.ptr(Mp), L.ptr(bias), L.ptr(alpha), L.ptr(rs), L.ptr(y1), None,
+                                                         B, H, W, C, act, L.stream_ptr()), "out")
+                L.check(lib.rn_winograd_input_transform(scheme, L.ptr(y1), L.ptr(V1), B, H, W, C, 1, L.stream_ptr()), "in")
+                y2 = torch.full((B, H, W, C), 7.0, device="cuda")
+                V2 = torch.full((nxi, T, C), 7.0, device="cuda")
+                L.check(lib.rn_winograd_output_input_transform(scheme, L.ptr(Mp), L.ptr(bias), L.ptr(alpha), L.ptr(rs),
+                                                               L.ptr(y2) if want_y else None, L.ptr(V2), B, H, W, C, act, L.stream_ptr()), "outin")
+                assert torch.equal(V1, V2), (scheme, B, H, W, C, act, float((V1 - V2).abs().max()))
+                if want_y:
+                    assert torch.equal(y1, y2)
+    assert lib.rn_winograd_output_input_supported(L.RN_WINO_F63, 64, 64, 24, 1) == 0          # channels not a multiple of 16
+    assert lib.rn_winograd_output_input_supported(L.RN_WINO_F44, 64, 64, 256, 1) == 0
+    assert lib.rn_winograd_output_input_supported(L.RN_WINO_F63, 64, 64, 256, 2) == 0          # sigmoid: not a res-block epilogue
