@@ -50,7 +50,8 @@ def build_parser():
                         help='Flag rotate and render an object by 360 degree in azimuth. Overwrites early settings in azimuth.')
     # additions (not in the reference)
     parser.add_argument('--weights', type=str, default=None,
-                        help='.npz of weights keyed by TF variable names (default: seeded random initialisation)')
+                        help='.npz of weights keyed by TF variable names, or the reference\'s frozen graph `*.pb` '
+                             '(its Const nodes are read without TensorFlow); default: seeded random initialisation')
     parser.add_argument('--batch', type=int, default=24, help='poses rendered per launch with --rotate')
     parser.add_argument('--gif', type=str, default=None,
                         help='with --rotate: also write the 72 frames as an animated GIF to this path (the reference ships '
@@ -89,7 +90,12 @@ def main(argv=None):
     from rendernet_amd.tools import binvox_rw, Phong_shading
 
     spec = ShaderSpec(out_ch=3).check()                       # the demo graph has the 3-channel normal-map head
-    if args.weights:
+    if args.weights and args.weights.endswith(".pb"):
+        # the reference's frozen graph (RenderNet_demo.py:23-30, :111 `./model/3d2d_renderer.pb`, made by
+        # demo/RenderNet_converter.py): its variables are Const nodes under their TF names
+        from rendernet_amd.tools.graphdef import load_frozen_weights
+        weights = load_frozen_weights(args.weights, init_shader_weights(spec, seed=1234))
+    elif args.weights:
         weights = dict(np.load(args.weights))
     else:
         print("no --weights given: using seeded random weights (the reference ships no trained model)")

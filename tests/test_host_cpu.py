@@ -333,3 +333,83 @@ def test_state_dict_loading_skips_optimizer_state_and_seeds_mix():
     ops.seed_dropout(5, 9 << 16)
     assert ops.dropout_state() == (5, 9 << 16)
     ops.seed_dropout(0x5EED0FD50)
+
+
+def _pb_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_field(num, payload, wt=2):
+    if wt == 2:
+        return _pb_varint(num << 3 | 2) + _pb_varint(len(payload)) + payload
+    if wt == 0:
+        return _pb_varint(num << 3) + _pb_varint(payload)
+    raise ValueError(wt)
+
+
+def _pb_const_node(name, arr, how="content", op="Const"):
+    """A NodeDef as TensorFlow serializes a Const: name, op, attr{dtype}, attr{value: tensor}."""
+    import struct
+    dt = {np.dtype(np.float32): 1, np.dtype(np.int32): 3}[arr.dtype]
+    shape = b"".join(_pb_field(2, _pb_field(1, d, 0)) for d in arr.shape)
+    tensor = _pb_field(1, dt, 0) + _pb_field(2, shape)
+    if how == "content":
+        tensor += _pb_field(4, arr.astype("<" + arr.dtype.str[1:]).tobytes())
+    elif how == "packed":
+        tensor += _pb_field(5, struct.pack("<%df" % arr.size, *arr.ravel()))
+    elif how == "unpacked":
+        tensor += b"".join(_pb_varint(5 << 3 | 5) + struct.pack("<f", float(v)) for v in arr.ravel())
+    elif how == "splat":
+        tensor += _pb_field(5, struct.pack("<f", float(arr.ravel()[0])))
+    elif how == "ints":
+        tensor += _pb_field(7, b"".join(_pb_varint(int(v)) for v in arr.ravel()))
+    attr_value = _pb_field(5, _pb_field(1, b"value") + _pb_field(2, _pb_field(8, tensor)))
+    attr_dtype = _pb_field(5, _pb_field(1, b"dtype") + _pb_field(2, _pb_field(6, dt, 0)))
+    return _pb_field(1, name.encode()) + _pb_field(2, op.encode()) + attr_dtype + attr_value
+
+
+def test_frozen_graph_reader_decodes_const_nodes_without_tensorflow(tmp_path):
+    """rendernet_amd/tools/graphdef.py: the demo's frozen `.pb` (RenderNet_demo.py:23-30, :111; demo/RenderNet_converter.py) is a
+    GraphDef whose variables are Const nodes.  The test serializes a GraphDef itself -- protobuf wire format by hand: tensors as
+    tensor_content, packed / unpacked float_val, the one-value splat, an int32 constant, Identity and Placeholder nodes, the
+    `versions` field -- and reads it back."""
+    from rendernet_amd.tools.graphdef import read_graphdef_constants, load_frozen_weights, GraphDefError
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((3, 3, 4, 8)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    al = rng.standard_normal(8).astype(np.float32)
+    nodes = [
+        _pb_const_node("encoder/res2_1/con1_3X3/weights", w, "content"),
+        _pb_field(1, b"encoder/res2_1/con1_3X3/weights/read") + _pb_field(2, b"Identity") + _pb_field(3, b"encoder/res2_1/con1_3X3/weights"),
+        _pb_const_node("encoder/res2_1/con1_3X3/biases", b, "packed"),
+        _pb_const_node("encoder/res2_1/alpha", al, "unpacked"),
+        _pb_const_node("encoder/zeros", np.full((2, 5), 0.25, np.float32), "splat"),
+        _pb_const_node("encoder/Reshape/shape", np.array([-1, 64, 64, 1024], np.int32), "ints"),
+        _pb_field(1, b"real_model_in") + _pb_field(2, b"Placeholder"),
+    ]
+    graph = b"".join(_pb_field(1, n) for n in nodes) + _pb_field(4, _pb_field(1, 26, 0))         # + VersionDef{producer: 26}
+    path = tmp_path / "frozen.pb"
+    path.write_bytes(graph)
+    c = read_graphdef_constants(str(path))
+    assert sorted(c) == ["encoder/res2_1/alpha", "encoder/res2_1/con1_3X3/biases", "encoder/res2_1/con1_3X3/weights", "encoder/zeros"]
+    assert np.array_equal(c["encoder/res2_1/con1_3X3/weights"], w) and c["encoder/res2_1/con1_3X3/weights"].dtype == np.float32
+    assert np.array_equal(c["encoder/res2_1/con1_3X3/biases"], b) and np.array_equal(c["encoder/res2_1/alpha"], al)
+    assert np.array_equal(c["encoder/zeros"], np.full((2, 5), 0.25, np.float32))
+    ints = read_graphdef_constants(graph, float_only=False)["encoder/Reshape/shape"]
+    assert ints.tolist() == [-1, 64, 64, 1024]
+    want = {"encoder/res2_1/con1_3X3/weights": w, "encoder/res2_1/alpha": al}
+    got = load_frozen_weights(graph, want)
+    assert list(got) == list(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    with pytest.raises(GraphDefError, match="lacks"):
+        load_frozen_weights(graph, {"encoder/e_conv1/e_conv1/weights": np.zeros((5, 5, 5, 1, 8), np.float32)})
+    with pytest.raises(GraphDefError, match="shape"):
+        load_frozen_weights(graph, {"encoder/res2_1/alpha": np.zeros(16, np.float32)})
+    with pytest.raises(GraphDefError):
+        read_graphdef_constants(graph[:-3] + b"\xff\xff\xff")                                       # truncated / garbage tail
