@@ -319,6 +319,7 @@ struct W43GemmArgs {
     int Cin, Cout;
     int mblocks, nblocks, ksteps;   // 256-row blocks of T this launch walks (from mb_begin), 256-channel blocks, K steps of 32
     int mb_begin, parts;            // parts: BM-row parts of a block that are enumerated (4 / WM; fewer for the ragged last block)
+    int mrows;                      // rows between consecutive m-blocks: GBM, or BM itself when the whole of T is walked in BM-row items
     int item_begin, item_end;       // this launch's range of the items L = (xi*mblocks + mb - mb_begin)*nblocks + nb
     unsigned v_bytes, u_bytes, m_bytes;  // one xi plane of V; one (xi, n-block) panel of U; one xi plane of M
     int probe;                      // RN_WINO43_PROBE (timing experiments; results are wrong when set): 1 no DMA in the loop, 2 no stores, 4 no barrier
@@ -368,7 +369,7 @@ void wino43_gemm_kernel(const W43GemmArgs a)
         const int mbx = L / a.nblocks;
         const int mb = a.mb_begin + mbx % a.mblocks, xi = mbx / a.mblocks;
         it.nb = nb;
-        it.m0 = (long long)mb * GBM + h * BM;
+        it.m0 = (long long)mb * a.mrows + h * BM;
         it.vplane = a.V + (size_t)xi * a.T * a.Cin;
         it.upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.Cin * GBN);
         it.mplane = a.M + (size_t)xi * a.T * a.Cout;
@@ -626,7 +627,45 @@ int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, lo
     // rounds of half the length) or quarter items (64 rows) when that fills the machine better -- rem = 128: 256 half items =
     // half a round; rem = 176: 704 quarter items = 3 quarter rounds instead of a whole one
     static const bool notail = getenv("RN_WINO43_NOTAIL") != nullptr;
+    static const bool nouniform = getenv("RN_WINO43_NOUNIFORM") != nullptr;
     const int tag = scheme == RN_WINO_F44 ? 2 : scheme == RN_WINO_F63 ? (Cin >= 1024 ? 3 : 4) : Cin >= 1024 ? 0 : 1;
+    a.mrows = GBM;
+    // Few tiles (one GPU's share of a strongly scaled batch: 3 frames = 363 tiles of F63): whole blocks + a ragged tail are two
+    // launches of one item per CU each, all pipeline fill and drain.  When T is below two blocks, walk ALL of T in 128- or 64-row
+    // items instead -- one launch, several items per CU back to back (an item's last step prefetches the next item's first) --
+    // whenever that costs no more quarter rounds than the split plan.
+    static const int umax = getenv("RN_WINO43_UNIFORM_MAXFULL") ? atoi(getenv("RN_WINO43_UNIFORM_MAXFULL")) : 1;      // measurement
+    if (!notail && !nouniform && full <= umax) {
+        auto tail_cost = [](int rem) {                      // quarter rounds of a last, partial round of `rem` whole items
+            if (rem == 0) return 0;
+            const int half = (2 * rem + 255) / 256 * 2, quarter = (4 * rem + 255) / 256;
+            int c = 4;
+            if (half < c) c = half;
+            if (quarter < c) c = quarter;
+            return c;
+        };
+        const int nfull = nxi * full * a.nblocks;
+        int cost_split = nfull / 256 * 4 + tail_cost(nfull % 256);
+        if (ragged > 0) {
+            const int nit = nxi * a.nblocks;
+            int best = (nit + 255) / 256 * 4;
+            for (int wm = 2; wm >= 1; --wm) {
+                const int parts = (ragged + wm * 64 - 1) / (wm * 64), cost = (nit * parts + 255) / 256 * wm;
+                if (cost < best) best = cost;
+            }
+            cost_split += best;
+        }
+        int uwm = 0, ucost = cost_split + 1;
+        for (int wm = 2; wm >= 1; --wm) {
+            const long long items = (long long)nxi * a.nblocks * ((T + wm * 64 - 1) / (wm * 64));
+            const int cost = (int)((items + 255) / 256) * wm;
+            if (cost < ucost) { ucost = cost; uwm = wm; }
+        }
+        if (uwm != 0 && ucost <= cost_split) {
+            a.mb_begin = 0; a.mrows = uwm * 64; a.mblocks = (int)((T + a.mrows - 1) / a.mrows);
+            return wino43_gemm_launch(uwm, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
+        }
+    }
     if (full > 0) {
         a.mb_begin = 0; a.mblocks = full;
         const int nitems = nxi * full * a.nblocks;

@@ -299,6 +299,156 @@ void resample_concat_kernel(const ConcatArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Brick form of the Ca = 1, Cb = 4 case for DENSE volumes (the decoded texture volume is non-zero everywhere, so nothing can
+// be culled the way resample_tiled.hip culls empty space): a workgroup owns an 8 x 8 x 8 brick of output samples.  Its
+// source footprint is a rotated box of about 4 x 4 x 4 voxels (the 128^3 grid samples the 64^3 volume at half-voxel steps);
+// a box containing all its taps is staged in LDS once (<= 10^3 voxels x 20 B) with row-contiguous
+// loads, the 8 x 5 taps of every sample are then LDS reads instead of 16 divergent global gathers, and the results leave
+// through LDS as whole 160-byte line segments in 16-byte stores.  Same arithmetic per sample as resample_concat_kernel:
+// bit-identical.  A brick whose box does not fit (an extreme scale through the affine entry) gathers from global memory.
+// Measured (B=24, 64^3 -> 128^3, 1+4 channels): see DESIGN.md section 4.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int BRK = 8, BRK_MAXVOX = 1000;          // 10^3 voxels: 30 KB of LDS with the output stage -> five workgroups per CU
+}
+
+template <bool FROM_POSE>
+__global__ __launch_bounds__(256)
+void resample_concat_brick_kernel(const ConcatArgs a)
+{
+    __shared__ float msh_[12];
+    __shared__ float ga[BRK_MAXVOX];
+    __shared__ __attribute__((aligned(16))) float gb[BRK_MAXVOX * 4];
+    __shared__ __attribute__((aligned(16))) float ob[BRK * BRK * BRK * 5];
+    const int N = a.N, tid = threadIdx.x;
+    const int nbk = N / BRK, nbj = a.pw / BRK, nbi = a.ph / BRK;
+    int blk = blockIdx.x;
+    const int bk = blk % nbk; blk /= nbk;
+    const int bj = blk % nbj; blk /= nbj;
+    const int bi = blk % nbi;
+    const int b = blk / nbi;
+    // the matrix: with the affine entry 12 wave-uniform loads (no barrier); from a pose one lane's double-precision closed form
+    // (rendernet_amd.ops converts poses with rn_pose_to_affine first: one small launch instead of a ~2 us chain per brick)
+    float msh[12];
+    if (FROM_POSE) {
+        if (tid == 0) pose_to_affine_dev(a.mat + 3 * b, a.S, N, msh_);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 12; ++q) msh[q] = msh_[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) msh[q] = a.mat[12 * b + q];
+    }
+    const int mx = a.S - 1;
+    // the brick's sample (li, lj, lk) has grid coordinates gx = k, gy / gz from (i, j) as in resample_concat_kernel
+    auto grid_of = [&](int li, int lj, int lk, float& gx, float& gy, float& gz) {
+        const int i = bi * BRK + li + a.h0, j = bj * BRK + lj + a.w0;
+        gx = (float)(bk * BRK + lk);
+        gy = a.image_layout ? (float)(N - 1 - i) : (float)j;
+        gz = a.image_layout ? (float)j : (float)i;
+    };
+    // A box that CONTAINS all taps (a superset only stages a few more voxels): the coordinate is affine in the brick's local
+    // (li, lj, lk), so from the exact coordinate of sample (0, 0, 0) the extremes over the brick are at most the sums of the
+    // negative / positive axis contributions 7 * |m| away; 0.02 of slack covers the rounding of the per-sample chains (their
+    // error is ~1e-5 at these magnitudes).  ~40 instructions per thread instead of eight exact corner evaluations.
+    int blo[3], bhi[3];
+    {
+        float gx, gy, gz, hx, hy, hz;
+        grid_of(0, 0, 0, gx, gy, gz);
+        grid_of(BRK - 1, BRK - 1, BRK - 1, hx, hy, hz);
+        const float dx = hx - gx, dy = hy - gy, dz = hz - gz;          // +-7 along each grid axis
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float c0 = coord(msh[4 * r], msh[4 * r + 1], msh[4 * r + 2], msh[4 * r + 3], gx, gy, gz);
+            const float ex = msh[4 * r] * dx, ey = msh[4 * r + 1] * dy, ez = msh[4 * r + 2] * dz;
+            const float lo = c0 + fminf(ex, 0.f) + fminf(ey, 0.f) + fminf(ez, 0.f) - 0.02f;
+            const float hi = c0 + fmaxf(ex, 0.f) + fmaxf(ey, 0.f) + fmaxf(ez, 0.f) + 0.02f;
+            blo[r] = min(max((int)floorf(fminf(fmaxf(lo, -4.0f), (float)a.S + 4.0f)), 0), mx);
+            bhi[r] = min(max((int)floorf(fminf(fmaxf(hi, -4.0f), (float)a.S + 4.0f)) + 1, 0), mx);
+        }
+    }
+    const int bx0 = blo[0], by0 = blo[1], bz0 = blo[2], nx = bhi[0] - blo[0] + 1, ny = bhi[1] - blo[1] + 1, nz = bhi[2] - blo[2] + 1;
+    const bool fits = nx * ny * nz <= BRK_MAXVOX;
+    const size_t S3 = (size_t)a.S * a.S * a.S;
+    const float* pa = a.va + (size_t)b * S3;
+    const float* pb = a.vb_ + (size_t)b * S3 * 4;
+    if (fits) {
+        const int nvox = nx * ny * nz;
+        for (int v = tid; v < nvox; v += 256) {
+            const int xx = v % nx, r = v / nx;
+            const int yy = r % ny, zz = r / ny;
+            const size_t si = ((size_t)(bz0 + zz) * a.S + (by0 + yy)) * a.S + (bx0 + xx);
+            ga[v] = pa[si];
+            *reinterpret_cast<float4*>(gb + 4 * v) = *reinterpret_cast<const float4*>(pb + si * 4);
+        }
+    }
+    __syncthreads();
+    const int line = tid >> 2, li = line >> 3, lj = line & 7;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int lk = (tid & 3) * 2 + q;
+        float gx, gy, gz;
+        grid_of(li, lj, lk, gx, gy, gz);
+        const float x = coord(msh[0], msh[1], msh[2], msh[3], gx, gy, gz);
+        const float y = coord(msh[4], msh[5], msh[6], msh[7], gx, gy, gz);
+        const float z = coord(msh[8], msh[9], msh[10], msh[11], gx, gy, gz);
+        int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+        int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+        x0 = min(max(x0, 0), mx); x1 = min(max(x1, 0), mx);
+        y0 = min(max(y0, 0), mx); y1 = min(max(y1, 0), mx);
+        z0 = min(max(z0, 0), mx); z1 = min(max(z1, 0), mx);
+        const float ax = __fsub_rn((float)x1, x), bx = __fsub_rn(x, (float)x0);
+        const float ay = __fsub_rn((float)y1, y), by = __fsub_rn(y, (float)y0);
+        const float az = __fsub_rn((float)z1, z), bz = __fsub_rn(z, (float)z0);
+        const float w8[8] = {__fmul_rn(__fmul_rn(ax, ay), az), __fmul_rn(__fmul_rn(ax, by), az),
+                             __fmul_rn(__fmul_rn(bx, ay), az), __fmul_rn(__fmul_rn(bx, by), az),
+                             __fmul_rn(__fmul_rn(ax, ay), bz), __fmul_rn(__fmul_rn(ax, by), bz),
+                             __fmul_rn(__fmul_rn(bx, ay), bz), __fmul_rn(__fmul_rn(bx, by), bz)};
+        float ta[8];
+        float4 tb[8];
+        if (fits) {
+            const int sy = nx, sz = nx * ny;
+            const int X0 = x0 - bx0, X1 = x1 - bx0, Y0 = (y0 - by0) * sy, Y1 = (y1 - by0) * sy, Z0 = (z0 - bz0) * sz, Z1 = (z1 - bz0) * sz;
+            const int i8[8] = {Z0 + Y0 + X0, Z0 + Y1 + X0, Z0 + Y0 + X1, Z0 + Y1 + X1, Z1 + Y0 + X0, Z1 + Y1 + X0, Z1 + Y0 + X1, Z1 + Y1 + X1};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ta[e] = ga[i8[e]];
+                tb[e] = *reinterpret_cast<const float4*>(gb + 4 * i8[e]);
+            }
+        } else {
+            const int S2 = a.S * a.S;
+            const int i8[8] = {z0 * S2 + y0 * a.S + x0, z0 * S2 + y1 * a.S + x0, z0 * S2 + y0 * a.S + x1, z0 * S2 + y1 * a.S + x1,
+                               z1 * S2 + y0 * a.S + x0, z1 * S2 + y1 * a.S + x0, z1 * S2 + y0 * a.S + x1, z1 * S2 + y1 * a.S + x1};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ta[e] = pa[i8[e]];
+                tb[e] = *reinterpret_cast<const float4*>(pb + (size_t)i8[e] * 4);
+            }
+        }
+        float v0 = __fmul_rn(w8[0], ta[0]), v1 = __fmul_rn(w8[0], tb[0].x), v2 = __fmul_rn(w8[0], tb[0].y);
+        float v3 = __fmul_rn(w8[0], tb[0].z), v4 = __fmul_rn(w8[0], tb[0].w);
+#pragma unroll
+        for (int e = 1; e < 8; ++e) {
+            v0 = __fadd_rn(v0, __fmul_rn(w8[e], ta[e]));
+            v1 = __fadd_rn(v1, __fmul_rn(w8[e], tb[e].x));
+            v2 = __fadd_rn(v2, __fmul_rn(w8[e], tb[e].y));
+            v3 = __fadd_rn(v3, __fmul_rn(w8[e], tb[e].z));
+            v4 = __fadd_rn(v4, __fmul_rn(w8[e], tb[e].w));
+        }
+        float* o = ob + (line * BRK + lk) * 5;
+        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
+    }
+    __syncthreads();
+    // 64 lines x 40 floats: whole 160-byte segments, 16-byte stores
+    for (int t = tid; t < BRK * BRK * 10; t += 256) {
+        const int ln = t / 10, f = t - ln * 10;
+        const int i = bi * BRK + (ln >> 3), j = bj * BRK + (ln & 7);
+        float* op = a.out + ((((size_t)b * a.ph + i) * a.pw + j) * N + (size_t)bk * BRK) * 5;
+        reinterpret_cast<float4*>(op)[f] = *reinterpret_cast<const float4*>(ob + ln * 40 + f * 4);
+    }
+}
+
 extern "C" int rn_resample_concat_fwd(const float* vox_a, int Ca, const float* vox_b, int Cb, const float* pose_or_m_inv,
                                       int affine, float* out, int B, int S, int N, int h0, int w0, int ph, int pw,
                                       int image_layout, void* stream)
@@ -318,6 +468,15 @@ extern "C" int rn_resample_concat_fwd(const float* vox_a, int Ca, const float* v
     if (nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "rn_resample_concat_fwd: grid too large");
     ConcatArgs a{vox_a, vox_b, pose_or_m_inv, out, B, S, N, Ca, Cb, h0, w0, ph, pw, image_layout};
     const bool fast = Ca == 1 && Cb == 4 && (((uintptr_t)vox_b | (uintptr_t)out) & 15) == 0;
+    static const bool no_brick = getenv("RN_RESAMPLE_NO_BRICK") != nullptr;
+    if (fast && !no_brick && N % BRK == 0 && ph % BRK == 0 && pw % BRK == 0) {
+        const long long nbr = (long long)B * (ph / BRK) * (pw / BRK) * (N / BRK);
+        if (nbr <= 0x7fffffffLL) {
+            if (affine) hipLaunchKernelGGL(resample_concat_brick_kernel<false>, dim3((unsigned)nbr), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL(resample_concat_brick_kernel<true>, dim3((unsigned)nbr), dim3(256), 0, (hipStream_t)stream, a);
+            return rn_check_launch("rn_resample_concat_fwd (brick)");
+        }
+    }
     if (affine && fast) hipLaunchKernelGGL((resample_concat_kernel<false, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
     else if (affine) hipLaunchKernelGGL((resample_concat_kernel<false, false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
     else if (fast) hipLaunchKernelGGL((resample_concat_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);

@@ -275,7 +275,9 @@ class _ResampleConcat(torch.autograd.Function):
         ev = LAUNCH_HOOK("resample", (B, S, S, S, Ca + Cb), None) if LAUNCH_HOOK is not None else None
         if ev is not None:
             ev[0].record()
-        L.check(L.lib().rn_resample_concat_fwd(L.ptr(vox_a), Ca, L.ptr(vox_b), Cb, L.ptr(pose), 1 if affine else 0, L.ptr(out),
+        # poses become matrices in one small launch (the same closed form the kernel would evaluate per workgroup)
+        m = pose if affine else pose_to_affine(pose, S, N)
+        L.check(L.lib().rn_resample_concat_fwd(L.ptr(vox_a), Ca, L.ptr(vox_b), Cb, L.ptr(m), 1, L.ptr(out),
                                                B, S, N, h0, w0, ph, pw, 1 if image_layout else 0, L.stream_ptr()),
                 "rn_resample_concat_fwd")
         if ev is not None:

@@ -190,3 +190,45 @@ def test_concat_resampler_equals_two_resamplers_and_their_gradients():
     torch.cat([ops.resample(a2, p2, N), ops.resample(b2, p2, N)], dim=4).backward(g)
     for x, y, name in ((a1.grad, a2.grad, "dvox_a"), (b1.grad, b2.grad, "dvox_b"), (p1.grad, p2.grad, "dpose")):
         assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max()) + 1e-6, name      # atomics: order differs
+
+
+def test_concat_resampler_brick_form_full_size_and_extreme_boxes(fixtures_vox):
+    """The brick form of rn_resample_concat_fwd (8^3-output bricks, the taps' bounding box staged in LDS) at the face
+    renderer's size (64^3 -> 128^3, geometry + dense 4-channel volume): bit-identical to the two separate resampler calls
+    for the bench poses, for scales whose source box overflows the LDS box (0.2: a brick spans ~20 voxels -> the global
+    gather branch) or collapses (3.0), for volumes entirely off one side (taps clamp to the border plane), through the
+    affine entry, and for a window that is not a multiple of 8 (the line-per-thread kernel)."""
+    from rendernet_amd import ops
+    rng = np.random.default_rng(5)
+    geo = torch.as_tensor(np.ascontiguousarray(fixtures_vox[[1, 3]])).cuda()
+    tex = torch.as_tensor(rng.standard_normal((2, 64, 64, 64, 4)).astype(np.float32)).cuda()
+    poses = [[250 * np.pi / 180, 30 * np.pi / 180, 1.0], [0.3, 1.2, 0.85], [2.0, 0.1, 0.2], [4.0, 0.6, 3.0], [1.0, 0.5, 1.14]]
+    for k in range(0, len(poses) - 1):
+        pose = torch.as_tensor(np.array(poses[k:k + 2], np.float32)).cuda()
+        for window in (None, (40, 8, 64, 96), (3, 5, 30, 28)):
+            got = ops.resample_concat(geo, tex, pose, 128, window)
+            want = torch.cat([ops.resample(geo, pose, 128, window), ops.resample(tex, pose, 128, window)], dim=4)
+            assert torch.equal(got, want), (k, window)
+    m = ops.pose_to_affine(torch.as_tensor(np.array(poses[:2], np.float32)).cuda(), 64, 128)
+    m[1, :, 3] += 90.0                                                # the whole volume off one side: every tap clamps
+    got = ops.resample_concat(geo, tex, m, 128, None, True, True)
+    want = torch.cat([ops.resample(geo, m, 128, None, True, True), ops.resample(tex, m, 128, None, True, True)], dim=4)
+    assert torch.equal(got, want)
+
+
+def test_concat_entry_from_pose_equals_the_affine_form():
+    """ops.resample_concat turns poses into matrices with rn_pose_to_affine first; the C entry fed the poses themselves
+    (affine = 0: the closed form evaluated inside the kernel) writes the same bits."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    rng = np.random.default_rng(2)
+    B, S, N = 2, 16, 32
+    va = torch.as_tensor((rng.random((B, S, S, S, 1)) < 0.3).astype(np.float32)).cuda()
+    vb = torch.as_tensor(rng.standard_normal((B, S, S, S, 4)).astype(np.float32)).cuda()
+    pose = torch.as_tensor(np.array([[250 * np.pi / 180, 30 * np.pi / 180, 1.0], [1.0, 0.7, 0.9]], np.float32)).cuda()
+    want = ops.resample_concat(va, vb, pose, N)
+    for (h0, w0, ph, pw) in ((0, 0, N, N), (1, 2, 30, 16)):              # brick form / line-per-thread form
+        got = torch.empty((B, ph, pw, N, 5), device="cuda")
+        L.check(L.lib().rn_resample_concat_fwd(L.ptr(va), 1, L.ptr(vb), 4, L.ptr(pose), 0, L.ptr(got), B, S, N, h0, w0, ph, pw, 1,
+                                               L.stream_ptr()), "rn_resample_concat_fwd")
+        assert torch.equal(got, want[:, h0:h0 + ph, w0:w0 + pw])
