@@ -1,0 +1,40 @@
+#!/bin/bash
+# Everything the round's evidence under profiles/ comes from, in one pass on the GPU box (copy gpurun_out/$TAG_* to profiles/):
+#   bench lines of the four modes (un-profiled), rocprofv3 per-shape tables of render / texture / train, the batch sweep,
+#   the stage A/B and 3-D layer timings.   usage: gpurun -- "bash scripts/round_measure.sh r03c"
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-rXX}
+O=$R/gpurun_out
+mkdir -p "$O"
+cd "$R"
+python bench.py --steps 20 --warmup 3 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err"
+python bench.py --mode texture --steps 20 --warmup 3 > "$O/${TAG}_bench_texture.json" 2>> "$O/${TAG}_bench.err"
+python bench.py --mode stress --steps 5 --warmup 2 > "$O/${TAG}_bench_stress.json" 2>> "$O/${TAG}_bench.err"
+python bench.py --mode train --steps 10 --warmup 3 > "$O/${TAG}_bench_train.json" 2>> "$O/${TAG}_bench.err"
+RN_NO_WINOGRAD63=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$O/${TAG}_bench_f43only.json" 2>> "$O/${TAG}_bench.err"
+{
+  echo "# python bench.py --batch B --steps 10 --warmup 3 --no-cpu-baseline, one MI355X, git ${GIT_REV:-?}"
+  for b in 1 3 6 12 24 48; do
+    python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('batch %3d  %8.2f frames/s  %8.2f ms/step  GEMM-stage frac %.3f' % ($b, d['value'], d['ms_per_step'], d['roofline']['frac']))"
+  done
+} > "$O/${TAG}_batch_sweep.txt"
+{
+  echo "# scripts/wino_stage_bench.py / res1_bench.py / outin_bench.py, one MI355X, git ${GIT_REV:-?}"
+  python scripts/wino_stage_bench.py --shapes 64x1024,64x512 --batch 24 2>&1 | grep -v amdgpu.ids
+  python scripts/res1_bench.py 2>&1 | grep -v amdgpu.ids
+  for l in e_conv7 e_conv8 e_conv9; do
+    RN_NO_WINOGRAD_S2=1 python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (direct phase kernels)/'
+    python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (F(2x2,2x2) per phase)/'
+  done
+} > "$O/${TAG}_stage_ab.txt"
+bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_texture --mode texture --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+tail -3 "$O/${TAG}_bench.err"
+cut -c1-250 "$O/${TAG}_bench.json"
+cat "$O/${TAG}_batch_sweep.txt"
