@@ -146,7 +146,7 @@ __device__ __forceinline__ void wino_block(const WinoArgs& a, int id, int wave, 
 
 // PROBE (measurement switches, RN_WINO_PROBE; 0 = the product kernel): 1 = skip the input transform (wrong results),
 // 2 = no DMA inside the loop (wrong results), 4 = input transform with plain v_add/v_sub instead of v_pk_add_f32,
-// 8 = all DMAs of a step at its top instead of interleaved with the MFMAs.
+// 8 = all DMAs of a step at its top instead of interleaved with the MFMAs, 64 = no epilogue, 128 = no per-step barrier.
 //
 // Persistent: the grid is one workgroup per CU; workgroup g works on items g, g + G, g + 2G, ...  The K loop runs
 // straight across item boundaries: during the LAST step of an item the first step of the NEXT item is fetched into the
@@ -312,11 +312,19 @@ void conv_wino_kernel(const WinoArgs a)
             }
             if (!last) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                if (!(PROBE & 128)) __syncthreads();              // measurement: 128 = no barrier between the steps (wrong results)
                 stage = st1;
             }
         }
-        {
+        if (PROBE & 64) {                                      // measurement: no epilogue at all (wrong results)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f32x4 keep_ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i_ = 0; i_ < NXI; ++i_)
+#pragma unroll
+                for (int nt_ = 0; nt_ < NT; ++nt_) { keep_ += acc[i_][nt_]; acc[i_][nt_] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (a.B < 0) *reinterpret_cast<f32x4*>(a.y) = keep_;      // never taken: keeps the MFMAs alive
+        } else {
         // epilogue of the finished item (its successor's first step is in flight).  C/D layout of the 16x16 MFMA with the
         // filter as A: row = 4*(lane>>4) + r = channel within the 16-wide n-tile, col = lane&15 = the tile's tx: a lane
         // holds channels 4kq..4kq+3 of tile (ty, tx) = (wave, l16) -> 16-B loads and stores, 128 contiguous bytes per pixel
@@ -528,6 +536,9 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
         case 3: return wino_launch<3, 2, 0>(a, grid, st);
         case 4: return wino_launch<4, 2, 0>(a, grid, st);
         case 8: return wino_launch<8, 2, 0>(a, grid, st);
+        case 64: return wino_launch<64, 2, 0>(a, grid, st);     // no epilogue
+        case 67: return wino_launch<67, 2, 0>(a, grid, st);     // no transform, no DMA in the loop, no epilogue
+        case 195: return wino_launch<195, 2, 0>(a, grid, st);   // ... and no per-step barrier: the MFMA loop + fragment reads alone
         default: return wino_launch<0, 2, 0>(a, grid, st);
     }
 }
