@@ -362,6 +362,158 @@ void conv_stem_kernel(const TiledArgs2 a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_stem_dc_kernel: conv_stem_kernel with the depth axis cut into chunks of DCH = 16*NPOS outputs PER WORKGROUP.
+// PMC on conv_stem_kernel<5,8,16> (texture net stem, B=24): vector ALU 33 % busy, LDS 33 % busy (54 % of that bank
+// conflicts), 38 % of the wave cycles waiting -- with 98 KB of staged rows there is one workgroup = one wave per SIMD on a CU
+// and nothing to hide its LDS / staging latency behind.  Here a workgroup stages only the row SEGMENTS its 32 output depths
+// touch (72 positions instead of 140: 51 KB + the 20 KB filter), a lane owns NPOS = 2 consecutive outputs, and TWO 256-thread
+// workgroups fit a CU.  Same arithmetic per output (same tap order): bit-identical to conv_stem_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN, int CO, int RPW, int NPOS>
+__global__ __launch_bounds__(RPW * 16, 2)
+void conv_stem_dc_kernel(const TiledArgs2 a)
+{
+    constexpr int K = 5, S = 2, NROW = (RPW - 1) * S + K;
+    constexpr int NTH = RPW * 16, NW = RPW / 4;
+    constexpr int DCH = 16 * NPOS;                                   // output depths per workgroup
+    constexpr int WIN = ((NPOS - 1) * S + K) * CIN;                  // a lane's window in a staged row (floats)
+    constexpr int NPS = ((DCH - 1) * S + K + 3 + 3) / 4 * 4;         // staged positions per row: the chunk's span + alignment slack, multiple of 4
+    constexpr int ROWLEN = NPS * CIN, PITCH = ROWLEN | 1;            // odd pitch: the rows of a wave start in different banks
+    constexpr int KTOT = K * K * K * CIN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                      // [KTOT][CO]
+    float* rows = wl + KTOT * CO;                                    // [NROW][PITCH]
+    int* flags = reinterpret_cast<int*>(rows + NROW * PITCH);        // [NROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int blk = blockIdx.x;
+    const int nch = (a.O2 + DCH - 1) / DCH;
+    const int ch = blk % nch; blk /= nch;
+    const int ng = (a.O1 + RPW - 1) / RPW;
+    const int g = blk % ng; blk /= ng;
+    const int o0 = blk % a.O0; const int b = blk / a.O0;
+    const int rl = wave * 4 + (lane >> 4);
+    const int o1 = g * RPW + rl;
+    const int c0 = ch * DCH;                                          // first output depth of the chunk
+    // first staged position: 2*c0 - P2 rounded down to a multiple of 4 (so that segment and row ends fall on 16-byte pieces;
+    // the launcher checks I2 % 4 == 0).  May be negative: pieces outside [0, I2) stay zero = SAME padding.
+    const int pstart = ((c0 * S - a.P2) & ~3);
+    for (int i = tid; i < KTOT * CO; i += NTH) {
+        const int k = i / CO, n = i % CO;
+        wl[i] = (n < a.Cout) ? a.w[((size_t)(k >> 2) * a.Npad + n) * 4 + (k & 3)] : 0.f;
+    }
+    constexpr int NF4 = ROWLEN / 4;                                   // 16-byte pieces of a staged segment
+    const int o2 = c0 + (lane & 15) * NPOS;                           // first of this lane's outputs
+    const int w0 = (o2 * S - a.P2 - pstart) * CIN;                    // its window's first float in a staged row (>= 0, + WIN <= ROWLEN)
+    float acc[NPOS][CO];
+#pragma unroll
+    for (int q = 0; q < NPOS; ++q)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[q][n] = 0.f;
+    for (int k0 = 0; k0 < K; ++k0) {
+        const int i0 = o0 * S - a.P0 + k0;
+        if ((unsigned)i0 >= (unsigned)a.I0) continue;                 // uniform per workgroup
+        __syncthreads();                                              // the previous plane's rows are consumed
+        if (tid < NROW) flags[tid] = 0;
+        __syncthreads();
+        {
+            const int nrw = (NROW - wave + NW - 1) / NW;              // rows of this wave
+            const int total = nrw * NF4;
+            const float* xp = a.x + (((size_t)b * a.I0 + i0) * a.I1) * a.I2 * CIN;
+            for (int base = 0; base < total; base += 64 * 8) {
+                f32x4s v[8]; int dst[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 64 + lane;
+                    dst[u] = -1;
+                    v[u] = f32x4s{0.f, 0.f, 0.f, 0.f};
+                    if (idx < total) {
+                        const int r = idx / NF4, f = idx - r * NF4;
+                        const int j = wave + NW * r;
+                        const int i1 = g * RPW * S - a.P1 + j;
+                        const int gf = pstart * CIN + f * 4;          // first float of this piece in the global row
+                        dst[u] = j * PITCH + f * 4;
+                        if ((unsigned)i1 < (unsigned)a.I1 && gf >= 0 && gf + 3 < a.I2 * CIN)
+                            v[u] = *reinterpret_cast<const f32x4s*>(xp + (size_t)i1 * a.I2 * CIN + gf);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (dst[u] >= 0) {
+                        float* d = rows + dst[u];
+                        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+                        if (v[u][0] != 0.f || v[u][1] != 0.f || v[u][2] != 0.f || v[u][3] != 0.f)
+                            flags[dst[u] / PITCH] = 1;                // benign race: every writer stores 1
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < K; ++k1) {
+            const int j = rl * S + k1;
+            if (!__any(flags[j] != 0)) continue;                      // all four rows of this wave are empty here
+            const float* xr = rows + j * PITCH + w0;
+            float xw[WIN];
+#pragma unroll
+            for (int e = 0; e < WIN; ++e) xw[e] = xr[e];
+            const float* wr = wl + (size_t)((k0 * K + k1) * K) * CIN * CO;
+#pragma unroll
+            for (int e = 0; e < K * CIN; ++e) {
+                float wv[CO];
+#pragma unroll
+                for (int n = 0; n < CO; ++n) wv[n] = wr[e * CO + n];
+#pragma unroll
+                for (int q = 0; q < NPOS; ++q) {
+                    const float xv = xw[q * S * CIN + e];
+#pragma unroll
+                    for (int n = 0; n < CO; ++n) acc[q][n] = fmaf(xv, wv[n], acc[q][n]);
+                }
+            }
+        }
+    }
+    if (o1 < a.O1) {
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            if (o2 + q >= a.O2) break;
+            const size_t oo = ((((size_t)b * a.O0 + o0) * a.O1 + o1) * a.O2 + o2 + q) * a.Cout;
+#pragma unroll
+            for (int n = 0; n < CO; ++n) {
+                if (n < a.Cout) {
+                    float v = acc[q][n] + (a.bias ? a.bias[n] : 0.f);
+                    if (a.z) a.z[oo + n] = v;
+                    if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+                    if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
+                    if (a.res) v += a.res[oo + n];
+                    if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                    a.y[oo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int CO, int RPW, int NPOS>
+static int launch_stem_dc(const RnConvProblem& p, hipStream_t st)
+{
+    TiledArgs2 a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
+    a.B = p.B; a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = p.I[2]; a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = p.O[2];
+    a.Cout = p.Cout; a.Npad = p.Npad; a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = p.P[2];
+    a.nt0 = a.nt1 = a.nt2 = 0; a.act = p.act;
+    constexpr int DCH = 16 * NPOS, NROW = (RPW - 1) * 2 + 5;
+    constexpr int NPS = ((DCH - 1) * 2 + 5 + 3 + 3) / 4 * 4, PITCH = (NPS * CIN) | 1;
+    const long long nb = (long long)p.B * p.O[0] * ((p.O[1] + RPW - 1) / RPW) * ((p.O[2] + DCH - 1) / DCH);
+    if (nb <= 0 || nb > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_stem_dc: bad grid %lld", nb);
+    const size_t lds = ((size_t)125 * CIN * CO + (size_t)NROW * PITCH) * sizeof(float) + NROW * sizeof(int);
+    // 16-byte pieces must not straddle a row end, windows must stay inside the staged segment (pad_before <= 3)
+    if (lds > 80 * 1024 || p.I[2] % 4 != 0 || (p.I[2] * CIN) % 4 != 0 || p.P[2] > 3 || (reinterpret_cast<size_t>(p.x) & 15) != 0) return RN_E_UNSUPPORTED;
+    auto kern = conv_stem_dc_kernel<CIN, CO, RPW, NPOS>;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(RPW * 16), lds, st, a);
+    return rn_check_launch("conv_stem_dc");
+}
+
 template <int CIN, int CO, int RPW>
 static int launch_stem(const RnConvProblem& p, hipStream_t st)
 {
@@ -406,6 +558,13 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     // conv_rows_kernel (four outputs per thread, row windows read straight from global memory) 4.9 ms, conv_stem_kernel
     // (rows staged in LDS by whole-row loads, below) 2.45 ms on dense input -- less on the mostly empty resampled grid
     static const bool no_stem = getenv("RN_NO_STEM_KERNEL") != nullptr;
+    static const bool no_stem_dc = getenv("RN_NO_STEM_DC") != nullptr;
+    if (!no_stem && !no_stem_dc && k555s2 && p.Cout == 8 && p.Cin == 5) {       // depth-chunked: two workgroups per CU
+        // measured (B=24, dense input): 16 rows x 32 depths, 2 outputs per lane 1.66-1.69 ms; 1 output per lane (three
+        // workgroups per CU, half the filter reuse) 1.80; 8 rows x 32 depths 2.06; conv_stem_kernel (one workgroup per CU) 2.42
+        const int rc = launch_stem_dc<5, 8, 16, 2>(p, st);
+        if (rc != RN_E_UNSUPPORTED) return rc;
+    }
     if (!no_stem && k555s2 && p.Cout == 8 && p.Cin == 5 && p.P[2] <= 2 && (p.O[2] - 1) * 2 - p.P[2] + 4 <= p.I[2] + 1) {             // row-staged stem (conv_stem_kernel)
         static const int rpw = getenv("RN_STEM_RPW") ? atoi(getenv("RN_STEM_RPW")) : 16;
         const int rc = rpw == 16 ? launch_stem<5, 8, 16>(p, st) : rpw == 4 ? launch_stem<5, 8, 4>(p, st) : launch_stem<5, 8, 8>(p, st);
