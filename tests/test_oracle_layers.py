@@ -148,3 +148,20 @@ def test_conv_matches_scipy_correlate(shape, k, s):
                 acc = acc + correlate(xp[b, ..., c], w[..., c, n].astype(np.float64), mode="valid")
             want[b, ..., n] = acc[tuple(slice(None, None, s[d]) for d in range(nd))]
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_tf_conv2d_documentation_example():
+    """The worked example of the `tf.nn.conv2d` API documentation (TF 2.x docstring: a 5x5x1 image, a [2,2,1,2] filter, VALID
+    padding, 4x4x2 result).  TensorFlow cannot be run or fetched in this container, so the numbers below are typed in from
+    memory of that page -- NOT a pin of the oracle against TensorFlow, only a check of the two conventions the example
+    exercises: tf.nn.conv2d is a cross-correlation (no filter flip) and the filter layout is [kh, kw, Cin, Cout].  Every value
+    is also a sum one can do by hand, e.g. out[3,1,0] = 2*2 + 3*0 + 0*0 + 1*3 = 7.  The oracle's conv is SAME-padded; for a
+    2x2 filter SAME pads only after the last row / column, so its top-left 4x4 block is the VALID result."""
+    x = np.array([[[[2], [1], [2], [0], [1]], [[1], [3], [2], [2], [3]], [[1], [1], [3], [3], [0]],
+                   [[2], [2], [0], [1], [1]], [[0], [0], [3], [1], [2]]]], np.float32)
+    k = np.array([[[[2, 0.1]], [[3, 0.2]]], [[[0, 0.3]], [[1, 0.4]]]], np.float32)
+    want = np.array([[[10, 1.9], [10, 2.2], [6, 1.6], [6, 2.0]], [[12, 1.4], [15, 2.2], [13, 2.7], [13, 1.7]],
+                     [[7, 1.7], [11, 1.3], [16, 1.3], [7, 1.0]], [[10, 0.6], [7, 1.4], [4, 1.5], [7, 1.4]]], np.float32)
+    got = OL.conv2d(x, k, None, (1, 1)).numpy()
+    assert got.shape == (1, 5, 5, 2)
+    assert np.abs(got[0, :4, :4] - want).max() <= 1e-6
