@@ -413,3 +413,40 @@ def test_frozen_graph_reader_decodes_const_nodes_without_tensorflow(tmp_path):
         load_frozen_weights(graph, {"encoder/res2_1/alpha": np.zeros(16, np.float32)})
     with pytest.raises(GraphDefError):
         read_graphdef_constants(graph[:-3] + b"\xff\xff\xff")                                       # truncated / garbage tail
+
+
+def test_bench_golden_parity_indexing_and_per_rank_fields():
+    """bench.py's self-check against the committed oracle renders (tests/golden/*.npz): an output assembled FROM the goldens
+    passes with error 0, a perturbed one fails, frames a rank does not hold are not counted -- for the render, texture and
+    stress lines; per_rank_fields aggregates min / mean / max."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    z = np.load(os.path.join(ROOT, "tests", "golden", "bench_frames.npz"))
+    out = torch.zeros((24, 512, 512, 1))
+    for k, f in enumerate(z["frames"].tolist()):
+        for c, (r0, c0) in enumerate(z["crops"].tolist()):
+            out[f, r0:r0 + 128, c0:c0 + 128, 0] = torch.from_numpy(z["output_%d" % k][c])
+    rec = bench.golden_parity("render", out, list(range(24)))
+    assert rec["ok"] and rec["max_abs_err"] == 0.0 and rec["frames"] == [0, 6, 12, 18, 9]
+    rec3 = bench.golden_parity("render", out[:3], [0, 1, 2])                      # an 8-way strong split: rank 0 holds frames 0-2
+    assert rec3["ok"] and rec3["frames"] == [0]
+    assert bench.golden_parity("render", out[1:3], [1, 2]) is None               # no golden frame held: no record
+    bad = out.clone()
+    bad[6, 130, 260, 0] += 0.01
+    assert not bench.golden_parity("render", bad, list(range(24)))["ok"]
+    zt = np.load(os.path.join(ROOT, "tests", "golden", "texture_bench_frames.npz"))
+    outt = torch.zeros((4, 512, 512, 6))
+    for k, f in enumerate(zt["frames"].tolist()):
+        outt[f, 192:320, 192:320, 0:3] = torch.from_numpy(zt["image_%d" % k])
+        outt[f, 192:320, 192:320, 3:6] = torch.from_numpy(zt["normal_%d" % k])
+    rt = bench.golden_parity("texture", outt, [0, 1, 2, 3])
+    assert rt["ok"] and rt["max_abs_err"] == 0.0 and rt["frames"] == [0, 1, 2, 3]
+    zs = np.load(os.path.join(ROOT, "tests", "golden", "stress_bench_frames.npz"))
+    outs = torch.zeros((2, 1024, 1024, 1))
+    for f in range(2):
+        outs[f, 448:576, 448:576, 0] = torch.from_numpy(zs["output_%d" % f])
+    assert bench.golden_parity("stress", outs, [0, 1])["max_abs_err"] == 0.0
+    pr = bench.per_rank_fields([0.2, 0.1, 0.3], [3, 3, 3], 10)
+    assert pr["ms_per_step_per_rank"] == {"min": 10.0, "mean": 20.0, "max": 30.0} and pr["per_rank"]["units_per_step"] == [3, 3, 3]
