@@ -103,7 +103,7 @@ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H
                 const float c = S::BT(j, k);
                 if (c != 0.f) acc += c * tt[i][k];
             }
-            *reinterpret_cast<vec*>(vb + (size_t)(i * A + j) * plane) = acc;
+            *reinterpret_cast<vec*>(vb + (size_t)(i * A + j) * plane) = acc;       // (non-temporal stores measured 2-4 % slower here)
         }
 }
 
@@ -133,7 +133,7 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
     for (int j = 0; j < A; ++j) {
         vec m[A];
 #pragma unroll
-        for (int i = 0; i < A; ++i) m[i] = *reinterpret_cast<const vec*>(mb + (size_t)(i * A + j) * plane);
+        for (int i = 0; i < A; ++i) m[i] = __builtin_nontemporal_load(reinterpret_cast<const vec*>(mb + (size_t)(i * A + j) * plane));   // read once: non-temporal (output transform 0.327 -> 0.317 ms on the res2 shape)
 #pragma unroll
         for (int p_ = 0; p_ < MO; ++p_) {
             vec acc = vec(0.f);
