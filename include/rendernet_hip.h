@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 170            /* 0.1.7: + Winograd F(6x6,3x3) on the three-launch path */
+#define RN_VERSION 180            /* 0.1.8: + stride-2 transposed convs through F(2x2,2x2) per phase, fused output->input transform, brick resampler */
 
 /* error codes */
 #define RN_OK              0
