@@ -221,6 +221,27 @@ def train_parity(tr, spec, world):
                          "(2 samples, crop 64 at %s, full-width net)" % (tuple(start),)}
 
 
+def cpu_baseline_train(weights, patch):
+    """The oracle's training step (torch-CPU autograd over the oracle graph + the NumPy restatement of TF's Adam) on ONE sample of
+    the train bench's batch at the benched crop: a bounded sample (~10-20 s) of the same workload, `kind` "port" as for the
+    render line (TensorFlow itself is not installable)."""
+    from oracle import resample as OR
+    from oracle import train as OTR
+    cores, ncpu = pick_threads()
+    vox, poses = synthetic_batch(1)
+    target = np.random.default_rng(11).uniform(0, 1, (1, 512, 512, 1)).astype(np.float32)
+    t0 = time.time()
+    full = OR.net_input(vox, poses, 64, 128)
+    net_in, tgt = OTR.crop_voxel_image(full, target, (31, 17), patch)
+    loss, grads, _ = OTR.loss_and_grads(np.ascontiguousarray(net_in), np.ascontiguousarray(tgt), weights)
+    OTR.Adam().apply(weights, grads)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "protocol": {"samples": 1, "patch": patch, "threads": cores},
+            "sample": "one sample of the bench batch: resampler + crop %d + forward + BCE + torch-CPU autograd backward + NumPy Adam over "
+                      "237M parameters on %d threads of a %d-core host: %.1f s (loss %.1f)" % (patch, cores, ncpu, dt, loss)}
+
+
 # ----------------------------------------------------------------------------------------------------------------
 def train_main(args, world, rank, local_rank):
     """BASELINE configs[3]: Phong-shader training step, batch 24 per GPU (global batch 24*N), crop `--patch`,
@@ -299,6 +320,7 @@ def train_main(args, world, rank, local_rank):
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
             "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
             "roofline": roof, "final_loss": lossv, "parity": parity,
+            **({"cpu_baseline": cpu_baseline_train(weights, p)} if (world == 1 and not args.no_cpu_baseline) else {}),
             **per_rank_fields(by_rank, [B] * world, args.steps)}), flush=True)
         if parity is not None and not parity["ok"]:
             raise SystemExit("PARITY FAILURE (training step): %s" % json.dumps(parity))

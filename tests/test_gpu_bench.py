@@ -111,3 +111,13 @@ def test_stress_line_checks_against_committed_renders():
     d = _run(["--mode", "stress", "--steps", "1", "--warmup", "1", "--batch", "2"])
     assert "cpu_baseline" not in d
     assert d["parity"]["ok"] is True and d["parity"]["frames"] == [0, 1] and d["parity"]["max_abs_err"] <= 1e-3
+
+
+def test_single_rank_training_line_has_parity_and_cpu_baseline():
+    """BASELINE configs[3] at N = 1: parity (loss + sampled gradients vs float64 autograd) and the oracle's own training step timed
+    beside it (one sample: forward, backward, Adam)."""
+    d = _run(["--mode", "train", "--steps", "1", "--warmup", "1", "--batch", "2", "--patch", "32"])
+    assert d["parity"]["ok"] is True and d["parity"]["variables"] == 166
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "samples/s" and c["value"] > 0 and c["protocol"]["patch"] == 32
+    _check_per_rank(d, 1, [2])
