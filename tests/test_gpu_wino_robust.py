@@ -106,3 +106,31 @@ def test_renderer_validate_winograd(fixtures_vox):
     r2 = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True))
     assert r2.validate_winograd(vox, pose, tol=2e-4) == []
     assert torch.equal(r2.render(vox, pose), before)
+
+
+@pytest.mark.parametrize("k", [0, 1, 4])
+def test_f44_layers_on_hostile_statistics(k):
+    """The 4x4 layers (e_conv5: 1024 -> 512, RenderNet_Shader.py:86-88) run F(4x4,4x4) by default: the same hostile inputs, the
+    route against a float64 conv with TF's SAME padding for an even filter (1 before, 2 after), next to the F(2x2,2x2)x4 kernel
+    and the direct one."""
+    from rendernet_amd import ops
+    rng = np.random.default_rng(99)
+    name, x, _, _ = list(RU.hostile_inputs(rng, 1, 64, 64, C, 512))[k]
+    w = RU.xavier(rng, (4, 4, C, 512))
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    xn = F.pad(torch.as_tensor(x).double().permute(0, 3, 1, 2), (1, 2, 1, 2))
+    want = (F.conv2d(xn, torch.as_tensor(w).double().permute(3, 2, 0, 1)).permute(0, 2, 3, 1) + torch.as_tensor(b).double()).contiguous()
+    ymax = float(want.abs().max())
+    xd, wd, bd = (torch.as_tensor(a).cuda() for a in (x, w, b))
+    errs = {}
+    for scheme in ("f44", "f22x4", "direct"):
+        pw = ops.pack_conv(wd)
+        if scheme != "f44":
+            pw.wino43 = None
+        if scheme == "direct":
+            pw.wino4 = None
+        with torch.no_grad():
+            got = ops.conv2d(xd, pw, bd)
+        errs[scheme] = float((got.cpu().double() - want).abs().max()) / ymax
+    print("%s (4x4 filter): max|y| %.3g  " % (name, ymax) + "  ".join("%s %.2e" % kv for kv in errs.items()))
+    assert errs["f44"] <= 1e-4 and errs["f22x4"] <= 3e-5 and errs["direct"] <= 3e-5, errs
