@@ -244,6 +244,32 @@ int rn_winograd_output_transform(int scheme, const float* M, const float* bias, 
 int rn_winograd_output_input_supported(int scheme, int H, int W, int C, int act);
 int rn_winograd_output_input_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
                                        float* y, float* V_next, int B, int H, int W, int C, int act, void* stream);
+/* The same three launches with the multiply stage on the bf16 matrix pipe AT FP32 ACCURACY ("split" route; replaces the
+ * slim.conv2d / tf.nn.conv2d of the wide stride-1 2-D layers -- tools/layer_util.py:91-105, :171, RenderNet_Shader.py:71-103 --
+ * exactly like the entries above).  gfx950 runs bf16-input MFMA at 16x the rate of f32-input MFMA, both accumulating in
+ * fp32.  Every fp32 value of V (input transform) and U (filter transform) is stored as the EXACT sum of three bf16 pieces
+ * (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even) and a product is the six piece products
+ * with i + j <= 2; what is dropped is <= 3 * 2^-25 |x||y| per product, below the rounding of an fp32 FMA.  The result is
+ * NOT bit-identical to the exact-fp32 route; against a float64 conv it measures the same or smaller error
+ * (tests/test_gpu_wino_robust.py, same bars).
+ *   rn_winograd_split_pack             w_tf (TF layout; transposed = 1: a conv_transpose filter, taps flipped) -> w_split,
+ *                                      rn_winograd_split_packed_bytes(scheme,Cin,Cout) = nxi*Cin*Cout*6 bytes
+ *   rn_winograd_split_input_transform  x [B,H,W,C] -> Vs [nxi][C/16][T][3][16] bf16 (rn_winograd_split_v_bytes(scheme,T,C))
+ *   rn_winograd_split_gemm             Vs, w_split -> M [nxi][T][Cout] fp32 (then rn_winograd_output_transform)
+ *   rn_conv2d_winograd_split_fwd       the three launches; workspace: rn_winograd_split_workspace_bytes(...) BYTES of device
+ *                                      memory; scheme RN_WINO_F43 | RN_WINO_F63 (3x3) | RN_WINO_F44 (4x4; transposed = 1 pads
+ *                                      two before); epilogue arguments as rn_conv2d_fwd_train.
+ * Needs Cin % 32 == 0, Cout % 256 == 0 (rn_winograd_split_supported); planes below 2 GiB as above. */
+int rn_winograd_split_supported(int scheme, int Cin, int Cout);
+size_t rn_winograd_split_packed_bytes(int scheme, int Cin, int Cout);
+size_t rn_winograd_split_v_bytes(int scheme, long long T, int Cin);
+size_t rn_winograd_split_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout);
+int rn_winograd_split_pack(int scheme, const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream);
+int rn_winograd_split_input_transform(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, void* stream);
+int rn_winograd_split_gemm(int scheme, const void* Vs, const void* w_split, float* M, long long T, int Cin, int Cout, void* stream);
+int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
+                                 const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
+                                 int Cin, int Cout, int transposed, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

@@ -51,8 +51,8 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None}
-        self._dirty = {"data": True, "wino": True, "wino4": True, "wino43": True, "wino63": True}
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None}
+        self._dirty = {k: True for k in self._buf}
         self._packed_on = {}              # form -> (stream, event recorded behind its last pack kernel)
         # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
         # used by every stride-1 launch of this filter (forward, and the input gradient through the dgrad pack).
@@ -84,13 +84,23 @@ class PackedWeight:
     def _packed(self, which, kind):
         if self._dirty[which]:
             lib = L.lib()
-            if self._buf[which] is None:
-                n = self._n if which == "data" else lib.rn_packed_weight_floats(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout)
-                if n == 0:
-                    raise L.RenderNetHipError("rn_packed_weight_floats (%s): %s" % (which, lib.rn_last_error().decode()))
-                self._buf[which] = torch.empty(n, dtype=torch.float32, device=self.w_tf.device)
-            L.check(lib.rn_pack_weights(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout, L.ptr(self.w_tf),
-                                        L.ptr(self._buf[which]), L.stream_ptr()), "rn_pack_weights (%s)" % which)
+            if which.endswith("s"):
+                # the bf16x3 split form of the three-launch path (csrc/conv_wino_bf3.hip): `kind` is the scheme here
+                if self._buf[which] is None:
+                    n = lib.rn_winograd_split_packed_bytes(kind, self.cin, self.cout)
+                    if n == 0:
+                        raise L.RenderNetHipError("rn_winograd_split_packed_bytes (%s): unsupported filter" % which)
+                    self._buf[which] = torch.empty(n, dtype=torch.uint8, device=self.w_tf.device)
+                L.check(lib.rn_winograd_split_pack(kind, L.ptr(self.w_tf), ctypes.c_void_p(self._buf[which].data_ptr()), self.cin, self.cout,
+                                                   1 if self.kind == L.RN_PACK_CONVT_S1 else 0, L.stream_ptr()), "rn_winograd_split_pack (%s)" % which)
+            else:
+                if self._buf[which] is None:
+                    n = self._n if which == "data" else lib.rn_packed_weight_floats(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout)
+                    if n == 0:
+                        raise L.RenderNetHipError("rn_packed_weight_floats (%s): %s" % (which, lib.rn_last_error().decode()))
+                    self._buf[which] = torch.empty(n, dtype=torch.float32, device=self.w_tf.device)
+                L.check(lib.rn_pack_weights(kind, self.ndim, L.ivec(self.kdims), self.cin, self.cout, L.ptr(self.w_tf),
+                                            L.ptr(self._buf[which]), L.stream_ptr()), "rn_pack_weights (%s)" % which)
             self._dirty[which] = False
             # the pack runs on the stream that first needed it; a launch on ANOTHER stream (two-stream serving sharing one
             # Renderer) must not read the buffer before that kernel has finished
@@ -148,6 +158,14 @@ class PackedWeight:
         if value is not None:
             raise ValueError("the F(6x6,3x3) Winograd pack can only be switched off (set to None)")
         self._wino63_kind = None
+
+    def split(self, which):
+        """The bf16x3 split form (uint8 buffer) of scheme `which` ("f43" | "f44" | "f63") for the split GEMM stage, or None."""
+        if which == "f63":
+            return None if self._wino63_kind is None else self._packed("wino63s", L.RN_WINO_F63)
+        if self._wino43_kind is None:
+            return None
+        return self._packed("wino43s", L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43)
 
     @property
     def wino4(self):
@@ -436,16 +454,41 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
     return _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which)
 
 
+# Multiply stage of the three-launch path: "f32" = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = the same products on
+# the 16x faster bf16 pipe with every fp32 operand as three bf16 pieces and six piece products, fp32 accumulation
+# (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
+WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
+
+
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
     lib = L.lib()
     f44, f63 = which == "f44", which == "f63"
-    u = pw.wino63 if f63 else pw.wino43
     transposed = 1 if pw.kind == L.RN_PACK_CONVT_S1 else 0
+    m = 6 if f63 else 4
+    T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
+    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
+    st = L.stream_ptr()
+    if WINO_GEMM == "split" and lib.rn_winograd_split_supported(scheme, Cin, Cout):
+        us = ctypes.c_void_p(pw.split(which).data_ptr())
+        ws = torch.empty(lib.rn_winograd_split_workspace_bytes(scheme, B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
+        wsp = ctypes.c_void_p(ws.data_ptr())
+        ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
+        if ev is None:
+            return lib.rn_conv2d_winograd_split_fwd(scheme, L.ptr(x), us, *e, wsp, B, H, W, Cin, Cout, transposed, act, st)
+        M = ctypes.c_void_p(ws.data_ptr() + lib.rn_winograd_split_v_bytes(scheme, T, Cin))
+        rc = lib.rn_winograd_split_input_transform(scheme, L.ptr(x), wsp, B, H, W, Cin, 2 if (f44 and transposed) else 1, st)
+        if rc != 0:
+            return rc
+        ev[0].record()
+        rc = lib.rn_winograd_split_gemm(scheme, wsp, us, M, T, Cin, Cout, st)
+        ev[1].record()
+        if rc != 0:
+            return rc
+        return lib.rn_winograd_output_transform(scheme, M, *e, B, H, W, Cout, act, st)
+    u = pw.wino63 if f63 else pw.wino43
     n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino63_workspace_floats if f63
          else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
-    m = 6 if f63 else 4
-    T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
     ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
     if ev is None:
         if f44:
@@ -454,8 +497,6 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
             return lib.rn_conv2d_wino63_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
         return lib.rn_conv2d_wino43_fwd(L.ptr(x), L.ptr(u), *e, L.ptr(ws), B, H, W, Cin, Cout, act, L.stream_ptr())
     # the same three launches through the stage entry points, the GEMM bracketed by the caller's events
-    st = L.stream_ptr()
-    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
     V, M = L.ptr(ws), ctypes.c_void_p(ws.data_ptr() + 4 * nxi * T * Cin)
     rc = lib.rn_winograd_input_transform(scheme, L.ptr(x), V, B, H, W, Cin, 2 if (f44 and transposed) else 1, st)
     if rc != 0:
