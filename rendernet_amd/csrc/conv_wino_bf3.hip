@@ -38,7 +38,7 @@ namespace {
 
 constexpr int SB_ROW = 96;                                   // bytes per row and K step
 constexpr int SB_BM = 256, SB_BN = 256;
-constexpr int SB_VB = SB_BM * SB_ROW, SB_UB = SB_BN * SB_ROW, SB_STAGE = SB_VB + SB_UB;      // 24 + 24 KiB
+constexpr int SB_UB = SB_BN * SB_ROW;                        // U part of a stage: 24 KiB (V: 24 | 12 KiB)
 constexpr int SB_NSTAGE = 3;
 
 __device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8) { return (blk & 7u) * (nblk8 >> 3) + (blk >> 3); }
@@ -65,58 +65,72 @@ __device__ __forceinline__ void split3(const float (&x)[VW], unsigned short (&p)
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. input transform V = B^T d B, written as three bf16 planes in the GEMM's row layout.  The arithmetic is that of
 // wino_input_kernel (conv_wino43.hip) per element -- V itself is bit-identical, only its representation changes.
-// thread = (tile, VW channels); a wave = 64 / (16 / VW) tiles x one 16-channel K-step group, so that the three stores of
-// a (xi, plane) triple cover the wave's rows completely (96 contiguous bytes per tile, neighbouring tiles adjacent);
-// a workgroup = those tiles x 64 channels.
-template <class S, int VW>
+// thread = (tile, 2 channels); workgroup = 8 consecutive tiles x 64 channels (4 K-step groups), 32 lanes per tile: a load
+// instruction reads two 256-byte runs.  What the workgroup produces for one (xi, K-step group) is 8 rows x 96 bytes =
+// 768 CONTIGUOUS bytes of Vs, but a thread holds only 4 bytes per plane of it -- measured on the res2 shape (B = 24): three
+// 4-byte stores per thread and xi 0.50 ms, the same bytes as whole-line 16-byte stores 0.3 ms.  So the pieces of one
+// output row i (A xi planes) are exchanged through LDS: every thread writes its 3 x A words, one barrier, then the
+// workgroup streams the A x 4 segments out in 16-byte stores, 48 consecutive lanes per segment (two LDS buffers: the
+// next row's writes need no second barrier).
+constexpr int IB_TILES = 8, IB_SEG = IB_TILES * SB_ROW + 32;  // LDS bytes per (xi, K-step group) segment: 768 + 32 (bank spread)
+
+template <class S>
 __global__ __launch_bounds__(256)
 void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, int H, int W, int C, int th, int tw,
                            long long T, unsigned ncb, unsigned nwg, unsigned nblk8, int pad_lo)
 {
-    typedef float vec __attribute__((ext_vector_type(VW)));
+    typedef float vec __attribute__((ext_vector_type(2)));
     constexpr int A = S::TA;
-    constexpr int LPS = 16 / VW, TPW = 64 / LPS;               // lanes per K-step group; tiles per wave
+    constexpr int NSEG = A * 4, BUF = NSEG * IB_SEG, NCHUNK = NSEG * (IB_TILES * SB_ROW / 16);   // 16-byte chunks per row batch
+    __shared__ __attribute__((aligned(16))) char xch[2 * BUF];
     const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
-    if (blk >= nwg) return;
+    if (blk >= nwg) return;                                    // (whole workgroups only: no barrier is skipped)
     const unsigned cb = blk % ncb;
     const long long tg = blk / ncb;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (int)cb * 64 + wave * 16 + (lane % LPS) * VW;
-    const long long t = tg * TPW + lane / LPS;
-    if (t >= T || c >= C) return;
-    const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
-    const long long b = t / ((long long)tw * th);
-    const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
-    const float* xb = x + ((size_t)b * H * W) * C + c;
+    const int tid = threadIdx.x, l32 = tid & 31, tl = tid >> 5;
+    const int c = (int)cb * 64 + l32 * 2;
+    const long long t0 = tg * IB_TILES, t = t0 + tl;
+    const bool live = t < T && c < C;
     vec tt[A][A];                                              // (B^T d)[i][col]
+    {
+        const long long tc = live ? t : 0;
+        const int tx = (int)(tc % tw), ty = (int)((tc / tw) % th);
+        const long long b = tc / ((long long)tw * th);
+        const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
+        const float* xb = x + ((size_t)b * H * W) * C + (live ? c : 0);
 #pragma unroll
-    for (int col = 0; col < A; ++col) {
-        vec d[A];
-        const int ix = x0 + col;
+        for (int col = 0; col < A; ++col) {
+            vec d[A];
+            const int ix = x0 + col;
 #pragma unroll
-        for (int r = 0; r < A; ++r) {
-            const int iy = y0 + r;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < A; ++i) {
-            vec acc = vec(0.f);
-#pragma unroll
-            for (int k = 0; k < A; ++k) {
-                const float cf = S::BT(i, k);
-                if (cf != 0.f) acc += cf * d[k];
+            for (int r = 0; r < A; ++r) {
+                const int iy = y0 + r;
+                const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
             }
-            tt[i][col] = acc;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                vec acc = vec(0.f);
+#pragma unroll
+                for (int k = 0; k < A; ++k) {
+                    const float cf = S::BT(i, k);
+                    if (cf != 0.f) acc += cf * d[k];
+                }
+                tt[i][col] = acc;
+            }
         }
     }
-    // row (xi, s = c / 16, t): plane p at +32 p, chunk (c % 16) / 8 at +16 (chunk ^ bit 3 of t), channel at +2 (c % 8)
-    const int s = c >> 4, within = c & 15;
-    const unsigned pos = (unsigned)(within >> 3) ^ (unsigned)((t >> 3) & 1);
+    // LDS position of this thread's word of plane 0 in segment (j = 0, its K-step group): row tl, chunk (l32 % 8) / 4 swapped
+    // when bit 3 of the tile index is set (t0 is a multiple of 8: the bit is that of tg), word l32 % 4
+    const unsigned sw = (unsigned)(tg & 1);
+    const unsigned wofs = (unsigned)((l32 >> 3) * IB_SEG + tl * SB_ROW) + ((((unsigned)(l32 >> 2) & 1u) ^ sw) << 4) + (unsigned)(l32 & 3) * 4;
     const size_t xi_stride = (size_t)T * C * 6;                // bytes per xi: (C / 16) K steps x T rows x 96
-    char* vb = Vs + ((size_t)s * T + t) * SB_ROW + pos * 16 + (within & 7) * 2;
+    const size_t step_stride = (size_t)T * SB_ROW;
+    char* vbase = Vs + ((size_t)cb * 4 * T + t0) * SB_ROW;     // segment (xi = 0, K-step group 4 cb) of this tile group
+    const int tiles_here = (int)((T - t0) < IB_TILES ? (T - t0) : IB_TILES);
 #pragma unroll
-    for (int i = 0; i < A; ++i)
+    for (int i = 0; i < A; ++i) {
+        char* buf = xch + (i & 1) * BUF;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             vec acc = vec(0.f);
@@ -125,24 +139,23 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
                 const float cf = S::BT(j, k);
                 if (cf != 0.f) acc += cf * tt[i][k];
             }
-            float a[VW];
+            const float a2[2] = {acc[0], acc[1]};
+            unsigned short p[3][2];
+            split3<2>(a2, p);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) a[e] = acc[e];
-            unsigned short p[3][VW];
-            split3<VW>(a, p);
-            char* dst = vb + (size_t)(i * A + j) * xi_stride;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if constexpr (VW == 2) {
-                    *reinterpret_cast<unsigned*>(dst + q * 32) = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
-                } else {
-                    uint2 o;
-                    o.x = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
-                    o.y = (unsigned)p[q][2] | ((unsigned)p[q][3] << 16);
-                    *reinterpret_cast<uint2*>(dst + q * 32) = o;
-                }
-            }
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<unsigned*>(buf + j * (4 * IB_SEG) + wofs + q * 32) = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
         }
+        __syncthreads();
+        for (int q = tid; q < NCHUNK; q += 256) {
+            const int seg = q / 48, r = q - seg * 48;          // segment (j, K-step group), 16-byte chunk of its 768 bytes
+            if (r >= tiles_here * 6) continue;
+            const int j = seg >> 2, sg = seg & 3;
+            if ((int)cb * 4 + sg >= (C >> 4)) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + seg * IB_SEG + r * 16);
+            *reinterpret_cast<u32x4*>(vbase + (size_t)(i * A + j) * xi_stride + sg * step_stride + r * 16) = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -218,8 +231,10 @@ struct Bf3GemmArgs {
     const char* V; const char* U; float* M;
     long long T;
     int Cin, Cout;
-    int mblocks, nblocks, ksteps;   // 256-row blocks of T (the last may be ragged), 256-channel blocks, K steps of 16
-    int nitems;                     // nxi * mblocks * nblocks
+    int mblocks, nblocks, ksteps;   // row blocks of T this launch walks (from mb_begin), 256-channel blocks, K steps of 16
+    int mb_begin, parts;            // parts: BM-row parts of a block that are enumerated (4 / WM; fewer for the ragged last block)
+    int mrows;                      // rows between consecutive row blocks: 256, or BM itself when all of T is walked in BM-row items
+    int item_begin, item_end;       // this launch's range of the items L = (xi*mblocks + mb - mb_begin)*nblocks + nb
     unsigned v_step_bytes;          // T * 96: one (xi, K step) sub-plane of Vs
     unsigned m_bytes;               // one xi plane of M
     int probe;                      // RN_WINO_BF3_PROBE (timing experiments; results are wrong when set): 1 no DMA in the loop, 2 no stores
@@ -227,54 +242,78 @@ struct Bf3GemmArgs {
 
 #define BF3_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles, 128
+// accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64 = 2 x 2 tiles): the launcher runs ragged row blocks, the
+// items of a last partial round and small batches as half items.
 // TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower)
-template <int TAG>
+template <int WM, int TAG>
 __global__ __launch_bounds__(512, 2)
 void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V 256 x 96 | U 256 x 96]
+    constexpr int WN = 8 / WM, NT2 = 8 / WN;                          // 32-channel MFMA tiles per wave along channels (4 | 2)
+    constexpr int BM = WM * 64, VB = BM * SB_ROW, STAGE = VB + SB_UB;  // V 24 | 12 KiB + U 24 KiB per stage
+    constexpr int VP = VB / 1024;                                     // V DMA pieces per stage (24 | 12); U: 24
+    constexpr int NSTORE = 2 * NT2 * 4;                               // 16-byte stores of a wave's epilogue (32 | 16)
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V BM x 96 | U 256 x 96]
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hb = lane >> 5;                       // 32x32x16 MFMA: lane = (row / column, k group of 8)
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const unsigned sw = (unsigned)((l32 >> 3) & 1);
     const unsigned vfrag = (unsigned)((wm * 64 + l32) * SB_ROW) + (((unsigned)hb ^ sw) << 4);
-    const unsigned ufrag = (unsigned)(SB_VB + (wn * 128 + l32) * SB_ROW) + (((unsigned)hb ^ sw) << 4);
+    const unsigned ufrag = (unsigned)(VB + (wn * (NT2 * 32) + l32) * SB_ROW) + (((unsigned)hb ^ sw) << 4);
     const unsigned dma_lane = (unsigned)(wave * 1024 + lane * 16);
+    const bool vextra = wave < VP % 8;                                // this wave carries one V piece more than VP / 8 (WM = 2: waves 0..3)
 
     struct Item { const char* vplane; const char* upanel; float* mplane; long long m0; int nb; };
+    const int rounds_total = (a.item_end - a.item_begin) * a.parts;
     const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);   // XCD-contiguous slot in a round
     auto decode = [&](int r, Item& it) -> bool {
-        const int L = r * (int)gridDim.x + perm;                      // gridDim.x is a multiple of 8
-        if (L >= a.nitems) return false;
+        const int id = r * (int)gridDim.x + perm;                     // gridDim.x is a multiple of 8
+        if (id >= rounds_total) return false;
+        const int L = a.item_begin + id / a.parts, h = id % a.parts;
         const int nb = L % a.nblocks;
         const int mbx = L / a.nblocks;
-        const int mb = mbx % a.mblocks, xi = mbx / a.mblocks;
+        const int mb = a.mb_begin + mbx % a.mblocks, xi = mbx / a.mblocks;
         it.nb = nb;
-        it.m0 = (long long)mb * SB_BM;
+        it.m0 = (long long)mb * a.mrows + h * BM;
         it.vplane = a.V + (size_t)xi * a.ksteps * a.v_step_bytes;
         it.upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.ksteps * SB_UB);
         it.mplane = a.M + (size_t)xi * a.T * a.Cout;
         return true;
     };
-    // one K step of one item -> LDS stage `buf`: 3 + 3 wave instructions of 1 KiB.  Rows >= T of a V sub-plane lie beyond
-    // its buffer window: zeros (their outputs are never stored).
+    // one K step of one item -> LDS stage `buf`: VP / 8 (+1) + 3 wave instructions of 1 KiB per wave.  Rows >= T of a V
+    // sub-plane lie beyond its buffer window: zeros (their outputs are never stored).
     auto issue = [&](const Item& it, int s, int buf) {
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
-        char* sb = smem + buf * SB_STAGE;
+        char* sb = smem + buf * STAGE;
         const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < VP / 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * i) * 1024), 16, vo + i * 8192, 0, 0, 0);
+        if constexpr (VP % 8 != 0) {
+            if (vextra)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * (VP / 8)) * 1024), 16, vo + (VP / 8) * 8192, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + SB_VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, 0);
+    };
+    // wait until all but the newest stage's DMAs of this wave (and, behind an item's end, its NSTORE stores) have landed, then the barrier
+    auto wait_stage = [&](bool issued, bool after_store) {
+        if (!issued) { BF3_WAIT_BARRIER(0); return; }
+        if constexpr (WM == 4) {
+            if (after_store) BF3_WAIT_BARRIER(38); else BF3_WAIT_BARRIER(6);
+        } else {
+            if (vextra) { if (after_store) BF3_WAIT_BARRIER(21); else BF3_WAIT_BARRIER(5); }
+            else        { if (after_store) BF3_WAIT_BARRIER(20); else BF3_WAIT_BARRIER(4); }
+        }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT2];
     auto ldv = [&](const char* sb, int mt, bf16x8 (&v)[3]) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const bf16x8*>(sb + vfrag + mt * (32 * SB_ROW) + p * 32);
@@ -296,20 +335,20 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     bf16x8 x0[3], x1[3], ua[3], ub[3];
     issue(cur, 0, 0);
     issue(cur, 1, 1);
-    BF3_WAIT_BARRIER(6);
+    wait_stage(true, false);
     ldv(smem, 0, x0);
     ldu(smem, 0, ua);
     int buf = 0;                                                      // stage of the current K step
-    bool after_store = false;                                         // the previous item's 32 stores sit in the queue behind DMA(g+1)
+    bool after_store = false;                                         // the previous item's stores sit in the queue behind DMA(g+1)
 
-    // One K step = 8 (row tile, channel tile) groups of 6 MFMAs in an order in which consecutive groups share an operand, so
-    // that 4 fragment sets (2 V, 2 U: 48 registers) suffice: a group's new operand is read from LDS two groups ahead of its
-    // use.  At entry v0 holds the fragments of row tile 0 and ua those of channel tile 0 (read under the previous step's last
-    // group); v1 is free.  Before the last group the next stage is waited for (counted: the stage after it stays in flight),
-    // the barrier says every wave has finished reading this stage, and the next step's first operands are read into the
-    // two sets that have just become free -- the next step runs with the roles of v0 / v1 swapped.
+    // One K step = 2 x NT2 (row tile, channel tile) groups of 6 MFMAs in an order in which consecutive groups share an operand,
+    // so that 4 fragment sets (2 V, 2 U: 48 registers) suffice: a group's new operand is read from LDS about two groups ahead
+    // of its use.  At entry v0 holds the fragments of row tile 0 and ua those of channel tile 0 (read under the previous step's
+    // last group); v1 is free.  Before the last group the next stage is waited for (counted: the stage after it stays in
+    // flight), the barrier says every wave has finished reading this stage, and the next step's first operands are read into
+    // the two sets that have just become free -- the next step runs with the roles of v0 / v1 swapped.
     auto step = [&](int s, bf16x8 (&v0)[3], bf16x8 (&v1)[3]) {
-        const char* sb = smem + buf * SB_STAGE;
+        const char* sb = smem + buf * STAGE;
         const int bn = buf == SB_NSTAGE - 1 ? 0 : buf + 1;
         const int b2 = bn == SB_NSTAGE - 1 ? 0 : bn + 1;
         const int s2 = s + 2;
@@ -323,23 +362,23 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
         grp(v0, ua, acc[0][0]);
         grp(v1, ua, acc[1][0]);
         __builtin_amdgcn_sched_barrier(0);
-        ldu(sb, 2, ua);
-        grp(v1, ub, acc[1][1]);
-        grp(v0, ub, acc[0][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        ldu(sb, 3, ub);
-        grp(v0, ua, acc[0][2]);
-        grp(v1, ua, acc[1][2]);
-        grp(v1, ub, acc[1][3]);
-        if (!issued) BF3_WAIT_BARRIER(0);
-        else if (after_store) BF3_WAIT_BARRIER(38);
-        else BF3_WAIT_BARRIER(6);
+        if constexpr (NT2 == 4) {
+            ldu(sb, 2, ua);
+            grp(v1, ub, acc[1][1]);
+            grp(v0, ub, acc[0][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            ldu(sb, 3, ub);
+            grp(v0, ua, acc[0][2]);
+            grp(v1, ua, acc[1][2]);
+        }
+        grp(v1, ub, acc[1][NT2 - 1]);
+        wait_stage(issued, after_store);
         if (s + 1 < a.ksteps || have_next) {
-            const char* sn = smem + bn * SB_STAGE;
+            const char* sn = smem + bn * STAGE;
             ldv(sn, 0, v1);
             ldu(sn, 0, ua);
         }
-        grp(v0, ub, acc[0][3]);
+        grp(v0, ub, acc[0][NT2 - 1]);
         __builtin_amdgcn_sched_barrier(0);
         buf = bn;
         after_store = false;
@@ -349,7 +388,7 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         for (int s = 0; s < a.ksteps; s += 2) {
@@ -360,17 +399,18 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
         // (r & 3) + 8*(r >> 2) + 4*hb of the 32-channel tile, tile row l32 -> four 16-byte stores per MFMA tile
         if (!(a.probe & 2)) {
             const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
-            const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l32) * a.Cout + cur.nb * SB_BN + wn * 128 + hb * 4) * 4);
+            const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l32) * a.Cout + cur.nb * SB_BN + wn * (NT2 * 32) + hb * 4) * 4);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 o = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), mrsrc,
                                                                mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, 0);
                     }
+            static_assert(NSTORE == 2 * NT2 * 4, "the counted waits assume this many stores per wave");
             after_store = true;
         }
         if (!have_next) break;
@@ -418,31 +458,47 @@ int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H,
     if (m == 0 || C % 16 != 0) return rn_set_error(RN_E_INVALID, "wino_input_bf3: scheme %d, C %d", scheme, C);
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
-    const int vw = scheme == RN_WINO_F43 ? 4 : 2;
-    const int tpw = 64 / (16 / vw);
     const unsigned ncb = (unsigned)((C + 63) / 64);
-    const unsigned long long n = (unsigned long long)((T + tpw - 1) / tpw) * ncb;
+    const unsigned long long n = (unsigned long long)((T + IB_TILES - 1) / IB_TILES) * ncb;
     if (n > 0x7fffff00ULL) return rn_set_error(RN_E_UNSUPPORTED, "wino_input_bf3: grid too large");
     const unsigned nwg = (unsigned)n, nblk8 = (unsigned)((n + 7) / 8 * 8);
     char* v = static_cast<char*>(Vs);
     if (scheme == RN_WINO_F43)
-        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
     else if (scheme == RN_WINO_F44)
-        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF44>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
     else
-        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF63>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
     return rn_check_launch("wino_input_bf3");
 }
 
-template <int TAG>
-static int wino_gemm_bf3_launch_t(const Bf3GemmArgs& a, hipStream_t st)
+// items [begin, end) of the block range the args name, `parts` BM-row parts of each (0: all 4 / WM of them)
+template <int WM, int TAG>
+static int wino_gemm_bf3_launch_t(Bf3GemmArgs a, int begin, int end, int parts, hipStream_t st)
 {
-    const size_t lds = (size_t)SB_NSTAGE * SB_STAGE;
-    auto kern = wino_gemm_bf3_kernel<TAG>;
+    a.item_begin = begin; a.item_end = end; a.parts = parts > 0 ? parts : 4 / WM;
+    const size_t lds = (size_t)SB_NSTAGE * (WM * 64 * SB_ROW + SB_UB);
+    auto kern = wino_gemm_bf3_kernel<WM, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
-    const int n = a.nitems;
+    const int n = (end - begin) * a.parts;
     hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
     return rn_check_launch("wino_gemm_bf3");
+}
+
+template <int WM>
+static int wino_gemm_bf3_launch_w(int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
+{
+    switch (tag) {
+    case 0: return wino_gemm_bf3_launch_t<WM, 0>(a, begin, end, parts, st);
+    case 1: return wino_gemm_bf3_launch_t<WM, 1>(a, begin, end, parts, st);
+    case 2: return wino_gemm_bf3_launch_t<WM, 2>(a, begin, end, parts, st);
+    default: return wino_gemm_bf3_launch_t<WM, 3>(a, begin, end, parts, st);
+    }
+}
+
+static int wino_gemm_bf3_launch(int wm, int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
+{
+    return wm == 4 ? wino_gemm_bf3_launch_w<4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<2>(tag, a, begin, end, parts, st);
 }
 
 int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
@@ -452,19 +508,61 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
         return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: a transform plane must stay below the 2 GiB buffer window");
     Bf3GemmArgs a;
     a.V = static_cast<const char*>(Vs); a.U = static_cast<const char*>(us); a.M = M; a.T = T; a.Cin = Cin; a.Cout = Cout;
-    a.nblocks = Cout / SB_BN; a.ksteps = Cin / 16; a.mblocks = (int)((T + SB_BM - 1) / SB_BM);
-    const long long nitems = (long long)rn_wino_scheme_nxi(scheme) * a.mblocks * a.nblocks;
-    if (nitems > 0x3fffffff) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: too many items");
-    a.nitems = (int)nitems;
+    a.nblocks = Cout / SB_BN; a.ksteps = Cin / 16;
     a.v_step_bytes = (unsigned)(T * SB_ROW); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO_BF3_PROBE") ? atoi(getenv("RN_WINO_BF3_PROBE")) : 0; a.probe = probe; }
+    static const bool notail = getenv("RN_WINO_BF3_NOTAIL") != nullptr;
+    const int nxi = rn_wino_scheme_nxi(scheme);
     const int tag = scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
-    switch (tag) {
-    case 0: return wino_gemm_bf3_launch_t<0>(a, st);
-    case 1: return wino_gemm_bf3_launch_t<1>(a, st);
-    case 2: return wino_gemm_bf3_launch_t<2>(a, st);
-    default: return wino_gemm_bf3_launch_t<3>(a, st);
+    const int full = (int)(T / SB_BM), ragged = (int)(T % SB_BM);    // whole 256-row blocks; rows of the last, partial one
+    if ((long long)nxi * (full + 1) * a.nblocks * 2 > 0x3fffffff) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: too many items");
+    a.mrows = SB_BM;
+    // One workgroup per CU takes items id, id + 256, ...  Costs below are in half rounds (a whole item = 2, a 128-row half item = 1).
+    auto tail_cost = [](int rem) { if (rem == 0) return 0; const int half = (2 * rem + 255) / 256; return half < 2 ? half : 2; };
+    // the ragged block's rows as whole items or as 1 .. 2 half items per (xi, n-block)
+    auto ragged_plan = [&](int& wm, int& parts) {
+        const int nit = nxi * a.nblocks;
+        wm = 4; parts = 1;
+        int best = (nit + 255) / 256 * 2;
+        const int hp = (ragged + 127) / 128, hc = (nit * hp + 255) / 256;
+        if (!notail && hc < best) { best = hc; wm = 2; parts = hp; }
+        return best;
+    };
+    // Few tiles (one GPU's share of a strongly scaled batch): below two blocks walk ALL of T in 128-row items, one launch,
+    // several items per CU back to back, whenever that costs no more than whole blocks + a ragged tail.
+    if (!notail && full <= 1) {
+        const int nfull = nxi * full * a.nblocks;
+        int cost_split = nfull / 256 * 2 + tail_cost(nfull % 256);
+        if (ragged > 0) { int wm, parts; cost_split += ragged_plan(wm, parts); }
+        const long long items = (long long)nxi * a.nblocks * ((T + 127) / 128);
+        const int ucost = (int)((items + 255) / 256);
+        if (ucost <= cost_split) {
+            a.mb_begin = 0; a.mrows = 128; a.mblocks = (int)((T + 127) / 128);
+            return wino_gemm_bf3_launch(2, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
+        }
     }
+    if (full > 0) {
+        a.mb_begin = 0; a.mblocks = full;
+        const int nitems = nxi * full * a.nblocks;
+        const int rem = nitems % 256;
+        const bool half_tail = !notail && rem != 0 && tail_cost(rem) < 2;       // the last, partial round as half items: half a round
+        const int tail = half_tail ? rem : 0;
+        if (nitems - tail > 0) {
+            const int rc = wino_gemm_bf3_launch(4, tag, a, 0, nitems - tail, 0, st);
+            if (rc != RN_OK) return rc;
+        }
+        if (tail > 0) {
+            const int rc = wino_gemm_bf3_launch(2, tag, a, nitems - tail, nitems, 0, st);
+            if (rc != RN_OK) return rc;
+        }
+    }
+    if (ragged > 0) {
+        a.mb_begin = full; a.mblocks = 1;
+        int wm, parts;
+        ragged_plan(wm, parts);
+        return wino_gemm_bf3_launch(wm, tag, a, 0, nxi * a.nblocks, parts, st);
+    }
+    return RN_OK;
 }
 
 // x [B,H,W,Cin] -> y [B,H,W,Cout]; us from rn_launch_wino_pack_bf3; ws >= rn_wino_bf3_workspace_bytes(...) bytes

@@ -109,21 +109,27 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--no-timing", action="store_true")
+    ap.add_argument("--shapes", type=str, default="", help="indices into the timing shape list, e.g. 0,2")
     args = ap.parse_args()
     if not args.no_accuracy:
         accuracy(1, 24, 256, 256, 3, forced="f43")
         accuracy(1, 24, 256, 256, 3, forced="f63")
         accuracy(2, 30, 64, 512, 3, forced="f63")           # ragged planes, several K steps only
         accuracy(3, 16, 512, 256, 4)
-        accuracy(5, 64, 256, 256, 3)                         # T = 605: three row blocks, the last ragged
+        accuracy(5, 64, 256, 256, 3)                         # T = 605: two whole row blocks + a ragged one
+        accuracy(3, 64, 256, 512, 3)                         # T = 363: walked in 128-row items
+        accuracy(9, 64, 64, 256, 3)                          # T = 1089: 4 whole blocks x 64 xi = 256 items + ragged 65 rows
+        accuracy(2, 64, 64, 256, 4)                          # F44: T = 512, 98 items (less than one round)
         if not args.quick:
             accuracy(1, 64, 1024, 1024, 3)
             accuracy(1, 64, 1024, 1024, 3, forced="f43")
             accuracy(1, 64, 1024, 512, 4)
     if not args.no_timing:
         B = args.batch
-        for (hw, cin, cout, k, forced) in ((64, 1024, 1024, 3, None), (64, 512, 512, 3, None), (64, 1024, 512, 4, None),
-                                           (64, 512, 256, 4, None), (64, 1024, 1024, 3, "f43")):
+        shapes = ((64, 1024, 1024, 3, None), (64, 512, 512, 3, None), (64, 1024, 512, 4, None), (64, 512, 256, 4, None), (64, 1024, 1024, 3, "f43"))
+        if args.shapes:
+            shapes = tuple(shapes[int(i)] for i in args.shapes.split(","))
+        for (hw, cin, cout, k, forced) in shapes:
             print("B=%d %dx%d %d->%d k%d %s" % (B, hw, hw, cin, cout, k, forced or ""), flush=True)
             timing(B, hw, cin, cout, k, args.iters, forced)
 
