@@ -368,6 +368,65 @@ def build_workload(mode, device):
             "out_hw": 4 * spec.new_size, "out_ch": 6, "trunk": (spec.new_size // 2, spec.w_res2)}
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+
+
+def gemm_roofline(gemm_events, layer_events, wtrunk, hw, nloc, mode, gemm_mode):
+    """`roofline` of the dominant kernel from the HIP-event brackets of one timed pass.  gemm_mode "f32": executed fp32 MFMA
+    FLOPs over the exact-fp32 MFMA peak; "split": the SAME fp32-equivalent FLOPs, each executed as six bf16 piece products --
+    priced against the bf16 peak / 6 (and named so), i.e. frac = (6 x those FLOPs per second) / 2.5 PFLOP/s."""
+    from rendernet_amd import ops  # noqa: F401
+    if not layer_events:
+        return None
+    layer_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in layer_events]))
+    kinds = {k for _, k in layer_events}
+    kind = kinds.pop() if len(kinds) == 1 else "mixed"
+    M = nloc * hw * hw
+    direct_flop = 2.0 * M * 9 * wtrunk * wtrunk                    # M*K*N*2 (SURVEY App. B)
+    where = " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc)
+    peak, peak_name = PEAK_FP32_MFMA_TFLOPS, None
+    if kind == "wino43" and gemm_events:
+        # three launches per layer; the dominant one is the GEMM stage (36 / 64 GEMMs T x Cin x Cout), timed on its own
+        kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
+        T, which = gemm_events[0][1][0], gemm_events[0][1][3]
+        nxi, fname = WINO_SCHEMES[which]
+        m = 6 if which == "f63" else 4
+        exec_flop = 2.0 * nxi * T * wtrunk * wtrunk
+        if gemm_mode == "split":
+            name = ("wino_gemm_bf3_kernel (GEMM stage of Winograd %s on split operands: 256x256x16 blocks, six 32x32x16 bf16 MFMAs per "
+                    "fp32 product tile, fp32 accumulate, LDS-DMA 3 stages, persistent)" % fname)
+            basis = ("fp32-equivalent FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles; every one executed as 6 bf16 "
+                     "piece products (x0y0, x0y1, x1y0, x0y2, x1y1, x2y0)" % (nxi, m, m))
+            peak, peak_name = PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 MFMA dense peak / 6 (six bf16 products per fp32 product)"
+            tkey = "wino63_gemm_bf3_res2" if which == "f63" else "wino43_gemm_bf3_res2"
+        else:
+            name = "wino43_gemm_kernel (GEMM stage of Winograd %s: 256x256x32 blocks, 32x32x2 fp32 MFMA, LDS-DMA, persistent)" % fname
+            basis = "executed MFMA FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles" % (nxi, m, m)
+            tkey = "wino63_gemm_res2" if which == "f63" else "wino43_gemm_res2"
+    else:
+        kern_ms = layer_ms
+        exec_flop = direct_flop * 16.0 / 36.0 if kind == "wino" else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
+        name = ("conv_wino_kernel (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA, fused transforms)" if kind == "wino" else
+                "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA)")
+        basis = "executed MFMA FLOPs = 2*(M/4)*16*Cin*Cout" if kind == "wino" else "2*M*9*Cin*Cout"
+        tkey = "conv_wino_res2" if kind == "wino" else "conv_igemm_res2"
+    achieved = exec_flop / (kern_ms * 1e-3) / 1e12
+    traffic, tsrc = read_traffic(tkey) if (mode == "render" and nloc == 24) else (None, None)
+    roof = {
+        "kernel": name + where,
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "avg_launch_ms": round(kern_ms, 4),
+        "launches_timed": len(gemm_events) if kind == "wino43" and gemm_events else len(layer_events), "flop_per_launch": exec_flop,
+        "flop_basis": basis,
+        "layer_ms": round(layer_ms, 4),       # the whole layer (wino43: input transform + GEMM + output transform)
+        "layer_effective_tflops_direct_equiv": round(direct_flop / (layer_ms * 1e-3) / 1e12, 2),
+        "traffic": traffic, "traffic_source": tsrc}
+    if peak_name:
+        roof["peak_name"] = peak_name
+        roof["bf16_tflops_executed"] = round(6.0 * achieved, 1)
+    return roof
+
+
 def render_main(args, world, rank, local_rank):
     import torch
     import torch.distributed as dist
@@ -377,24 +436,7 @@ def render_main(args, world, rank, local_rank):
     mode = args.mode
     wl = build_workload(mode, "cuda:%d" % local_rank)
     B = args.batch
-    if args.scaling == "strong":
-        # ONE batch of B frames split over the ranks in contiguous blocks
-        if B < world:
-            raise SystemExit("--scaling strong: batch %d < %d ranks" % (B, world))
-        vox_np, aux_np, poses_np = wl["inputs"](B)
-        lo, hi = shard_range(B, rank, world)
-        vox_np, poses_np = vox_np[lo:hi], poses_np[lo:hi]
-        aux_np = None if aux_np is None else aux_np[lo:hi]
-        total_frames = B
-    else:
-        vox_np, aux_np, poses_np = wl["inputs"](B)
-        poses_np = poses_np.copy()
-        poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)    # every rank its own pose set: independent shards
-        total_frames = B * world
-    vox = torch.as_tensor(vox_np).cuda()
-    poses = torch.as_tensor(poses_np).cuda()
-    aux = None if aux_np is None else torch.as_tensor(aux_np).cuda()
-    nloc = vox.shape[0]
+    hw, wtrunk = wl["trunk"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -402,50 +444,94 @@ def render_main(args, world, rank, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
 
-    hw, wtrunk = wl["trunk"]
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = wl["render"](vox, aux, poses)
-        # dominant kernel = the 3x3 conv of the res2 trunk (21 launches per step): bracket each of its launches with HIP
-        # events on the launch stream during the timed region; same for the resampler's launches
-        events, rs_events, gemm_events = [], [], []
+    def shard(scaling):
+        """This rank's inputs: weak -- its own batch of B frames (every rank its own pose set); strong -- ONE batch of B frames
+        split over the ranks in contiguous blocks (24 -> 24/12/6/3 per GPU)."""
+        vox_np, aux_np, poses_np = wl["inputs"](B)
+        if scaling == "strong":
+            if B < world:
+                raise SystemExit("--scaling strong: batch %d < %d ranks" % (B, world))
+            lo, hi = shard_range(B, rank, world)
+            vox_np, poses_np = vox_np[lo:hi], poses_np[lo:hi]
+            aux_np = None if aux_np is None else aux_np[lo:hi]
+            total = B
+        else:
+            poses_np = poses_np.copy()
+            poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)
+            total = B * world
+        return (torch.as_tensor(vox_np).cuda(), None if aux_np is None else torch.as_tensor(aux_np).cuda(),
+                torch.as_tensor(poses_np).cuda(), total)
+
+    def timed_pass(vox, aux, poses, gemm_mode, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; the dominant layer,
+        its GEMM stage and the resampler bracketed by HIP events on the launch stream.  -> (out, max-over-ranks seconds,
+        per-rank seconds, events)."""
+        ops.WINO_GEMM = gemm_mode
+        ev = {"layer": [], "gemm": [], "resample": []}
 
         def stage_hook(stage, tkn):
             if stage == "gemm" and tkn[1] == wtrunk and tkn[2] == wtrunk:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                gemm_events.append((ev, tkn))
-                return ev
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev["gemm"].append((e, tkn))
+                return e
             return None
 
         def hook(m, xshape, pw):
             if m == "resample":
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                rs_events.append((ev, xshape))
-                return ev
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev["resample"].append((e, xshape))
+                return e
             if m == "conv2d" and pw.cin == wtrunk and pw.cout == wtrunk and pw.kdims[0] == 3:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                events.append((ev, "wino43" if ops._use_wino43(pw, xshape[1], xshape[2]) else "wino" if pw.wino is not None else "direct"))
-                return ev
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev["layer"].append((e, "wino43" if ops._use_wino43(pw, xshape[1], xshape[2]) else "wino" if pw.wino is not None else "direct"))
+                return e
             return None
 
-        ops.LAUNCH_HOOK = hook
-        ops.STAGE_HOOK = stage_hook
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = wl["render"](vox, aux, poses)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        ops.LAUNCH_HOOK = None
-        ops.STAGE_HOOK = None
+        with torch.no_grad():
+            for _ in range(warmup):
+                out = wl["render"](vox, aux, poses)
+            ops.LAUNCH_HOOK, ops.STAGE_HOOK = hook, stage_hook
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = wl["render"](vox, aux, poses)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            ops.LAUNCH_HOOK = ops.STAGE_HOOK = None
+        ops.WINO_GEMM = "f32"
+        if isinstance(out, (tuple, list)):
+            out = torch.cat(list(out), dim=3)          # after the timed region: the checks below index one [n,H,W,6] tensor
+        assert out.shape == (vox.shape[0], wl["out_hw"], wl["out_hw"], wl["out_ch"])
+        assert bool(torch.isfinite(out).all())
+        by_rank = gather_per_rank(elapsed, world, rank)
+        return out, max(by_rank), by_rank, ev
 
-    if isinstance(out, (tuple, list)):
-        out = torch.cat(list(out), dim=3)          # after the timed region: the checks below index one [n,H,W,6] tensor
-    assert out.shape == (nloc, wl["out_hw"], wl["out_hw"], wl["out_ch"])
-    assert bool(torch.isfinite(out).all())
-    by_rank = gather_per_rank(elapsed, world, rank)
+    # ---- the primary pass: exact-fp32 MFMA everywhere
+    vox, aux, poses, total_frames = shard(args.scaling)
+    nloc = vox.shape[0]
+    out, elapsed, by_rank, ev = timed_pass(vox, aux, poses, "f32", args.steps, args.warmup)
     frames_by_rank = gather_per_rank(nloc, world, rank)
-    elapsed = max(by_rank)
+    # ---- the same steps with the multiply stage of the wide 2-D layers on the bf16 pipe (fp32 accuracy by operand splitting)
+    alt = None
+    if not args.no_alt:
+        out_alt, el_alt, by_rank_alt, ev_alt = timed_pass(vox, aux, poses, "split", args.steps, max(1, args.warmup))
+        alt = (out_alt, el_alt, by_rank_alt, ev_alt)
+    # ---- N > 1: the other scaling regime as well (weak: every rank its own batch; strong: ONE batch split 24 -> 24/N)
+    other = None
+    if world > 1 and not args.no_other_scaling:
+        oscal = "strong" if args.scaling == "weak" else "weak"
+        if not (oscal == "strong" and B < world):
+            v2, a2, p2, tot2 = shard(oscal)
+            o2, el2, br2, _ = timed_pass(v2, a2, p2, "f32", args.steps, 1)
+            fr2 = gather_per_rank(v2.shape[0], world, rank)
+            other = {"scaling": oscal, "value": round(tot2 * args.steps / el2, 3), "unit": "frames/s",
+                     "ms_per_step": round(1e3 * el2 / args.steps, 3), "global_batch": tot2,
+                     **per_rank_fields(br2, fr2, args.steps)}
+            if alt is not None:
+                o3, el3, br3, _ = timed_pass(v2, a2, p2, "split", args.steps, 1)
+                other["alt_value"] = round(tot2 * args.steps / el3, 3)
+                other["alt_ms_per_step"] = round(1e3 * el3 / args.steps, 3)
+            del v2, a2, p2, o2
     if rank != 0:
         return
 
@@ -468,41 +554,12 @@ def render_main(args, world, rank, local_rank):
         "effective_tflops_direct_equiv": round(fps / world * gmac * 2e-3, 2),
         **per_rank_fields(by_rank, frames_by_rank, args.steps),
     }
-    if events:
-        layer_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in events]))
-        kinds = {k for _, k in events}
-        kind = kinds.pop() if len(kinds) == 1 else "mixed"
-        M = nloc * hw * hw
-        direct_flop = 2.0 * M * 9 * wtrunk * wtrunk                    # M*K*N*2
-        where = " on the res2 3x3 %d->%d conv @%dx%dx%d" % (wtrunk, wtrunk, hw, hw, nloc)
-        if kind == "wino43" and gemm_events:
-            # three launches per layer; the dominant one is the GEMM stage (36 / 64 GEMMs T x Cin x Cout), timed on its own
-            kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
-            T, which = gemm_events[0][1][0], gemm_events[0][1][3]
-            nxi, fname = WINO_SCHEMES[which]
-            m = 6 if which == "f63" else 4
-            exec_flop = 2.0 * nxi * T * wtrunk * wtrunk
-            name = "wino43_gemm_kernel (GEMM stage of Winograd %s: 256x256x32 blocks, 32x32x2 fp32 MFMA, LDS-DMA, persistent)" % fname
-            basis = "executed MFMA FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles" % (nxi, m, m)
-            tkey = "wino63_gemm_res2" if which == "f63" else "wino43_gemm_res2"
-        else:
-            kern_ms = layer_ms
-            exec_flop = direct_flop * 16.0 / 36.0 if kind == "wino" else direct_flop   # F(2x2,3x3): 16 multiplies per 2x2 tile vs 36
-            name = ("conv_wino_kernel (Winograd F(2x2,3x3), 16x16x4 fp32 MFMA, fused transforms)" if kind == "wino" else
-                    "conv_igemm_glds_kernel (128x128x32 tile, LDS-DMA)")
-            basis = "executed MFMA FLOPs = 2*(M/4)*16*Cin*Cout" if kind == "wino" else "2*M*9*Cin*Cout"
-            tkey = "conv_wino_res2" if kind == "wino" else "conv_igemm_res2"
-        achieved = exec_flop / (kern_ms * 1e-3) / 1e12
-        traffic, tsrc = read_traffic(tkey) if (mode == "render" and nloc == 24) else (None, None)
-        res["roofline"] = {
-            "kernel": name + where,
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(kern_ms, 4),
-            "launches_timed": len(gemm_events) if kind == "wino43" and gemm_events else len(events), "flop_per_launch": exec_flop,
-            "flop_basis": basis,
-            "layer_ms": round(layer_ms, 4),       # the whole layer (wino43: input transform + GEMM + output transform)
-            "layer_effective_tflops_direct_equiv": round(direct_flop / (layer_ms * 1e-3) / 1e12, 2),
-            "traffic": traffic, "traffic_source": tsrc}
+    if other is not None:
+        res["other_scaling"] = other
+    roof = gemm_roofline(ev["gemm"], ev["layer"], wtrunk, hw, nloc, mode, "f32")
+    if roof is not None:
+        res["roofline"] = roof
+    rs_events = ev["resample"]
     if rs_events:
         # second roofline of the path: the resampler is HBM-bound (per frame and channel 1 MiB (64^3) source
         # read + 8 MiB (128^3) grid written); all its launches of a step are summed
@@ -518,6 +575,7 @@ def render_main(args, world, rank, local_rank):
     # rank 0's frames as bench-batch indices (weak: rank 0 renders the un-shifted batch; strong: the first block)
     frame_ids = list(range(nloc))
     failures = []
+    want = None
     if world == 1 and not args.no_cpu_baseline:
         rec, want = cpu_baseline(wl["weights"], mode, frames=min({"render": 4, "texture": 2, "stress": 1}[mode], nloc))
         got = out[:want.shape[0]].cpu().numpy()
@@ -536,6 +594,32 @@ def render_main(args, world, rank, local_rank):
         res["parity_golden" if "parity" in res else "parity"] = gp
         if not gp["ok"]:
             failures.append("max|gpu - committed oracle render| = %g > %g (frames %s)" % (gp["max_abs_err"], PARITY_TOL, gp["frames"]))
+    if alt is not None:
+        out_alt, el_alt, by_rank_alt, ev_alt = alt
+        fps_alt = total_frames * args.steps / el_alt
+        ablk = {"dtype": "bf16x3-split, fp32 accumulate",
+                "what": "the same steps with the GEMM stage of the wide stride-1 2-D convs (res2, res3, *_skip, e_conv5, e_conv6) on the "
+                        "bf16 matrix pipe: every fp32 operand as three bf16 pieces, six piece products with i + j <= 2, fp32 "
+                        "accumulation (csrc/conv_wino_bf3.hip); every other kernel unchanged (exact fp32)",
+                "value": round(fps_alt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el_alt / args.steps, 3),
+                "steps": args.steps, "speedup_vs_value": round(fps_alt / fps, 4),
+                **per_rank_fields(by_rank_alt, frames_by_rank, args.steps)}
+        aroof = gemm_roofline(ev_alt["gemm"], ev_alt["layer"], wtrunk, hw, nloc, mode, "split")
+        if aroof is not None:
+            ablk["roofline"] = aroof
+        if want is not None:
+            aerr = float(np.abs(out_alt[:want.shape[0]].cpu().numpy() - want).max())
+            ablk["parity"] = {"frames": int(want.shape[0]), "max_abs_err": aerr, "tol": PARITY_TOL, "ok": aerr <= PARITY_TOL,
+                              "reference": "the same live oracle render as `parity`"}
+            if aerr > PARITY_TOL:
+                failures.append("alt (split): max|gpu - oracle| = %g > %g" % (aerr, PARITY_TOL))
+        agp = golden_parity(mode, out_alt, frame_ids)
+        if agp is not None:
+            ablk["parity_golden" if "parity" in ablk else "parity"] = agp
+            if not agp["ok"]:
+                failures.append("alt (split): max|gpu - committed oracle render| = %g > %g" % (agp["max_abs_err"], PARITY_TOL))
+        ablk["max_abs_diff_vs_primary_output"] = float((out_alt - out).abs().max())
+        res["alt"] = ablk
     print(json.dumps(res), flush=True)
     if failures:
         raise SystemExit("PARITY FAILURE: " + "; ".join(failures))
@@ -591,6 +675,8 @@ def main():
                     help="render = the headline metric (BASELINE configs[1]); texture = configs[2]; stress = configs[4] "
                          "(128^3 -> 1024^2, batch 8); train = the training step of configs[3] (samples/s)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second timed pass (split bf16x3 GEMM stage) and its `alt` block")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the pass in the other scaling regime (`other_scaling`)")
     ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")
     args = ap.parse_args()
     if args.batch is None:

@@ -10,7 +10,7 @@ import torch
 
 from rendernet_amd import ops
 
-SCHEMES = ("direct", "f22", "f43", "f63")
+SCHEMES = ("direct", "f22", "f43", "f63", "f43s", "f63s")      # ...s: the split (bf16x3) GEMM stage of the same scheme
 
 
 def xavier(rng, shape):
@@ -40,6 +40,9 @@ def hostile_inputs(rng, B, H, W, Cin, Cout):
 def conv_with_scheme(x, w, b, scheme, alpha=None, residual=None):
     """x [B,H,W,Cin], w [3,3,Cin,Cout] HIP tensors -> conv through the kernel family `scheme` forces."""
     pw = ops.pack_conv(w)
+    split = scheme.endswith("s")
+    if split:
+        scheme = scheme[:-1]
     if scheme == "direct":
         pw.wino43 = None
         pw.wino = None
@@ -54,8 +57,13 @@ def conv_with_scheme(x, w, b, scheme, alpha=None, residual=None):
         pw.force_scheme = "f63"
     else:
         raise ValueError(scheme)
-    with torch.no_grad():
-        return ops.conv2d(x, pw, b, alpha, residual)
+    old = ops.WINO_GEMM
+    ops.WINO_GEMM = "split" if split else "f32"
+    try:
+        with torch.no_grad():
+            return ops.conv2d(x, pw, b, alpha, residual)
+    finally:
+        ops.WINO_GEMM = old
 
 
 def res_stack_weights(rng, C, n_blocks=10):

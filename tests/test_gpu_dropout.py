@@ -122,8 +122,8 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
 
     ref = run(Trainer(spec, w, **kw), range(3))
     ref2 = run(Trainer(spec, w, **kw), range(3))
-    def dist(p, q):
-        return float(torch.quantile((p - q).abs()[::7].float(), 0.99))          # every 7th parameter: quantile() caps its input size
+    def dist(p, q, quant=0.99):
+        return float(torch.quantile((p - q).abs()[::7].float(), quant))         # every 7th parameter: quantile() caps its input size
 
     spread = dist(ref2.param, ref.param)                            # wgrad accumulates with atomics: order varies
     a = run(Trainer(spec, w, **kw), range(2))
@@ -139,4 +139,8 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     run(c, [2])
     cold = dist(c.param, ref.param)
     assert b.global_step == 3 and resumed <= max(20 * spread, 2e-5), (resumed, spread)     # lr = 1e-3: a step is ~1e-3
-    assert cold > 10 * (resumed + 1e-7), (cold, resumed)
+    # the weights-only restart is off for (nearly) EVERY parameter -- lr staircase back at step 0, Adam at t = 1 -- so compare the
+    # MEDIANS: the kink crossings above reach a few per cent of the parameters in some runs (seen: 99th percentile 3.9e-4 against
+    # 1.5e-3 cold), the median of a correct resume stays at the last-bits level
+    cold_med, resumed_med = dist(c.param, ref.param, 0.5), dist(b.param, ref.param, 0.5)
+    assert cold > resumed and cold_med > 10 * (resumed_med + 1e-7), (cold, resumed, cold_med, resumed_med)

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from scripts import robust_util as RU
 
 pytestmark = pytest.mark.gpu
-BAR = {"direct": 3e-5, "f22": 3e-5, "f43": 3e-5, "f63": 1e-4}
+BAR = {"direct": 3e-5, "f22": 3e-5, "f43": 3e-5, "f63": 1e-4, "f43s": 3e-5, "f63s": 1e-4}      # the split stage: the SAME bars
 C = 1024
 
 
@@ -123,14 +123,19 @@ def test_f44_layers_on_hostile_statistics(k):
     ymax = float(want.abs().max())
     xd, wd, bd = (torch.as_tensor(a).cuda() for a in (x, w, b))
     errs = {}
-    for scheme in ("f44", "f22x4", "direct"):
+    for scheme in ("f44", "f44s", "f22x4", "direct"):
         pw = ops.pack_conv(wd)
-        if scheme != "f44":
+        if scheme not in ("f44", "f44s"):
             pw.wino43 = None
         if scheme == "direct":
             pw.wino4 = None
-        with torch.no_grad():
-            got = ops.conv2d(xd, pw, bd)
+        old = ops.WINO_GEMM
+        ops.WINO_GEMM = "split" if scheme == "f44s" else "f32"
+        try:
+            with torch.no_grad():
+                got = ops.conv2d(xd, pw, bd)
+        finally:
+            ops.WINO_GEMM = old
         errs[scheme] = float((got.cpu().double() - want).abs().max()) / ymax
     print("%s (4x4 filter): max|y| %.3g  " % (name, ymax) + "  ".join("%s %.2e" % kv for kv in errs.items()))
-    assert errs["f44"] <= 1e-4 and errs["f22x4"] <= 3e-5 and errs["direct"] <= 3e-5, errs
+    assert errs["f44"] <= 1e-4 and errs["f44s"] <= 1e-4 and errs["f22x4"] <= 3e-5 and errs["direct"] <= 3e-5, errs

@@ -1,0 +1,217 @@
+"""The split (bf16x3, fp32-accumulate) multiply stage of the three-launch Winograd path (csrc/conv_wino_bf3.hip).  -m gpu.
+
+The layers it serves are the wide stride-1 2-D convs of the reference -- res_block_2d / *_skip (slim.conv2d [3,3],
+tools/layer_util.py:91-105, RenderNet_Shader.py:71-84, :91-99) and e_conv5 / e_conv6 (slim.conv2d [4,4], :86-88, :101-103).
+Gates: the SAME bars as the exact-fp32 route -- every conv flavour <= 1e-4 * max|ref| against the oracle conv
+(oracle/layers.py), the hostile-statistics suite against float64 (tests/test_gpu_wino_robust.py carries the split schemes
+in its table), every sampled tap of the benched frames <= 2e-4 * max, image <= 1e-3 -- plus statements of the two layouts
+(packed filter, transformed input) in NumPy: the three bf16 pieces must sum to the fp32 value they replace."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import layers as OL
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _xavier(rng, shape):
+    rf = int(np.prod(shape[:-2]))
+    lim = np.sqrt(6.0 / ((shape[-2] + shape[-1]) * rf))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+def _close(got, want, what, rtol=1e-4):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err, ref = float(np.abs(got - want).max()), float(np.abs(want).max())
+    assert err <= rtol * ref + 1e-7, "%s: max err %g, max |ref| %g" % (what, err, ref)
+
+
+def _bf16_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _rows_to_planes(rows, nrows_axis_bit3):
+    """rows [..., R, 48] uint16 (96-byte rows: 3 planes x 2 chunks x 8 bf16, the chunks swapped where bit 3 of the row index
+    is set) -> [..., R, 3, 16] uint16 in channel order."""
+    r = rows.reshape(rows.shape[:-1] + (3, 2, 8)).copy()
+    swap = nrows_axis_bit3.astype(bool)
+    r[..., swap, :, :, :] = r[..., swap, :, ::-1, :]
+    return r.reshape(rows.shape[:-1] + (3, 16))
+
+
+SCHEMES = {"f43": (0, 36, 4, 3), "f44": (1, 49, 4, 4), "f63": (2, 64, 6, 3)}      # name -> (scheme id, planes, tile, filter)
+
+
+@pytest.mark.parametrize("which,cin,cout,transposed", [("f43", 64, 256, 0), ("f63", 96, 512, 0), ("f44", 32, 256, 0),
+                                                         ("f63", 256, 256, 1), ("f44", 256, 256, 1)])
+def test_split_pack_is_the_fp32_pack_in_three_pieces(which, cin, cout, transposed):
+    """rn_winograd_split_pack: Us [nxi][Cout/256][Cin/16][256][3][16]; the pieces of every element sum to the element of the
+    fp32 pack (rn_pack_weights, same double-precision transform) EXACTLY, each piece is a bf16 of the running remainder."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    sid, nxi, _, R = SCHEMES[which]
+    rng = np.random.default_rng(cin * 7 + cout)
+    w = _xavier(rng, (R, R, cout, cin) if transposed else (R, R, cin, cout))
+    pw = ops.pack_conv_transpose(_dev(w), 1) if transposed else ops.pack_conv(_dev(w))
+    u32 = (pw.wino63 if which == "f63" else pw.wino43).cpu().numpy().reshape(nxi, cout // 256, cin // 4, 256, 4)
+    us = pw.split(which).cpu().numpy().view(np.uint16).reshape(nxi, cout // 256, cin // 16, 256, 48)
+    planes = _rows_to_planes(us, (np.arange(256) >> 3) & 1)                       # [nxi, nb, s, 256, 3, 16]
+    want = u32.reshape(nxi, cout // 256, cin // 16, 4, 256, 4).transpose(0, 1, 2, 4, 3, 5).reshape(nxi, cout // 256, cin // 16, 256, 16)
+    p = _bf16_to_f64(planes)
+    assert np.array_equal(p[..., 0, :] + p[..., 1, :] + p[..., 2, :], want.astype(np.float64))
+    # piece 0 is the nearest bf16 of the value: |x - p0| <= half a bf16 ulp = 2^-9 |x| (and so on down the remainders)
+    assert np.all(np.abs(want - p[..., 0, :]) <= 2.0 ** -8 * np.abs(want) + 1e-45)
+    assert np.all(np.abs(want - p[..., 0, :] - p[..., 1, :]) <= 2.0 ** -16 * np.abs(want) + 1e-45)
+    assert L.lib().rn_winograd_split_packed_bytes(sid, cin, cout) == us.size * 2
+
+
+@pytest.mark.parametrize("which,B,H,W,C", [("f63", 2, 13, 16, 64), ("f43", 3, 9, 11, 96), ("f44", 1, 16, 16, 32), ("f63", 5, 64, 64, 128)])
+def test_split_input_transform_is_the_fp32_transform_in_three_pieces(which, B, H, W, C):
+    """rn_winograd_split_input_transform: Vs [nxi][C/16][T][3][16] holds V = B^T d B of rn_winograd_input_transform as three bf16
+    pieces per element (exact sum; the two kernels may contract their FMAs differently: V itself within 2 ulp-ish)."""
+    from rendernet_amd import _lib as L
+    sid, nxi, m, _ = SCHEMES[which]
+    lib = L.lib()
+    rng = np.random.default_rng(H * 31 + W)
+    x = _dev(rng.standard_normal((B, H, W, C)).astype(np.float32))
+    T = B * (-(-H // m)) * (-(-W // m))
+    V = torch.empty(nxi * T * C, device="cuda")
+    L.check(lib.rn_winograd_input_transform(sid, L.ptr(x), L.ptr(V), B, H, W, C, 1, L.stream_ptr()), "input")
+    nb = lib.rn_winograd_split_v_bytes(sid, T, C)
+    assert nb >= nxi * T * C * 6
+    Vs = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    L.check(lib.rn_winograd_split_input_transform(sid, L.ptr(x), ctypes.c_void_p(Vs.data_ptr()), B, H, W, C, 1, L.stream_ptr()), "split input")
+    rows = Vs.cpu().numpy()[:nxi * T * C * 6].view(np.uint16).reshape(nxi, C // 16, T, 48)
+    p = _bf16_to_f64(_rows_to_planes(rows, (np.arange(T) >> 3) & 1))            # [nxi, s, T, 3, 16]
+    got = (p[..., 0, :] + p[..., 1, :] + p[..., 2, :]).transpose(0, 2, 1, 3).reshape(nxi, T, C)
+    want = V.cpu().numpy().reshape(nxi, T, C).astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    assert np.array_equal(got.astype(np.float32).astype(np.float64), got)        # the sum of the pieces IS an fp32 number
+
+
+CASES = [   # (which, B, H, W, Cin, Cout): ragged planes, 1 .. many tiles (below / across / above the 256-row block, the 128-row
+            # item plan, partial rounds), one K step pair .. 64, 1 .. 4 channel blocks
+    ("f43", 1, 4, 4, 32, 256), ("f43", 2, 16, 16, 256, 256), ("f43", 3, 33, 5, 96, 256), ("f43", 1, 16, 16, 1024, 512),
+    ("f43", 5, 30, 34, 128, 1024), ("f43", 2, 64, 64, 64, 256),
+    ("f63", 1, 6, 6, 32, 256), ("f63", 1, 1, 1, 32, 256), ("f63", 1, 13, 16, 1024, 512), ("f63", 5, 30, 34, 128, 1024),
+    ("f63", 2, 64, 64, 64, 256), ("f63", 3, 64, 64, 256, 512), ("f63", 6, 64, 64, 32, 1024), ("f63", 9, 64, 64, 64, 256),
+    ("f44", 1, 5, 7, 32, 256), ("f44", 2, 16, 16, 256, 256), ("f44", 1, 64, 64, 64, 512), ("f44", 3, 33, 9, 128, 256),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_split_vs_oracle(case):
+    """ops.conv2d with ops.WINO_GEMM = "split" vs the oracle conv (bias / PReLU / residual / pre-activation / sigmoid
+    epilogues), vs the exact-fp32 route on the same filter, and the input gradient through the transposed pack."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    which, B, H, W, Cin, Cout = case
+    sid, nxi, m, R = SCHEMES[which]
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = _xavier(rng, (R, R, Cin, Cout))
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    old_min, old_mode = ops.WINO43_MIN_PIXELS, ops.WINO_GEMM
+    ops.WINO43_MIN_PIXELS = 1
+    try:
+        y0 = OL.conv2d(x, w, b, (1, 1))
+        res = rng.standard_normal(y0.shape).astype(np.float32)
+        outs = {}
+        for mode in ("f32", "split"):
+            ops.WINO_GEMM = mode
+            pw = ops.pack_conv(_dev(w))
+            if which != "f44":
+                pw.force_scheme = which
+            with torch.no_grad():
+                outs[mode] = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+                if mode == "split":
+                    _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "split %s" % which)
+                    _close(ops.conv2d(_dev(x), pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "split+sigmoid")
+        _close(outs["split"], OL.prelu(y0, alpha) + torch.from_numpy(res), "split %s +prelu+res" % which)
+        assert float((outs["split"] - outs["f32"]).abs().max()) <= 1e-4 * float(outs["f32"].abs().max())
+        assert not torch.equal(outs["split"], outs["f32"]) or Cin * H * W < 64       # (a different summation, not the same bits)
+        # the C entry with the pre-activation output
+        lib = L.lib()
+        ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sid, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+        yy, zz = torch.empty(y0.shape, device="cuda"), torch.empty(y0.shape, device="cuda")
+        xd, bd, ad = _dev(x), _dev(b), _dev(alpha)
+        L.check(lib.rn_conv2d_winograd_split_fwd(sid, L.ptr(xd), ctypes.c_void_p(pw.split(which).data_ptr()), L.ptr(bd),
+                                                 L.ptr(ad), None, L.ptr(yy), L.ptr(zz), ctypes.c_void_p(ws.data_ptr()),
+                                                 B, H, W, Cin, Cout, 0, 1, L.stream_ptr()), "rn_conv2d_winograd_split_fwd")
+        _close(zz, y0, "split preact")
+        _close(yy, OL.prelu(y0, alpha), "split prelu")
+        if Cin % 256 == 0:                               # the conv's input gradient: the transposed pack of the same filter
+            dp = pw.dgrad_pack(True)
+            dz = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+            dx = torch.empty((B, H, W, Cin), device="cuda")
+            if which != "f44":
+                dp.force_scheme = which
+            ops.WINO_GEMM = "split"
+            dzd = _dev(dz)
+            L.check(ops._wino43_fwd(dzd, dp, (None, None, None, L.ptr(dx), None), B, H, W, Cout, Cin, 0), "split dgrad")
+            _close(dx, OL.conv2d_transpose(dz, w, None, (1, 1)), "split dgrad vs oracle")
+    finally:
+        ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
+
+
+def test_conv2d_transpose_s1_split():
+    """e_conv7_1-like stride-1 transposed 4x4 conv (slim.conv2d_transpose, RenderNet_Shader.py:109-111) through F(4x4,4x4) on
+    the split stage (pad two before)."""
+    from rendernet_amd import ops
+    rng = np.random.default_rng(5)
+    B, H, W, Cin, Cout = 2, 16, 18, 256, 256
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    wt = _xavier(rng, (4, 4, Cout, Cin))
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    old_min, old_mode = ops.WINO43_MIN_PIXELS, ops.WINO_GEMM
+    ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = 1, "split"
+    try:
+        pt = ops.pack_conv_transpose(_dev(wt), 1)
+        assert pt.split("f44") is not None
+        with torch.no_grad():
+            got = ops.conv2d_transpose(_dev(x), pt, _dev(b), None, None, (1, 1))
+        _close(got, OL.conv2d_transpose(x, wt, b, (1, 1)), "split convT s1")
+    finally:
+        ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
+
+
+def test_bench_frames_match_golden_split(fixtures_vox):
+    """The benched configuration with the split stage: the five golden frames of bench.py's batch (tests/golden/bench_frames.npz,
+    oracle output) at the bars of tests/test_gpu_net.py::test_bench_frames_match_golden -- sampled taps <= 2e-4 * max, image
+    <= 1e-3, logits <= 5e-4 * max."""
+    from rendernet_amd import ops
+    from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
+    from bench import synthetic_batch
+    g = np.load(os.path.join(GOLDEN_DIR, "bench_frames.npz"))
+    idx = [int(i) for i in g["frames"]]
+    vox, poses = synthetic_batch(24)
+    spec = ShaderSpec().check()
+    r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True))
+    old = ops.WINO_GEMM
+    ops.WINO_GEMM = "split"
+    try:
+        taps = {}
+        out = r.render(vox[idx], poses[idx], taps=taps).cpu().numpy()
+    finally:
+        ops.WINO_GEMM = old
+    for k in range(5):
+        e4 = taps["enc4"][k, 3::8, 5::8, :].cpu().numpy()
+        assert np.abs(e4 - g["enc4_%d" % k]).max() <= 2e-4 * np.abs(g["enc4_%d" % k]).max() + 1e-6
+        for c, (r0, c0) in enumerate(g["crops"]):
+            crop = out[k, r0:r0 + 128, c0:c0 + 128, 0]
+            assert np.abs(crop - g["output_%d" % k][c]).max() <= 1e-3, (k, c)
+            lg = np.log(crop.astype(np.float64) / (1 - crop.astype(np.float64)))
+            want = g["logits_%d" % k][c]
+            assert np.abs(lg - want).max() <= 5e-4 * np.abs(want).max() + 1e-5, (k, c)
