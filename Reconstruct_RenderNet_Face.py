@@ -48,14 +48,15 @@ def main(argv=None):
     max_steps = int(argv[argv.index("--max-steps") + 1]) if "--max-steps" in argv else None
 
     dec_spec = RC.ShapeDecoderSpec(z_dim=int(cfg['z_dim']))
-    weights = None
+    weight_dict_MLP = weight_dict_decoder = None
     wd, wdd = cfg.get('weight_dir', ''), cfg.get('weight_dir_decoder', '')
     if os.path.isdir(wd) and os.path.isdir(wdd):
-        weights = RC.state_from_pretrained(RC.load_weights(wd), RC.load_weights(wdd), dec_spec=dec_spec)
+        weight_dict_MLP, weight_dict_decoder = RC.load_weights(wd), RC.load_weights(wdd)      # :337-339, by the reference's keys
     else:
         print("weight_dir / weight_dir_decoder not found: using seeded random weights (the reference ships no trained model)")
     ambient_in, k_diffuse, light_col = 0.0, 1.0, (1.0, 1.0, 1.0)                             # :323-325
-    rec = RC.Reconstructor(dec_spec=dec_spec, weights=weights, batch_size=int(cfg['batch_size']),
+    rec = RC.Reconstructor(dec_spec=dec_spec, weight_dict_rendernet=weight_dict_MLP, weight_dict_decoder=weight_dict_decoder,
+                           batch_size=int(cfg['batch_size']),
                            light_elevation_deg=float(cfg['target_elevation_light']), light_col=light_col,
                            ambient=ambient_in, k_diffuse=k_diffuse, shape_eta=cfg['shape_eta'], pose_eta=cfg['pose_eta'],
                            tex_eta=cfg['tex_eta'], light_eta=cfg['light_eta'])

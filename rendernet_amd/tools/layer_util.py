@@ -122,13 +122,29 @@ def fully_connected(input_, output_size, reuse=False, scope='fully_connected', i
     return ops.fully_connected(input_, w, b, activation_alpha)
 
 
+_RELU_SLOPE = {}
+
+
+def _relu_slope(channels, device):
+    """tf.nn.relu through the PReLU epilogue: a CONSTANT all-zero slope vector (max(0,x) + 0*min(0,x)), cached per
+    (device, width) -- not a variable: the pretrained res blocks have no `alpha` (tools/layer_util.py:75-88, :107-121)."""
+    import torch
+    key = (str(device), int(channels))
+    t = _RELU_SLOPE.get(key)
+    if t is None:
+        t = _RELU_SLOPE[key] = torch.zeros(int(channels), dtype=torch.float32, device=device)
+    return t
+
+
 def res_block_3d(input, out_channels=64, scope='res_block', kernel=[3, 3, 3], stride=[1, 1, 1], weight_dict=None,
                  trainable=True):
-    """tools/layer_util.py:60-88: input + conv3d(prelu(conv3d(input))).  PReLU and the residual add
-    run in the epilogues of the two conv launches."""
+    """tools/layer_util.py:60-88: input + conv3d(act(conv3d(input))).  The two branches of the reference are two different
+    functions: WITHOUT a weight_dict (:66-73) the activation is prelu with an `alpha` variable in the block scope (:69 ->
+    :35-40); WITH one (:75-88, the pretrained nets of Reconstruct_RenderNet_Face.py:150-159) it is tf.nn.relu and NO alpha
+    variable exists.  Activation and residual add run in the epilogues of the two conv launches."""
     wd = weight_dict
     with _store().variable_scope(scope):
-        alpha = _alpha_var(out_channels)          # `alpha` lives in the block scope (:69 -> :35-40)
+        alpha = _alpha_var(out_channels) if wd is None else _relu_slope(out_channels, input.device)
         net = conv3d(input, out_channels, kernel_size=kernel, stride=stride, pad="SAME", scope="con1_3X3",
                      weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
                      bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
@@ -142,18 +158,21 @@ def res_block_3d(input, out_channels=64, scope='res_block', kernel=[3, 3, 3], st
 
 def res_block_2d(input, out_channels=64, scope='res_block', kernel=[3, 3], stride=[1, 1], weight_dict=None,
                  trainable=True):
-    """tools/layer_util.py:91-121 (slim branch: zero-initialised biases)."""
+    """tools/layer_util.py:91-121.  Without a weight_dict (:98-105): slim.conv2d (zero-initialised biases) + prelu with an
+    `alpha` variable; with one (:107-121; Reconstruct_RenderNet_Face.py:183-192, :213-217): the hand-rolled conv2d (bias
+    constant 0.001 unless the dict has it) + tf.nn.relu, no alpha variable."""
     wd = weight_dict
     with _store().variable_scope(scope):
-        alpha = _alpha_var(out_channels)
+        alpha = _alpha_var(out_channels) if wd is None else _relu_slope(out_channels, input.device)
+        db = 0.0 if wd is None else 0.001
         net = conv2d(input, out_channels, kernel_size=kernel, stride=stride, scope="con1_3X3",
                      weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
                      bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
-                     weight_initializer_type=xavier_initializer(), activation_alpha=alpha, default_bias=0.0)
+                     weight_initializer_type=xavier_initializer(), activation_alpha=alpha, default_bias=db)
         net = conv2d(net, out_channels, kernel_size=kernel, stride=stride, scope="conv2_3x3",
                      weight_initializer=get_weight(scope + '_conv2_3x3_weights', wd),
                      bias_initializer=get_weight(scope + '_conv2_3x3_biases', wd),
-                     weight_initializer_type=xavier_initializer(), residual=input, default_bias=0.0)
+                     weight_initializer_type=xavier_initializer(), residual=input, default_bias=db)
     return net
 
 
@@ -169,18 +188,20 @@ def res_stack_2d(input, out_channels, n_blocks, scope_fmt='res_%d', kernel=[3, 3
     for k in range(1, n_blocks + 1):
         scope = scope_fmt % k
         with st.variable_scope(scope):
-            alpha = _alpha_var(out_channels)
+            # the two branches of res_block_2d (tools/layer_util.py:98-105 | :107-121): prelu + alpha variable | relu, no alpha
+            alpha = _alpha_var(out_channels) if wd is None else _relu_slope(out_channels, input.device)
             packs = []
             for cs in ("con1_3X3", "conv2_3x3"):
                 w, wname, b = _conv_vars(cs, list(kernel) + [input.shape[-1], out_channels], True,
                                          get_weight(scope + '_' + cs + '_weights', wd), get_weight(scope + '_' + cs + '_biases', wd),
-                                         xavier_initializer(), out_channels, 0.0)
+                                         xavier_initializer(), out_channels, 0.0 if wd is None else 0.001)
                 packs.append((st.packed(wname, lambda w=w: ops.pack_conv(w)), b))
             blocks.append((packs[0][0], packs[0][1], alpha, packs[1][0], packs[1][1]))
     skip = None
     if skip_scope is not None:
         with st.variable_scope(skip_scope):
-            w, wname, b = _conv_vars("con1_3X3", list(kernel) + [input.shape[-1], out_channels], True, None, None,
+            w, wname, b = _conv_vars("con1_3X3", list(kernel) + [input.shape[-1], out_channels], True,
+                                     get_weight(skip_scope + '_con1_3X3_weights', wd), get_weight(skip_scope + '_con1_3X3_biases', wd),
                                      xavier_initializer(), out_channels, skip_default_bias)
             skip = (st.packed(wname, lambda: ops.pack_conv(w)), b, skip_residual)
     return ops.res_stack_2d(input, blocks, skip)

@@ -128,35 +128,41 @@ def test_conv3d_transpose_elu_forward_and_input_gradient(shape):
     assert torch.equal(got2, got.detach())
 
 
-def _tiny_setup(B=2):
+def _tiny_setup(B=2, extra_res_alpha=False):
+    """Tiny pretrained stand-ins keyed as the reference's weight folders (rendernet_amd.reconstruct.init_pretrained_weight_dicts).
+    extra_res_alpha: the RenderNet dict additionally carries NON-ZERO res*_alpha tensors -- which the reference's graph never
+    reads (tools/layer_util.py:75-88, :107-121)."""
     from rendernet_amd import reconstruct as RC
-    from rendernet_amd.texture import tiny_texture_spec, init_texture_weights
+    from rendernet_amd.texture import tiny_texture_spec
     ts, ds = tiny_texture_spec(), RC.tiny_shape_decoder_spec()
-    w = dict(init_texture_weights(ts, seed=77, perturb=True))
-    w.update(RC.init_shape_decoder_weights(ds, seed=78, perturb=True))
-    w["g_conv4/weights"] = w["g_conv4/weights"] * 30           # give the random-init volume some structure
+    wr, wd = RC.init_pretrained_weight_dicts(ts, ds, seed=77, perturb=True)
+    wd["g_conv4_weights"] = wd["g_conv4_weights"] * 30           # give the random-init volume some structure
     rng = np.random.default_rng(6)
+    if extra_res_alpha:
+        for blk, n, c in (("res1", ts.n_res1, ts.c3), ("res2", ts.n_res2, ts.w_res2), ("res3", ts.n_res3, ts.w5)):
+            for i in range(1, n + 1):
+                wr["%s_%d_alpha" % (blk, i)] = rng.uniform(0.1, 0.25, c).astype(np.float32)
     lat = dict(vector=rng.standard_normal((B, ds.z_dim)).astype(np.float32) * 2,
                param=np.array([[4.36, 0.52, 1.0], [4.0, 0.9, 1.0]], np.float32)[:B],
                texture=rng.standard_normal((B, ts.z_dim)).astype(np.float32),
                light=np.array([[4.2], [5.1]], np.float32)[:B])
     target = rng.uniform(0, 1, (B, 128, 128, 3)).astype(np.float32)
-    rec = RC.Reconstructor(ts, ds, w, batch_size=B, light_elevation_deg=75.0, shape_eta=0.8, pose_eta=0.01, tex_eta=0.8,
+    rec = RC.Reconstructor(ts, ds, wr, wd, batch_size=B, light_elevation_deg=75.0, shape_eta=0.8, pose_eta=0.01, tex_eta=0.8,
                            light_eta=0.4)
     rec.assign(**lat)
-    return rec, ts, ds, w, lat, target
+    return rec, ts, ds, wr, wd, lat, target
 
 
 def test_shape_decoder_matches_oracle():
     from rendernet_amd import reconstruct as RC
     from rendernet_amd import variables as V
-    rec, ts, ds, w, lat, _ = _tiny_setup()
+    rec, ts, ds, wr, wd, lat, _ = _tiny_setup()
     V.set_default_store(rec.store)
     taps = {}
     with torch.no_grad():
-        got = RC.decoder_3d_pretrained(torch.from_numpy(lat["vector"]).cuda(), ds, taps)
+        got = RC.decoder_3d_pretrained(torch.from_numpy(lat["vector"]).cuda(), wd, taps=taps)
     otaps = {}
-    want = OR.decoder_3d_torch(torch.from_numpy(lat["vector"]), {k: torch.from_numpy(v) for k, v in w.items()}, ds.base, ds.chans, otaps)
+    want = OR.decoder_3d_torch(torch.from_numpy(lat["vector"]), wd, otaps)
     for k in otaps:
         err, ref = np.abs(taps[k].cpu().numpy() - otaps[k]).max(), np.abs(otaps[k]).max()
         assert err <= 2e-4 * ref + 1e-6, (k, err, ref)
@@ -165,18 +171,73 @@ def test_shape_decoder_matches_oracle():
     assert want.numpy().std() > 0.01                              # not the flat 0.5 volume
 
 
+def test_pretrained_net_is_the_relu_graph_whatever_alpha_the_folder_holds():
+    """VERDICT r03, item 1.  RenderNet_pretrained (Reconstruct_RenderNet_Face.py:113-302) calls the res blocks with the weight
+    dict: tf.nn.relu, no alpha (tools/layer_util.py:75-88, :107-121).  A RenderNet dict that ALSO carries non-zero res*_alpha
+    tensors renders exactly what the dict without them renders, equals the oracle's ReLU graph on every tap, and differs from the
+    PReLU training graph (rendernet_amd.texture.RenderNetTexture) fed the same tensors with those slopes."""
+    from rendernet_amd import reconstruct as RC
+    from rendernet_amd import variables as V
+    from rendernet_amd.texture import RenderNetTexture
+    rec, ts, ds, wr, wd, lat, _ = _tiny_setup(extra_res_alpha=True)
+    assert any(k.startswith("res2_") and k.endswith("alpha") and wr[k].min() > 0.05 for k in wr)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 1, (2, 32, 32, 32, 5)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    V.set_default_store(rec.store)
+    taps = {}
+    with torch.no_grad():
+        img, nrm = RC.RenderNet_pretrained(xd, wr, prob=1.0, taps=taps)
+    assert not any("alpha" in n and n.split("/")[1].startswith("res") for n in rec.store.vars), "a res-block alpha variable was created"
+    otaps = {}
+    with torch.no_grad():
+        oimg, onrm = OR.rendernet_pretrained_torch(torch.from_numpy(x), wr, otaps)
+    for k in ("enc3", "enc3_skip", "enc4", "enc4_skip", "enc5", "enc5_skip"):
+        err, ref = np.abs(taps[k].cpu().numpy() - otaps[k]).max(), np.abs(otaps[k]).max()
+        assert err <= 2e-4 * ref + 1e-6, (k, err, ref)
+    assert np.abs(img.cpu().numpy() - oimg.numpy()).max() <= 1e-4 and np.abs(nrm.cpu().numpy() - onrm.numpy()).max() <= 1e-4
+    # the same folder without the alpha files: identical bits
+    wr_clean = {k: v for k, v in wr.items() if not (k.split("_")[0] in ("res1", "res2", "res3") and k.endswith("alpha"))}
+    rec2 = RC.Reconstructor(ts, ds, wr_clean, wd, batch_size=2)
+    V.set_default_store(rec2.store)
+    with torch.no_grad():
+        img2, nrm2 = RC.RenderNet_pretrained(xd, wr_clean, prob=1.0)
+    assert torch.equal(img2, img) and torch.equal(nrm2, nrm)
+    # the PReLU training graph with those slopes is a DIFFERENT function (what round 3 computed here)
+    state = RC.state_from_pretrained(wr_clean, wd, ts, ds)
+    for k in list(state):
+        parts = k.split("/")
+        if k.endswith("/alpha") and parts[1].split("_")[0] in ("res1", "res2", "res3"):
+            state[k] = wr["%s_alpha" % parts[1]]
+    st = V.VariableStore("cuda")
+    st.load_state_dict(state)
+    V.set_default_store(st)
+    with torch.no_grad():
+        pimg, _ = RenderNetTexture(xd, prob=1.0, spec=ts)
+    d = float((pimg - img).abs().max())
+    assert d > 1e-3, "PReLU net with non-zero res slopes must differ from the pretrained (ReLU) graph: %g" % d
+    # ... and with zero slopes it is the same function (PReLU(0) = ReLU)
+    state0 = RC.state_from_pretrained(wr_clean, wd, ts, ds)
+    st0 = V.VariableStore("cuda")
+    st0.load_state_dict(state0)
+    V.set_default_store(st0)
+    with torch.no_grad():
+        zimg, znrm = RenderNetTexture(xd, prob=1.0, spec=ts)
+    assert float((zimg - img).abs().max()) <= 1e-5 and float((znrm - nrm).abs().max()) <= 1e-5
+
+
 def test_inverse_rendering_step_matches_oracle():
     """recon_loss [B], the gradients of the four latent groups (shape code through decoder + resampler + net, pose
-    through the resampler's matrix, texture code, light azimuth through the Phong composite), and the SGD update."""
+    through the resampler's matrix, texture code, light azimuth through the Phong composite), and the SGD update.
+    The RenderNet dict carries non-zero res*_alpha tensors; the oracle's ReLU graph never reads them, nor may the HIP path."""
     from rendernet_amd import ops
-    rec, ts, ds, w, lat, target = _tiny_setup()
+    rec, ts, ds, wr, wd, lat, target = _tiny_setup(extra_res_alpha=True)
     taps = {}
     compos, img, nrm, shape = rec.forward(taps)
     loss = rec.loss_and_backward(compos, target).cpu().numpy().copy()
     M = ops.pose_to_affine(torch.from_numpy(lat["param"]).cuda(), ts.size, ts.new_size).cpu().numpy()
-    oloss, ograds, oout = OR.losses_and_grads(lat["vector"], lat["param"], lat["texture"], lat["light"], target, w, M, ts.size,
-                                              ts.new_size, ts.tex_res, (ts.n_res1, ts.n_res2, ts.n_res3), ds.base, ds.chans,
-                                              rec.elevation, (1.0, 1.0, 1.0), 0.0, 1.0, ts.tex_c0)
+    oloss, ograds, oout = OR.losses_and_grads(lat["vector"], lat["param"], lat["texture"], lat["light"], target, wr, wd, M, ts.size,
+                                              ts.new_size, rec.elevation, (1.0, 1.0, 1.0), 0.0, 1.0)
     assert np.abs(shape.detach().cpu().numpy() - oout["shape"]).max() <= 1e-4
     assert np.abs(taps["net_in"].detach().cpu().numpy() - oout["net_in"]).max() <= 1e-4
     assert np.abs(img.detach().cpu().numpy() - oout["img"]).max() <= 1e-3
@@ -201,15 +262,15 @@ def test_inverse_rendering_step_matches_oracle():
 
 def test_latent_descent_reduces_the_loss():
     """Optimising only through the frozen nets, from a perturbed start, towards an image the graph itself rendered."""
-    rec, ts, ds, w, lat, _ = _tiny_setup()
+    rec, ts, ds, wr, wd, lat, _ = _tiny_setup()
     with torch.no_grad():
         target = rec.forward()[0].cpu().numpy()
     rng = np.random.default_rng(12)
     rec.assign(texture=lat["texture"] + 0.5 * rng.standard_normal(lat["texture"].shape).astype(np.float32),
                light=lat["light"] + 0.3)
     rec.etas.update(vector=0.0, param=0.0, texture=20.0, light=5.0)
-    losses = [rec.step(target).cpu().numpy().sum() for _ in range(12)]
-    assert losses[-1] < 0.7 * losses[0], losses
+    losses = [rec.step(target).cpu().numpy().sum() for _ in range(24)]
+    assert losses[-1] < 0.7 * losses[0] and all(b <= a for a, b in zip(losses, losses[1:])), losses
 
 
 def test_full_size_inverse_rendering_step():

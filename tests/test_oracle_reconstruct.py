@@ -107,28 +107,60 @@ def test_resampler_autograd_wrapper_matches_its_numpy_backward():
     assert np.abs(m.grad.numpy() - dm).max() <= 1e-9 * np.abs(dm).max()
 
 
+def _tiny_dicts(seed=77):
+    from rendernet_amd import reconstruct as RC
+    from rendernet_amd.texture import tiny_texture_spec
+    ts, ds = tiny_texture_spec(), RC.tiny_shape_decoder_spec()
+    wr, wd = RC.init_pretrained_weight_dicts(ts, ds, seed=seed, perturb=True)
+    wd["g_conv4_weights"] = wd["g_conv4_weights"] * 30          # the random-init decoder emits sigmoid(~0) = 0.5 everywhere: give it structure
+    return ts, ds, wr, wd
+
+
 def test_shape_decoder_shapes_and_elu():
-    from rendernet_amd.reconstruct import tiny_shape_decoder_spec, init_shape_decoder_weights
-    spec = tiny_shape_decoder_spec()
-    w = init_shape_decoder_weights(spec, seed=5, perturb=True)
-    z = np.random.default_rng(5).standard_normal((2, spec.z_dim)).astype(np.float32)
+    ts, ds, wr, wd = _tiny_dicts(5)
+    z = np.random.default_rng(5).standard_normal((2, ds.z_dim)).astype(np.float32)
     taps = {}
-    out = OR.decoder_3d_torch(torch.from_numpy(z), {k: torch.from_numpy(v) for k, v in w.items()}, spec.base, spec.chans, taps)
+    out = OR.decoder_3d_torch(torch.from_numpy(z), wd, taps)
     assert out.shape == (2, 16, 16, 16, 1) and float(out.min()) > 0 and float(out.max()) < 1
     assert taps["gen1"].shape == (2, 4, 4, 4, 16) and taps["gen1"].min() > -1.0 and (taps["gen1"] < 0).any()   # ELU range
+
+
+def test_pretrained_res_blocks_are_relu_blocks_without_alpha():
+    """tools/layer_util.py:75-88, :107-121: with a weight_dict the res blocks are x + conv(relu(conv(x))) and read four keys per
+    block; an `alpha` entry in the dict is never looked at.  The oracle's pretrained net therefore (a) runs on dicts WITHOUT any
+    res*_alpha key, (b) gives the same output when such keys are added, (c) differs from the training graph's PReLU blocks
+    (oracle/texture_net.py) whenever those slopes are non-zero, and equals it when they are zero."""
+    from rendernet_amd import reconstruct as RC
+    from oracle import texture_net as TN
+    ts, ds, wr, wd = _tiny_dicts()
+    assert not any(k.startswith("res") and k.endswith("alpha") for k in wr)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.uniform(0, 1, (1, 32, 32, 32, 5)).astype(np.float32))
+    with torch.no_grad():
+        img, nrm = OR.rendernet_pretrained_torch(x, wr)
+        extra = dict(wr)
+        for blk, n, c in (("res1", ts.n_res1, ts.c3), ("res2", ts.n_res2, ts.w_res2), ("res3", ts.n_res3, ts.w5)):
+            for i in range(1, n + 1):
+                extra["%s_%d_alpha" % (blk, i)] = rng.uniform(0.1, 0.25, c).astype(np.float32)
+        img2, nrm2 = OR.rendernet_pretrained_torch(x, extra)
+        assert torch.equal(img, img2) and torch.equal(nrm, nrm2)
+        # the training graph on the same tensors: PReLU slopes 0 -> the same function; non-zero -> another one
+        state0 = RC.state_from_pretrained(wr, wd, ts, ds)
+        a0, n0 = TN.rendernet_texture_forward_torch(x, state0, ts.n_res1, ts.n_res2, ts.n_res3)
+        assert float((a0 - img).abs().max()) <= 1e-6 and float((n0 - nrm).abs().max()) <= 1e-6
+        state1 = dict(state0)
+        for k in state1:
+            if k.endswith("/alpha") and k.split("/")[1].split("_")[0] in ("res1", "res2", "res3"):
+                state1[k] = np.full_like(state1[k], 0.2)
+        a1, _ = TN.rendernet_texture_forward_torch(x, state1, ts.n_res1, ts.n_res2, ts.n_res3)
+        assert float((a1 - img).abs().max()) > 1e-4
 
 
 def test_inverse_rendering_gradients_match_finite_differences():
     """losses_and_grads on the tiny graph: d sum(recon_loss) / d light and d / d texture code against central
     differences of the oracle's own float32 forward (loose: float32 noise), and the per-hypothesis structure --
     hypothesis b's latents only move loss b."""
-    from rendernet_amd.reconstruct import tiny_shape_decoder_spec, init_shape_decoder_weights
-    from rendernet_amd.texture import tiny_texture_spec, init_texture_weights
-    ts, ds = tiny_texture_spec(), tiny_shape_decoder_spec()
-    w = dict(init_texture_weights(ts, seed=77, perturb=True))
-    w.update(init_shape_decoder_weights(ds, seed=78, perturb=True))
-    # the random-init decoder emits sigmoid(~0) = 0.5 everywhere; scale its last layer so the volume has structure
-    w["g_conv4/weights"] = w["g_conv4/weights"] * 30
+    ts, ds, wr, wd = _tiny_dicts()
     rng = np.random.default_rng(6)
     B = 2
     lat = dict(vector=rng.standard_normal((B, ds.z_dim)).astype(np.float32) * 2,
@@ -139,9 +171,8 @@ def test_inverse_rendering_gradients_match_finite_differences():
     M = R.inverse_affine(lat["param"], ts.size, ts.new_size)
 
     def run(l):
-        return OR.losses_and_grads(l["vector"], l["param"], l["texture"], l["light"], target, w, M, ts.size, ts.new_size,
-                                   ts.tex_res, (ts.n_res1, ts.n_res2, ts.n_res3), ds.base, ds.chans, 0.26, (1.0, 1.0, 1.0),
-                                   0.0, 1.0, ts.tex_c0)
+        return OR.losses_and_grads(l["vector"], l["param"], l["texture"], l["light"], target, wr, wd, M, ts.size, ts.new_size,
+                                   0.26, (1.0, 1.0, 1.0), 0.0, 1.0)
 
     loss, grads, out = run(lat)
     assert loss.shape == (B,) and out["compos"].shape == (B, 128, 128, 3)
@@ -160,34 +191,50 @@ def test_inverse_rendering_gradients_match_finite_differences():
         assert abs(fd - g) <= 0.08 * max(abs(fd), abs(g)) + 2e-6, (name, idx, fd, g)
 
 
-def test_pretrained_key_map_and_weight_folder_roundtrip(tmp_path):
-    """tools/model_util.py:26-39 file naming + the keys Reconstruct_RenderNet_Face.py reads (:40-326)."""
+def test_pretrained_keys_and_weight_folder_roundtrip(tmp_path):
+    """tools/model_util.py:26-39 file naming + the keys Reconstruct_RenderNet_Face.py reads (:40-299).  The folders hold NO
+    res*_alpha file (the reference's res blocks with a weight dict have no such variable) -- and load."""
     from rendernet_amd import reconstruct as RC
-    from rendernet_amd.texture import tiny_texture_spec, init_texture_weights, texture_variable_shapes
+    from rendernet_amd.texture import tiny_texture_spec, texture_variable_shapes
     ts, ds = tiny_texture_spec(), RC.tiny_shape_decoder_spec()
-    km = RC.pretrained_key_map(ts, ds)
-    names = [n for n, _, _ in texture_variable_shapes(ts)] + [n for n, _, _ in RC.shape_decoder_variable_shapes(ds)]
-    assert sorted(km.values()) == sorted(names) and len(set(km)) == len(names)
-    for key in ("g_zP_g_gc1_weights", "g_conv1_g_conv1_biases", "g_conv4_weights", "e_tex_dc1_g_gc1_weights", "e_tex_dc1_alpha",
-                "e_tex_conv0_conv2d_transpose_weights", "e_tex_conv2_conv3d_biases", "e_conv1_e_conv1_weights", "e_conv3_alpha",
-                "res1_1_con1_3X3_weights", "res2_2_conv2_3x3_biases", "res3_skip_con1_3X3_weights", "e_conv4_e_conv4_weights",
-                "e_conv4_alpha", "e_conv5_e_conv5_weights", "Image_e_conv6_1_e_conv6_1_weights", "Image_e_conv7_1_alpha",
-                "Image_e_conv11_1_e_conv11_1_biases", "Normal_e_conv8_2_e_conv8_2_weights", "Normal_e_conv11_2_e_conv11_2_weights"):
-        assert key in km, key
-    w = dict(init_texture_weights(ts, seed=1))
-    w.update(RC.init_shape_decoder_weights(ds, seed=2))
+    keys = [k for k, _, _ in RC.pretrained_rendernet_shapes(ts)]
+    dkeys = [k for k, _, _ in RC.pretrained_decoder_shapes(ds)]
+    assert len(set(keys)) == len(keys) and not any("res" in k.split("_")[0] and k.endswith("alpha") for k in keys)
+    for key in ("e_tex_dc1_g_gc1_weights", "e_tex_dc1_alpha", "e_tex_conv0_conv2d_transpose_weights", "e_tex_conv2_conv3d_biases",
+                "e_conv1_e_conv1_weights", "e_conv3_alpha", "res1_1_con1_3X3_weights", "res2_2_conv2_3x3_biases",
+                "res3_skip_con1_3X3_weights", "e_conv4_e_conv4_weights", "e_conv4_alpha", "e_conv5_e_conv5_weights",
+                "Image_e_conv6_1_e_conv6_1_weights", "Image_e_conv7_1_alpha", "Image_e_conv11_1_e_conv11_1_biases",
+                "Normal_e_conv8_2_e_conv8_2_weights", "Normal_e_conv11_2_e_conv11_2_weights"):
+        assert key in keys, key
+    for key in ("g_zP_g_gc1_weights", "g_conv1_g_conv1_biases", "g_conv4_weights"):
+        assert key in dkeys, key
+    wr, wd = RC.init_pretrained_weight_dicts(ts, ds, seed=1)
     d1, d2 = tmp_path / "net", tmp_path / "dec"
     os.makedirs(d1); os.makedirs(d2)
-    for key, name in km.items():
-        np.savez(os.path.join(d2 if name.startswith("g_") else d1, key + ".txt.npz"), w[name])
-    state = RC.state_from_pretrained(RC.load_weights(str(d1)), RC.load_weights(str(d2)), ts, ds)
-    assert set(state) == set(w) and all(np.array_equal(state[k], w[k]) for k in w)
+    for k, v in wr.items():
+        np.savez(os.path.join(d1, k + ".txt.npz"), v)
+    for k, v in wd.items():
+        np.savez(os.path.join(d2, k + ".txt.npz"), v)
+    lr, ld = RC.load_weights(str(d1)), RC.load_weights(str(d2))
+    assert set(lr) == set(wr) and set(ld) == set(wd) and all(np.array_equal(lr[k], wr[k]) for k in wr)
+    RC.check_pretrained_weight_dicts(lr, ld, ts, ds)
+    # into the TRAINING graph's names: every variable of it is produced, the res-block slopes as zeros
+    km = RC.pretrained_key_map(ts, ds)
+    assert sorted(km) == sorted(set(wr) | set(wd))
+    state = RC.state_from_pretrained(lr, ld, ts, ds)
+    names = [n for n, _, _ in texture_variable_shapes(ts)] + [n for n, _, _ in RC.shape_decoder_variable_shapes(ds)]
+    assert sorted(state) == sorted(names)
+    for n in names:
+        if n.endswith("/alpha") and n.split("/")[1].split("_")[0] in ("res1", "res2", "res3"):
+            assert not state[n].any()
     os.remove(os.path.join(d1, "e_conv4_alpha.txt.npz"))
-    try:
-        RC.state_from_pretrained(RC.load_weights(str(d1)), RC.load_weights(str(d2)), ts, ds)
-        assert False, "missing tensor must raise"
-    except KeyError as e:
-        assert "e_conv4_alpha" in str(e)
+    for fn in (lambda: RC.state_from_pretrained(RC.load_weights(str(d1)), ld, ts, ds),
+               lambda: RC.check_pretrained_weight_dicts(RC.load_weights(str(d1)), ld, ts, ds)):
+        try:
+            fn()
+            assert False, "missing tensor must raise"
+        except KeyError as e:
+            assert "e_conv4_alpha" in str(e)
 
 
 def test_create_param_center():
