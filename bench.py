@@ -299,6 +299,29 @@ def train_main(args, world, rank, local_rank):
     elapsed = max(by_rank)
     lossv = float(loss.item())
     assert np.isfinite(lossv)
+    # the same steps with the GEMM stage of the wide 2-D convs (forward AND input gradient; the filter gradient stays exact fp32)
+    # on the bf16 pipe by operand splitting: a second trainer from the same initial weights, checked against the same golden
+    alt = None
+    if not args.no_alt:
+        del tr
+        torch.cuda.empty_cache()
+        ops.WINO_GEMM = "split"
+        try:
+            tr2 = Trainer(spec, weights, device="cuda:%d" % local_rank)
+            parity2 = train_parity(tr2, spec, world)
+            for i in range(max(1, args.warmup)):
+                tr2.step(vox, poses, targets, patch_size=p, start_point=starts[i])
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                loss2 = tr2.step(vox, poses, targets, patch_size=p, start_point=starts[args.warmup + i])
+            barrier()
+            el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
+        finally:
+            ops.WINO_GEMM = "f32"
+        alt = {"dtype": "bf16x3-split, fp32 accumulate (forward and input-gradient GEMM stages of the wide 2-D convs; filter gradients exact fp32)",
+               "value": round(B * world * args.steps / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
+               "speedup_vs_value": round(elapsed / el2, 4), "final_loss": float(loss2.item()), "parity": parity2}
     if rank == 0:
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
         fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2
@@ -324,11 +347,13 @@ def train_main(args, world, rank, local_rank):
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
             "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
-            "roofline": roof, "final_loss": lossv, "parity": parity,
+            "roofline": roof, "final_loss": lossv, "parity": parity, **({"alt": alt} if alt is not None else {}),
             **({"cpu_baseline": cpu_baseline_train(weights, p)} if (world == 1 and not args.no_cpu_baseline) else {}),
             **per_rank_fields(by_rank, [B] * world, args.steps)}), flush=True)
         if parity is not None and not parity["ok"]:
             raise SystemExit("PARITY FAILURE (training step): %s" % json.dumps(parity))
+        if alt is not None and not alt["parity"]["ok"]:
+            raise SystemExit("PARITY FAILURE (training step, split GEMM stage): %s" % json.dumps(alt["parity"]))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -509,11 +534,11 @@ def render_main(args, world, rank, local_rank):
     # ---- the primary pass: exact-fp32 MFMA everywhere
     vox, aux, poses, total_frames = shard(args.scaling)
     nloc = vox.shape[0]
-    out, elapsed, by_rank, ev = timed_pass(vox, aux, poses, "f32", args.steps, args.warmup)
+    out, elapsed, by_rank, ev = timed_pass(vox, aux, poses, args.gemm, args.steps, args.warmup)
     frames_by_rank = gather_per_rank(nloc, world, rank)
     # ---- the same steps with the multiply stage of the wide 2-D layers on the bf16 pipe (fp32 accuracy by operand splitting)
     alt = None
-    if not args.no_alt:
+    if not args.no_alt and args.gemm == "f32":
         out_alt, el_alt, by_rank_alt, ev_alt = timed_pass(vox, aux, poses, "split", args.steps, max(1, args.warmup))
         alt = (out_alt, el_alt, by_rank_alt, ev_alt)
     # ---- N > 1: the other scaling regime as well (weak: every rank its own batch; strong: ONE batch split 24 -> 24/N)
@@ -522,7 +547,7 @@ def render_main(args, world, rank, local_rank):
         oscal = "strong" if args.scaling == "weak" else "weak"
         if not (oscal == "strong" and B < world):
             v2, a2, p2, tot2 = shard(oscal)
-            o2, el2, br2, _ = timed_pass(v2, a2, p2, "f32", args.steps, 1)
+            o2, el2, br2, _ = timed_pass(v2, a2, p2, args.gemm, args.steps, 1)
             fr2 = gather_per_rank(v2.shape[0], world, rank)
             other = {"scaling": oscal, "value": round(tot2 * args.steps / el2, 3), "unit": "frames/s",
                      "ms_per_step": round(1e3 * el2 / args.steps, 3), "global_batch": tot2,
@@ -556,7 +581,9 @@ def render_main(args, world, rank, local_rank):
     }
     if other is not None:
         res["other_scaling"] = other
-    roof = gemm_roofline(ev["gemm"], ev["layer"], wtrunk, hw, nloc, mode, "f32")
+    roof = gemm_roofline(ev["gemm"], ev["layer"], wtrunk, hw, nloc, mode, args.gemm)
+    if args.gemm != "f32":
+        res["dtype"] = "f32 (GEMM stage of the wide 2-D convs: bf16x3-split, fp32 accumulate)"
     if roof is not None:
         res["roofline"] = roof
     rs_events = ev["resample"]
@@ -675,6 +702,9 @@ def main():
                     help="render = the headline metric (BASELINE configs[1]); texture = configs[2]; stress = configs[4] "
                          "(128^3 -> 1024^2, batch 8); train = the training step of configs[3] (samples/s)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--gemm", choices=["f32", "split"], default="f32",
+                    help="multiply stage of the wide 2-D convs in the PRIMARY pass: exact-fp32 MFMA (default; the split route is then timed as `alt`) "
+                         "or the bf16x3 split route (profiling: no alt pass)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed pass (split bf16x3 GEMM stage) and its `alt` block")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the pass in the other scaling regime (`other_scaling`)")
     ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")

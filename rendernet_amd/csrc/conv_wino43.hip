@@ -515,7 +515,7 @@ void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int
                 for (int r = 0; r < 4; ++r) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int p_ = 0; p_ < R; ++p_) acc += S::G(i, p_) * (double)g[p_][q][r];
+                    for (int p_ = 0; p_ < R; ++p_) acc = __builtin_fma(S::G(i, p_), (double)g[p_][q][r], acc);      // explicit: the fp32 and the split pack must round alike
                     gg[i][q][r] = acc;
                 }
         float* ub = u + (((size_t)nb * nkg + kg) * 256 + slot) * 4;
@@ -529,7 +529,7 @@ void wino_pack_kernel(const float* __restrict__ w_tf, float* __restrict__ u, int
                 for (int r = 0; r < 4; ++r) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int q = 0; q < R; ++q) acc += gg[i][q][r] * S::G(j, q);
+                    for (int q = 0; q < R; ++q) acc = __builtin_fma(gg[i][q][r], S::G(j, q), acc);
                     o[r] = (float)acc;
                 }
                 st4(ub + (size_t)(i * A + j) * plane, o);

@@ -159,69 +159,89 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// filter transform U = G g G^T (double, as wino_pack_kernel), rounded to fp32 and split: Us [nxi][Cout/256][Cin/16][256][3][16]
+// filter transform U = G g G^T (double, as wino_pack_kernel), rounded to fp32 and split: Us [nxi][Cout/256][Cin/16][256][3][16].
+// Once per weight update -- every step when training, for the forward AND the input-gradient pack of every layer, so its
+// stores matter: workgroup = 64 output channels x one 16-channel K step (thread = (channel, 4 input channels)); what it
+// produces per xi is 64 rows x 96 bytes = 6 KiB CONTIGUOUS, exchanged through LDS four xi at a time and written as 16-byte
+// stores (the straight form -- 8-byte stores at a 96-byte stride -- ran at 1 TB/s: 0.38 ms for the res2 filter).
+constexpr int PK_CO = 64, PK_XB = 4, PK_PITCH = 112;          // LDS row pitch (96 + 16: 16-byte aligned rows, 2-way write conflicts at worst)
+
 template <class S>
 __global__ __launch_bounds__(256)
 void wino_pack_bf3_kernel(const float* __restrict__ w_tf, char* __restrict__ us, int Cin, int Cout, int transposed)
 {
-    constexpr int A = S::TA, R = S::R;
-    const int nkg = Cin / 4, nblocks = Cout / 256, ksteps = Cin / 16;
-    const size_t total = (size_t)nkg * Cout;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(idx & 255);
-        const size_t rest = idx >> 8;
-        const int kg = (int)(rest % nkg), nb = (int)(rest / nkg);
-        const int co = nb * 256 + slot;
-        float g[R][R][4];
+    constexpr int A = S::TA, R = S::R, NXI = A * A;
+    __shared__ __attribute__((aligned(16))) char xch[PK_XB * PK_CO * PK_PITCH];
+    const int ksteps = Cin / 16, nblocks = Cout / 256, cgroups = Cout / PK_CO;
+    const int cg = blockIdx.x % cgroups, s = blockIdx.x / cgroups;          // consecutive workgroups: neighbouring channel groups of one K step
+    const int tid = threadIdx.x, col = tid & 63, kgl = tid >> 6;            // a wave = 64 channels x one group of 4 input channels
+    const int co = cg * PK_CO + col, kg = s * 4 + kgl;
+    float g[R][R][4];
 #pragma unroll
-        for (int p_ = 0; p_ < R; ++p_)
+    for (int p_ = 0; p_ < R; ++p_)
 #pragma unroll
-            for (int q = 0; q < R; ++q)
+        for (int q = 0; q < R; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = kg * 4 + r;
-                    g[p_][q][r] = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
-                                             : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
-                }
-        double gg[A][R][4];                                     // (G g)[i][q]
-#pragma unroll
-        for (int i = 0; i < A; ++i)
-#pragma unroll
-            for (int q = 0; q < R; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int p_ = 0; p_ < R; ++p_) acc += S::G(i, p_) * (double)g[p_][q][r];
-                    gg[i][q][r] = acc;
-                }
-        const int s = kg >> 2, within = (kg & 3) * 4;
-        const unsigned pos = (unsigned)(within >> 3) ^ (unsigned)((slot >> 3) & 1);
-        char* ub = us + (((size_t)nb * ksteps + s) * 256 + slot) * SB_ROW + pos * 16 + (within & 7) * 2;
-        const size_t plane = (size_t)nblocks * ksteps * 256 * SB_ROW;      // bytes per xi
-#pragma unroll
-        for (int i = 0; i < A; ++i)
-#pragma unroll
-            for (int j = 0; j < A; ++j) {
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < R; ++q) acc += gg[i][q][r] * S::G(j, q);
-                    o[r] = (float)acc;
-                }
-                unsigned short p[3][4];
-                split3<4>(o, p);
-                char* dst = ub + (size_t)(i * A + j) * plane;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    uint2 v;
-                    v.x = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
-                    v.y = (unsigned)p[q][2] | ((unsigned)p[q][3] << 16);
-                    *reinterpret_cast<uint2*>(dst + q * 32) = v;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int c = kg * 4 + r;
+                g[p_][q][r] = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
+                                         : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
             }
+    double gg[A][R][4];                                     // (G g)[i][q]
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < R; ++p_) acc = __builtin_fma(S::G(i, p_), (double)g[p_][q][r], acc);      // explicit: the fp32 and the split pack must round alike
+                gg[i][q][r] = acc;
+            }
+    // this thread's 8 bytes of plane 0 inside its row: chunk (4 kgl) / 8 swapped when bit 3 of the row (= channel within the
+    // 256-block) is set, then the second half of the chunk for odd kgl
+    const int slot = co & 255, nb = co >> 8;
+    const unsigned wofs = (unsigned)(col * PK_PITCH) + ((((unsigned)kgl >> 1) ^ (unsigned)((slot >> 3) & 1)) << 4) + (unsigned)(kgl & 1) * 8;
+    const size_t plane = (size_t)nblocks * ksteps * 256 * SB_ROW;                                   // bytes per xi
+    char* ubase = us + (((size_t)nb * ksteps + s) * 256 + (slot - col)) * SB_ROW;                   // row of this group's first channel, xi = 0
+    constexpr int NB = (NXI + PK_XB - 1) / PK_XB;
+#pragma unroll
+    for (int xb = 0; xb < NB; ++xb) {
+#pragma unroll
+        for (int e = 0; e < PK_XB; ++e) {
+            const int xi = xb * PK_XB + e;                      // compile-time after unrolling: the matrix entries fold
+            if (xi >= NXI) continue;
+            const int i = xi / A, j = xi % A;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc = __builtin_fma(gg[i][q][r], S::G(j, q), acc);
+                o[r] = (float)acc;
+            }
+            unsigned short p[3][4];
+            split3<4>(o, p);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                uint2 v;
+                v.x = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
+                v.y = (unsigned)p[q][2] | ((unsigned)p[q][3] << 16);
+                *reinterpret_cast<uint2*>(xch + e * (PK_CO * PK_PITCH) + wofs + q * 32) = v;
+            }
+        }
+        __syncthreads();
+        // 4 xi x 64 rows x 6 chunks of 16 bytes = 1536 chunks: 6 per thread, 384 consecutive lanes per xi
+        for (int qd = tid; qd < PK_XB * PK_CO * 6; qd += 256) {
+            const int e = qd / (PK_CO * 6), rr = qd - e * (PK_CO * 6);
+            const int xi = xb * PK_XB + e;
+            if (xi >= NXI) continue;
+            const int row = rr / 6, ch = rr - row * 6;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xch + e * (PK_CO * PK_PITCH) + row * PK_PITCH + ch * 16);
+            *reinterpret_cast<u32x4*>(ubase + (size_t)xi * plane + rr * 16) = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -286,21 +306,24 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     };
     // one K step of one item -> LDS stage `buf`: VP / 8 (+1) + 3 wave instructions of 1 KiB per wave.  Rows >= T of a V
     // sub-plane lie beyond its buffer window: zeros (their outputs are never stored).
-    auto issue = [&](const Item& it, int s, int buf) {
-        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
+    // piece j of a stage's DMAs of this wave: j < NV the V pieces (the last one only on waves that carry it), then the 3 U pieces
+    constexpr int NV = (VP + 7) / 8, NPIECE = NV + 3;
+    auto issue_piece = [&](const Item& it, int s, int buf, int j) {
         char* sb = smem + buf * STAGE;
-        const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
-#pragma unroll
-        for (int i = 0; i < VP / 8; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * i) * 1024), 16, vo + i * 8192, 0, 0, 0);
-        if constexpr (VP % 8 != 0) {
-            if (vextra)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * (VP / 8)) * 1024), 16, vo + (VP / 8) * 8192, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
+        if (j < NV) {
+            if (VP % 8 != 0 && j == NV - 1 && !vextra) return;
+            const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
+            const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * j) * 1024), 16, vo + j * 8192, 0, 0, 0);
+        } else {
+            const int i = j - NV;
+            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, 0);
+        }
+    };
+    auto issue = [&](const Item& it, int s, int buf) {
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) issue_piece(it, s, buf, j);
     };
     // wait until all but the newest stage's DMAs of this wave (and, behind an item's end, its NSTORE stores) have landed, then the barrier
     auto wait_stage = [&](bool issued, bool after_store) {
@@ -352,24 +375,36 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
         const int bn = buf == SB_NSTAGE - 1 ? 0 : buf + 1;
         const int b2 = bn == SB_NSTAGE - 1 ? 0 : bn + 1;
         const int s2 = s + 2;
-        bool issued = false;
-        if (!(a.probe & 1)) {
-            if (s2 < a.ksteps) { issue(cur, s2, b2); issued = true; }
-            else if (have_next) { issue(nxt, s2 - a.ksteps, b2); issued = true; }
-        }
+        // the DMAs of the stage two steps ahead go out one piece at a time behind the MFMA groups (all eight waves issuing
+        // their six pieces together at the head of the step stalled the matrix pipe for the length of the issue)
+        const bool in_item = s2 < a.ksteps;
+        const bool issued = !(a.probe & 1) && (in_item || have_next);
+        const Item& src = in_item ? cur : nxt;
+        const int ss = in_item ? s2 : s2 - a.ksteps;
+        const bool spread = !(a.probe & 4);
+        if (issued && !spread) issue(src, ss, b2);
+        auto dma = [&](int j) { if (issued && spread && j < NPIECE) issue_piece(src, ss, b2, j); };
         ldv(sb, 1, v1);
         ldu(sb, 1, ub);
         grp(v0, ua, acc[0][0]);
+        dma(0);
         grp(v1, ua, acc[1][0]);
+        dma(1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NT2 == 4) {
             ldu(sb, 2, ua);
             grp(v1, ub, acc[1][1]);
+            dma(2);
             grp(v0, ub, acc[0][1]);
+            dma(3);
             __builtin_amdgcn_sched_barrier(0);
             ldu(sb, 3, ub);
             grp(v0, ua, acc[0][2]);
+            dma(4);
             grp(v1, ua, acc[1][2]);
+            dma(5);
+        } else {
+            dma(2); dma(3); dma(4);
         }
         grp(v1, ub, acc[1][NT2 - 1]);
         wait_stage(issued, after_store);
@@ -443,8 +478,7 @@ size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st)
 {
     if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_pack_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
-    const size_t tot = (size_t)(Cin / 4) * Cout;
-    const unsigned nbw = (unsigned)((tot + 255) / 256 > 65536 ? 65536 : (tot + 255) / 256);
+    const unsigned nbw = (unsigned)((Cout / PK_CO) * (Cin / 16));
     char* u = static_cast<char*>(us);
     if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
