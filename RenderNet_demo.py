@@ -53,6 +53,12 @@ def build_parser():
                         help='.npz of weights keyed by TF variable names, or the reference\'s frozen graph `*.pb` '
                              '(its Const nodes are read without TensorFlow); default: seeded random initialisation')
     parser.add_argument('--batch', type=int, default=24, help='poses rendered per launch with --rotate')
+    parser.add_argument('--gemm', choices=['f32', 'split'], default='f32',
+                        help='multiply stage of the wide 2-D convs: exact-fp32 MFMA, or the bf16x3 split route (fp32 accuracy on '
+                             'the 16x faster bf16 matrix pipe; include/rendernet_hip.h, rn_conv2d_winograd_split_fwd)')
+    parser.add_argument('--no_winograd_check', action='store_true',
+                        help='weights given with --weights are checked once against F(4x4,3x3) where the net would take F(6x6,3x3) '
+                             '(Renderer.validate_winograd, tolerance 2e-4 of max|y| per layer); this flag skips the check')
     parser.add_argument('--gif', type=str, default=None,
                         help='with --rotate: also write the 72 frames as an animated GIF to this path (the reference ships '
                              'such turntables under images/*.gif, README.md)')
@@ -94,13 +100,16 @@ def main(argv=None):
         # the reference's frozen graph (RenderNet_demo.py:23-30, :111 `./model/3d2d_renderer.pb`, made by
         # demo/RenderNet_converter.py): its variables are Const nodes under their TF names
         from rendernet_amd.tools.graphdef import load_frozen_weights
-        weights = load_frozen_weights(args.weights, init_shader_weights(spec, seed=1234))
+        from rendernet_amd.shader import shader_variable_shapes
+        weights = load_frozen_weights(args.weights, {name: tuple(shape) for name, shape, _ in shader_variable_shapes(spec)})
     elif args.weights:
         weights = dict(np.load(args.weights))
     else:
         print("no --weights given: using seeded random weights (the reference ships no trained model)")
         weights = init_shader_weights(spec, seed=1234)
     renderer = Renderer(spec, weights)
+    from rendernet_amd import ops
+    ops.WINO_GEMM = args.gemm
 
     if not os.path.exists(args.render_dir):
         os.makedirs(args.render_dir)
@@ -111,6 +120,12 @@ def main(argv=None):
     with open(voxel_path, 'rb') as f:
         voxel = np.reshape(binvox_rw.read_as_3d_array(f).data.astype(np.float32), (1, 64, 64, 64, 1))
     model_name = os.path.basename(voxel_path).split('.binvox')[0]
+    if args.weights and not args.no_winograd_check:
+        # trained weights have statistics nobody has looked at: one render with the F(6x6,3x3) rounding guard on, on the object
+        # and a pose of this very run; filters whose F(6x6,3x3) output strays from F(4x4,3x3) are demoted for the session
+        demoted = renderer.validate_winograd(voxel, compute_pose_param(args.azimuth, args.elevation, args.radius), tol=2e-4)
+        print("winograd check (tolerance 2e-4 of max|conv|): %s" % ("all F(6x6,3x3) layers kept" if not demoted else
+              "%d layer(s) demoted to F(4x4,3x3): %s" % (len(demoted), demoted)))
 
     if args.rotate:
         # RenderNet_demo.py:130-137: 72 poses, 5 degrees apart, numbered 000..071 -- rendered `--batch` poses per launch

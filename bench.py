@@ -124,6 +124,47 @@ def cpu_baseline(weights, mode="render", frames=4):
     return rec, np.asarray(out)
 
 
+def cpu_baseline_full(weights):
+    """BASELINE.md §3, the whole protocol, once (`--cpu-baseline-full`; minutes of CPU -- not part of the default bench line):
+    the oracle's forward of the headline workload as ONE B=24 pass and the mean of THREE B=1 passes, with
+    torch.set_num_threads(os.cpu_count()) as the plan prescribes AND with the best-of-{8..128} thread count the bench's cut
+    protocol uses; core count and CPU model of the box printed.  Returns the record."""
+    import platform
+    import torch
+    from oracle import rendernet as ON
+    from oracle import resample as OR
+    ncpu = os.cpu_count() or 1
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        model = platform.processor()
+    vox, poses = synthetic_batch(24)
+    run = lambda n: np.asarray(ON.rendernet_forward(OR.net_input(vox[:n], poses[:n], 64, 128), weights))
+    best, _ = pick_threads()
+    legs = {}
+    for name, th in (("all_cores", ncpu), ("best_of_sweep", best)):
+        torch.set_num_threads(th)
+        run(1)                                   # oneDNN primitive caches, first-touch of the weights
+        t0 = time.time()
+        run(24)
+        t24 = time.time() - t0
+        t1s = []
+        for _ in range(3):
+            t0 = time.time()
+            run(1)
+            t1s.append(time.time() - t0)
+        legs[name] = {"threads": th, "b24_pass_s": round(t24, 2), "b24_frames_per_s": round(24.0 / t24, 4),
+                      "b1_passes_s": [round(t, 2) for t in t1s], "b1_mean_frames_per_s": round(3.0 / sum(t1s), 4)}
+    return {"protocol": "BASELINE.md §3: one B=24 forward + the mean of three B=1 forwards of the oracle (NumPy resampler + torch-CPU "
+                        "oneDNN convs, fp32), headline workload (5 fixtures cycled to 24, bench poses, seed-1234 weights)",
+            "kind": "port", "host_cores": ncpu, "cpu_model": model, "legs": legs,
+            "value": legs["all_cores"]["b24_frames_per_s"], "unit": "frames/s", "cores": ncpu}
+
+
 # ----------------------------------------------------------------------------------------------------------------
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
@@ -702,6 +743,9 @@ def main():
                     help="render = the headline metric (BASELINE configs[1]); texture = configs[2]; stress = configs[4] "
                          "(128^3 -> 1024^2, batch 8); train = the training step of configs[3] (samples/s)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="run ONLY the full CPU-baseline protocol of BASELINE.md §3 (one B=24 pass + three B=1 passes of the oracle, all "
+                         "cores and the best-of sweep; minutes) and print its record as one JSON line")
     ap.add_argument("--gemm", choices=["f32", "split"], default="f32",
                     help="multiply stage of the wide 2-D convs in the PRIMARY pass: exact-fp32 MFMA (default; the split route is then timed as `alt`) "
                          "or the bf16x3 split route (profiling: no alt pass)")
@@ -716,6 +760,11 @@ def main():
 
     import torch
 
+    if args.cpu_baseline_full:
+        from rendernet_amd.shader import ShaderSpec, init_shader_weights
+        spec = ShaderSpec().check()
+        print(json.dumps({"cpu_baseline_full": cpu_baseline_full(init_shader_weights(spec, seed=1234, perturb=True))}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU render path)")
     ndev = torch.cuda.device_count()

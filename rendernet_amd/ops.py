@@ -104,9 +104,15 @@ class PackedWeight:
             self._dirty[which] = False
             # the pack runs on the stream that first needed it; a launch on ANOTHER stream (two-stream serving sharing one
             # Renderer) must not read the buffer before that kernel has finished
-            ev = torch.cuda.Event()
-            ev.record()
-            self._packed_on[which] = (torch.cuda.current_stream(), ev)
+            # (inside a hipGraph capture no event is recorded: it would become part of the capture and a later query() from
+            # another stream would fail; Renderer.capture joins the warm-up stream before capturing, and a REpack -- an
+            # optimiser step or a demotion -- is single-stream by contract: the trainers run pack and readers on one stream)
+            if torch.cuda.is_current_stream_capturing():
+                self._packed_on[which] = None
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._packed_on[which] = (torch.cuda.current_stream(), ev)
         else:
             on = self._packed_on.get(which)
             if on is not None:
@@ -194,6 +200,8 @@ class PackedWeight:
         if self._dgrad is None:
             kind = L.RN_PACK_CONVT_S1 if self.kind == L.RN_PACK_CONV else L.RN_PACK_CONV
             self._dgrad = PackedWeight(self.w_tf, kind, self.ndim)
+            if getattr(self, "_wino63_demoted", False):
+                self._dgrad.wino63 = None                     # the forward pack was demoted by the F(6x6,3x3) self-check
         return self._dgrad
 
 
@@ -423,9 +431,10 @@ WINO63_MIN_GAIN = float(os.environ.get("RN_WINO63_MIN_GAIN", "0.08"))
 # positive means, log-normal channel gains, sparse spikes, 21 stacked convs) the scheme stays within 4.0e-5 * max|y| of the
 # float64 conv at Cin = 1024 (F(4x4,3x3): 9.7e-6, direct: 6e-6), i.e. 5x inside the 2e-4 * max|y| bar of the per-tap tests.
 # For weights / activations one does not trust, WINO63_CHECK_TOL (env RN_WINO63_CHECK_TOL, or Renderer.validate_winograd)
-# turns on a self-check: the FIRST F(6x6,3x3) launch of every filter is repeated with F(4x4,3x3) on the same input, and if
-# max|y63 - y43| > tol * max|y43| the filter is demoted to F(4x4,3x3) for good (one extra conv and one host sync per layer,
-# once; off by default; never inside a hipGraph capture).  WINO63_DEMOTED lists the demotions.
+# turns on a self-check: before the FIRST F(6x6,3x3) launch of every filter both schemes run on that input WITHOUT epilogue (raw
+# conv outputs: a residual would inflate the reference), and if max|y63 - y43| > tol * max|y43| the filter -- and its
+# input-gradient pack -- is demoted to F(4x4,3x3) for good (two extra convs and one host sync per layer, once; off by default;
+# never inside a hipGraph capture).  WINO63_DEMOTED lists the demotions.  RenderNet_demo.py --weights runs it at load.
 WINO63_CHECK_TOL = float(os.environ["RN_WINO63_CHECK_TOL"]) if os.environ.get("RN_WINO63_CHECK_TOL") else None
 WINO63_DEMOTED = []
 
@@ -437,20 +446,25 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
     which = _wino_scheme(pw, H, W)
     if (which == "f63" and WINO63_CHECK_TOL is not None and y_t is not None and getattr(pw, "_wino63_verdict", None) is None
             and getattr(pw, "force_scheme", None) is None and not torch.cuda.is_current_stream_capturing()):
-        rc = _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, "f63")
+        # Both schemes on the same input with NO epilogue (no bias, activation or residual): the residual of a res block or a
+        # *_skip conv would inflate max|y| and hide a conv error well above tol * max|conv|.  Then the real launch.
+        raw = (None, None, None)
+        y63, y43 = torch.empty_like(y_t), torch.empty_like(y_t)
+        rc = _wino43_run(x, pw, raw + (L.ptr(y63), None), B, H, W, Cin, Cout, 0, "f63")
         if rc != 0:
             return rc
-        y2 = torch.empty_like(y_t)
-        rc = _wino43_run(x, pw, (e[0], e[1], e[2], L.ptr(y2), None), B, H, W, Cin, Cout, act, "f43")
+        rc = _wino43_run(x, pw, raw + (L.ptr(y43), None), B, H, W, Cin, Cout, 0, "f43")
         if rc != 0:
             return rc
-        diff, ref = float((y_t - y2).abs().max()), float(y2.abs().max())
+        diff, ref = float((y63 - y43).abs().max()), float(y43.abs().max())
         pw._wino63_verdict = diff <= WINO63_CHECK_TOL * ref
-        if pw._wino63_verdict:
-            return 0
-        WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30)})
-        pw.wino63 = None                                      # this filter takes F(4x4,3x3) from now on
-        return _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, "f43")
+        if not pw._wino63_verdict:
+            WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30)})
+            pw.wino63 = None                                  # this filter takes F(4x4,3x3) from now on ...
+            if pw._dgrad is not None:
+                pw._dgrad.wino63 = None                       # ... and so does its input-gradient pack
+            pw._wino63_demoted = True
+            which = "f43"
     return _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which)
 
 

@@ -78,9 +78,14 @@ def _shape(buf):
     return dims
 
 
+MAX_TENSOR_ELEMENTS = 1 << 31          # no tensor of the path comes near this (the largest filter: 9.4 M); a cap on untrusted input
+
+
 def _repeated(val, wt, fmt, size):
     """A repeated scalar field arrives packed (one length-delimited blob) or one element per key."""
     if wt == 2:
+        if len(val) % size != 0:
+            raise GraphDefError("packed field of %d bytes is not a whole number of %d-byte items" % (len(val), size))
         return list(struct.unpack("<%d%s" % (len(val) // size, fmt), bytes(val)))
     return [struct.unpack("<" + fmt, struct.pack("<Q" if size == 8 else "<I", val))[0]]
 
@@ -110,8 +115,17 @@ def _tensor(buf):
     np_dtype = _DTYPES.get(dtype)
     if np_dtype is None:
         return None                                         # strings, resources, ...: not weights
-    count = int(np.prod(shape)) if shape else 1
+    if any(d < 0 for d in shape):
+        raise GraphDefError("tensor with an unknown / negative dimension: %s" % (shape,))
+    count = 1
+    for d in shape:
+        count *= int(d)
+        if count > MAX_TENSOR_ELEMENTS:
+            raise GraphDefError("tensor shape %s exceeds %d elements" % (shape, MAX_TENSOR_ELEMENTS))
     if content is not None:
+        item = np.dtype(np_dtype).itemsize
+        if len(content) % item != 0:
+            raise GraphDefError("tensor_content of %d bytes is not a whole number of %d-byte items" % (len(content), item))
         arr = np.frombuffer(content, dtype=np.dtype(np_dtype).newbyteorder("<")).astype(np_dtype)
     else:
         vals = fvals if np_dtype == np.float32 else dvals if np_dtype == np.float64 else ivals
@@ -165,6 +179,8 @@ def load_frozen_weights(path_or_bytes, expected=None):
     consts = read_graphdef_constants(path_or_bytes, float_only=True)
     if expected is None:
         return consts
+    # `expected`: {name: array} | {name: shape tuple} | iterable of names -- shapes are enough, nobody needs to materialise
+    # 237 M random weights to ask for names (rendernet_amd.shader.shader_variable_shapes gives them)
     names = list(expected)
     missing = [n for n in names if n not in consts]
     if missing:
@@ -173,7 +189,11 @@ def load_frozen_weights(path_or_bytes, expected=None):
     out = {}
     for n in names:
         a = consts[n]
-        want = getattr(expected[n], "shape", None) if hasattr(expected, "keys") else None
+        want = None
+        if hasattr(expected, "keys"):
+            want = getattr(expected[n], "shape", None)
+            if want is None and isinstance(expected[n], (tuple, list)):
+                want = tuple(expected[n])
         if want is not None and tuple(a.shape) != tuple(want):
             raise GraphDefError("variable %s has shape %s in the graph, the net expects %s" % (n, tuple(a.shape), tuple(want)))
         out[n] = np.ascontiguousarray(a, dtype=np.float32)

@@ -222,9 +222,13 @@ class _TrainerBase:
                 raise ValueError(msg)
             warnings.warn(msg)
         for n in self.names:
-            if n in sd and int(np.asarray(sd[n]).size) != self.store.vars[n].numel():
-                raise ValueError("checkpoint variable %s has %d elements, the net's has %d"
-                                 % (n, np.asarray(sd[n]).size, self.store.vars[n].numel()))
+            if n not in sd:
+                continue
+            have_shape, want_shape = tuple(np.shape(sd[n])), tuple(self.store.vars[n].shape)
+            # the SHAPE must match (same element count in another layout -- [kh,kw,Cin,Cout] vs [kh,kw,Cout,Cin] -- would load
+            # silently wrong); the one documented exception: singleton axes may be dropped or added (a [C] bias saved as [1,C])
+            if have_shape != want_shape and tuple(d for d in have_shape if d != 1) != tuple(d for d in want_shape if d != 1):
+                raise ValueError("checkpoint variable %s has shape %s, the net's has %s" % (n, have_shape, want_shape))
         opt_keys = ("__adam_m__", "__adam_v__", "__global_step__")
         have = [k for k in opt_keys if k in sd]
         if have and len(have) != len(opt_keys):
@@ -242,6 +246,12 @@ class _TrainerBase:
                 self.m.copy_(torch.as_tensor(np.asarray(sd["__adam_m__"], np.float32)))
                 self.v.copy_(torch.as_tensor(np.asarray(sd["__adam_v__"], np.float32)))
                 self.global_step = int(sd["__global_step__"])
+                # strict=False with variables missing: their values were NOT restored, so their moments must not be either
+                # (stale m / v for weights they do not belong to) -- those slices restart from zero
+                for n in missing:
+                    o, k = self.layout[n]
+                    self.m[o:o + k].zero_()
+                    self.v[o:o + k].zero_()
             else:
                 self.m.zero_()
                 self.v.zero_()

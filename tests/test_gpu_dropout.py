@@ -138,9 +138,11 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     c = Trainer(spec, {k: v for k, v in a.state_dict().items()}, **kw)     # weights only: the round-1 checkpoint
     run(c, [2])
     cold = dist(c.param, ref.param)
-    assert b.global_step == 3 and resumed <= max(20 * spread, 2e-5), (resumed, spread)     # lr = 1e-3: a step is ~1e-3
-    # the weights-only restart is off for (nearly) EVERY parameter -- lr staircase back at step 0, Adam at t = 1 -- so compare the
-    # MEDIANS: the kink crossings above reach a few per cent of the parameters in some runs (seen: 99th percentile 3.9e-4 against
-    # 1.5e-3 cold), the median of a correct resume stays at the last-bits level
-    cold_med, resumed_med = dist(c.param, ref.param, 0.5), dist(b.param, ref.param, 0.5)
+    assert b.global_step == 3
+    # the weights-only restart is off for (nearly) EVERY parameter -- lr staircase back at step 0, Adam at t = 1 -- so the test
+    # compares MEDIANS: the kink crossings above reach a few per cent of the parameters in some runs (seen: 99th percentile of the
+    # resumed run 3.9e-4 against 1.5e-3 cold, with a run-to-run spread of 2e-5 in the same session), the median of a correct resume
+    # stays at the last-bits level (lr = 1e-3: a step that forgot its moments moves the median parameter by >= 4e-5)
+    cold_med, resumed_med, spread_med = dist(c.param, ref.param, 0.5), dist(b.param, ref.param, 0.5), dist(ref2.param, ref.param, 0.5)
+    assert resumed_med <= max(20 * spread_med, 2e-6), (resumed_med, spread_med, resumed, spread)
     assert cold > resumed and cold_med > 10 * (resumed_med + 1e-7), (cold, resumed, cold_med, resumed_med)

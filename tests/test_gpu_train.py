@@ -403,10 +403,13 @@ def test_load_checkpoint_validates_before_it_mutates(tmp_path):
         return torch.equal(b.param, before[0]) and torch.equal(b.m, before[1]) and b.global_step == before[2]
 
     some = next(iter(w))
+    wide = next(k for k in w if k.endswith("weights") and w[k].ndim == 5 and w[k].shape[-1] != w[k].shape[-2] and w[k].shape[-2] > 1)
     for bad, what in (({k: v for k, v in good.items() if k != some}, "lacks"),
                       ({**good, "__adam_m__": good["__adam_m__"][:-4]}, "flat buffer"),
                       ({k: v for k, v in good.items() if k != "__adam_v__"}, "only part"),
-                      ({**good, some: np.zeros(3, np.float32)}, "elements")):
+                      ({**good, some: np.zeros(3, np.float32)}, "shape"),
+                      # the same element count in another layout ([k,k,k,Cin,Cout] read as [k,k,k,Cout,Cin]) must not load
+                      ({**good, wide: np.ascontiguousarray(np.swapaxes(good[wide], -1, -2))}, "shape")):
         with pytest.raises(ValueError, match=what):
             b.load_checkpoint(bad)
         assert untouched(), what
@@ -415,3 +418,8 @@ def test_load_checkpoint_validates_before_it_mutates(tmp_path):
     assert b.load_checkpoint(a.state_dict()) == 0 and b.global_step == 0 and float(b.m.abs().max()) == 0.0   # weights only
     with pytest.warns(UserWarning):
         b.load_checkpoint({k: v for k, v in good.items() if k != some}, strict=False)
+    o, n = b.layout[some]                              # the variable that was NOT restored gets no stale moments either
+    assert float(b.m[o:o + n].abs().max()) == 0.0 and float(b.v[o:o + n].abs().max()) == 0.0 and float(b.m.abs().max()) > 0.0
+    # a [C] tensor saved with a singleton axis loads (the documented exception)
+    bias = next(k for k in good if k.endswith("biases"))
+    assert b.load_checkpoint({**good, bias: good[bias][None]}) == 4

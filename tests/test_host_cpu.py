@@ -413,6 +413,26 @@ def test_frozen_graph_reader_decodes_const_nodes_without_tensorflow(tmp_path):
         load_frozen_weights(graph, {"encoder/res2_1/alpha": np.zeros(16, np.float32)})
     with pytest.raises(GraphDefError):
         read_graphdef_constants(graph[:-3] + b"\xff\xff\xff")                                       # truncated / garbage tail
+    # expected shapes without materialised weights; malformed tensors raise GraphDefError, never struct.error / ValueError / MemoryError
+    got = load_frozen_weights(graph, {"encoder/res2_1/alpha": (8,)})
+    assert np.array_equal(got["encoder/res2_1/alpha"], al)
+    with pytest.raises(GraphDefError, match="shape"):
+        load_frozen_weights(graph, {"encoder/res2_1/alpha": (16,)})
+
+    def tensor_node(name, tensor_bytes):
+        attr = _pb_field(1, b"value") + _pb_field(2, _pb_field(8, tensor_bytes))
+        return _pb_field(1, _pb_field(1, name) + _pb_field(2, b"Const") + _pb_field(5, attr))
+
+    shape2 = _pb_field(2, _pb_field(2, _pb_field(1, 2, 0)))                                             # TensorShapeProto{dim{size: 2}}
+    bad = {
+        "odd tensor_content": _pb_field(1, 1, 0) + shape2 + _pb_field(4, b"\x00" * 7),
+        "odd packed float_val": _pb_field(1, 1, 0) + shape2 + _pb_field(5, b"\x00" * 6),
+        "negative dim": _pb_field(1, 1, 0) + _pb_field(2, _pb_field(2, _pb_field(1, (1 << 64) - 1, 0))) + _pb_field(5, b"\x00" * 4),
+        "huge splat": _pb_field(1, 1, 0) + _pb_field(2, b"".join(_pb_field(2, _pb_field(1, 1 << 20, 0)) for _ in range(3))) + _pb_field(5, b"\x00" * 4),
+    }
+    for what, t in bad.items():
+        with pytest.raises(GraphDefError):
+            read_graphdef_constants(tensor_node(b"encoder/bad", t))
 
 
 def test_bench_golden_parity_indexing_and_per_rank_fields():
