@@ -270,6 +270,20 @@ int rn_winograd_split_gemm(int scheme, const void* Vs, const void* w_split, floa
 int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
                                  const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
                                  int Cin, int Cout, int transposed, int act, void* stream);
+/* The 3x3x3, stride-1, 32 -> 32 channel convs of the 3-D encoder (res_block_3d, res1_skip: tools/layer_util.py:60-73 ->
+ * tf.nn.conv3d :253; RenderNet_Shader.py:51-64) on the bf16 matrix pipe at fp32 accuracy: Winograd F(2x2,3x3) over (H, W),
+ * direct over depth like rn_conv3d_wino_fwd, every product taken as six bf16 piece products with fp32 accumulation (see the
+ * split entries above), fused in one launch (filter fragments register-resident, transforms in registers, 16-byte pixel
+ * epilogue).  x, y [B,H,W,D,32]; w_split from rn_conv3d_winograd_split_pack (rn_conv3d_winograd_split_packed_bytes bytes;
+ * w_tf = the TF filter [3,3,3,32,32]; transposed = 1: the input-gradient form -- taps flipped, channel roles swapped -- of
+ * the same tensor); epilogue arguments as rn_conv3d_fwd_train.  Measured (MI355X, B = 24, 64x64x32 layer): 0.86 ms against
+ * rn_conv3d_wino_fwd's 0.83 ms, error 2.4e-7 .. 3.8e-7 of max|y| against 3.2e-7 .. 4.9e-7 -- as accurate, not yet faster,
+ * so the Python surface uses it only on request (RN_CONV3D_SPLIT=1; DESIGN.md section 4 has the analysis). */
+int rn_conv3d_winograd_split_supported(int Cin, int Cout);
+size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout);
+int rn_conv3d_winograd_split_pack(const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream);
+int rn_conv3d_winograd_split_fwd(const float* x, const void* w_split, const float* bias, const float* alpha, const float* residual,
+                                 float* y, float* preact, int B, int H, int W, int D, int Cin, int Cout, int act, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

@@ -499,6 +499,26 @@ extern "C" int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const vo
                                    (hipStream_t)stream);
 }
 
+// ---- the 3x3x3 32 -> 32 convs of the 3-D encoder on the bf16 matrix pipe at fp32 accuracy (conv3d_wino_bf3.hip)
+extern "C" int rn_conv3d_winograd_split_supported(int Cin, int Cout) { return rn_conv3d_wino_bf3_supported(Cin, Cout) ? 1 : 0; }
+extern "C" size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout)
+{
+    return (Cin == 32 && Cout == 32) ? rn_conv3d_wino_bf3_packed_bytes() : 0;
+}
+extern "C" int rn_conv3d_winograd_split_pack(const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream)
+{
+    if (!w_tf || !w_split) return rn_set_error(RN_E_INVALID, "rn_conv3d_winograd_split_pack: null pointer");
+    if (Cin != 32 || Cout != 32) return rn_set_error(RN_E_UNSUPPORTED, "rn_conv3d_winograd_split_pack: Cin=%d Cout=%d (32 -> 32 only)", Cin, Cout);
+    return rn_launch_conv3d_wino_pack_bf3(w_tf, w_split, transposed ? 1 : 0, (hipStream_t)stream);
+}
+extern "C" int rn_conv3d_winograd_split_fwd(const float* x, const void* w_split, const float* bias, const float* alpha, const float* residual,
+                                            float* y, float* preact, int B, int H, int W, int D, int Cin, int Cout, int act, void* stream)
+{
+    if (!x || !w_split || !y) return rn_set_error(RN_E_INVALID, "rn_conv3d_winograd_split_fwd: null pointer");
+    if (!rn_conv3d_wino_bf3_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "rn_conv3d_winograd_split_fwd: Cin=%d Cout=%d", Cin, Cout);
+    return rn_launch_conv3d_wino_bf3(x, w_split, bias, alpha, residual, y, preact, B, H, W, D, act, (hipStream_t)stream);
+}
+
 extern "C" int rn_winograd_output_input_supported(int scheme, int H, int W, int C, int act)
 {
     static const bool off = getenv("RN_NO_WINO_OUTIN") != nullptr;

@@ -51,7 +51,8 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None}
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None,
+                     "wino3ds": None}
         self._dirty = {k: True for k in self._buf}
         self._packed_on = {}              # form -> (stream, event recorded behind its last pack kernel)
         # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
@@ -84,7 +85,15 @@ class PackedWeight:
     def _packed(self, which, kind):
         if self._dirty[which]:
             lib = L.lib()
-            if which.endswith("s"):
+            if which == "wino3ds":
+                # the bf16x3 split form of the fused 3x3x3 32 -> 32 kernel (csrc/conv3d_wino_bf3.hip), in MFMA fragment order
+                if self._buf[which] is None:
+                    self._buf[which] = torch.empty(lib.rn_conv3d_winograd_split_packed_bytes(self.cin, self.cout), dtype=torch.uint8,
+                                                   device=self.w_tf.device)
+                L.check(lib.rn_conv3d_winograd_split_pack(L.ptr(self.w_tf), ctypes.c_void_p(self._buf[which].data_ptr()), self.cin, self.cout,
+                                                          1 if self.kind == L.RN_PACK_CONVT_S1 else 0, L.stream_ptr()),
+                        "rn_conv3d_winograd_split_pack")
+            elif which.endswith("s"):
                 # the bf16x3 split form of the three-launch path (csrc/conv_wino_bf3.hip): `kind` is the scheme here
                 if self._buf[which] is None:
                     n = lib.rn_winograd_split_packed_bytes(kind, self.cin, self.cout)
@@ -172,6 +181,14 @@ class PackedWeight:
         if self._wino43_kind is None:
             return None
         return self._packed("wino43s", L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43)
+
+    def split3d(self):
+        """The bf16x3 split form of a 3x3x3 32 -> 32 filter for rn_conv3d_winograd_split_fwd (uint8 buffer), or None."""
+        if self.ndim != 3 or self.kdims != [3, 3, 3] or self._wino_kind is None:
+            return None
+        if not L.lib().rn_conv3d_winograd_split_supported(self.cin, self.cout):
+            return None
+        return self._packed("wino3ds", 0)
 
     @property
     def wino4(self):
@@ -472,6 +489,10 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
 # the 16x faster bf16 pipe with every fp32 operand as three bf16 pieces and six piece products, fp32 accumulation
 # (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
 WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
+# The fused 3x3x3 32 -> 32 kernel has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip).  It is as accurate as the fp32 kernel
+# (2.4e-7 .. 3.8e-7 of max|y| against 3.2e-7 .. 4.9e-7) but NOT faster yet (0.86 ms against 0.83 ms on the B = 24 64^3 layer:
+# DESIGN.md section 4), so it is opt-in and independent of WINO_GEMM.  env RN_CONV3D_SPLIT=1, or set ops.CONV3D_SPLIT.
+CONV3D_SPLIT = os.environ.get("RN_CONV3D_SPLIT", "0") not in ("", "0")
 
 
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
@@ -536,6 +557,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     unit = all(int(v) == 1 for v in stride)
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
+        if unit and CONV3D_SPLIT and pw.split3d() is not None:
+            return lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(pw.split3d().data_ptr()), *e, B, H, W, D, Cin, pw.cout, act, st)
         if unit and pw.wino is not None:
             return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
         return lib.rn_conv3d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
@@ -648,7 +671,10 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
-            if mode == "conv3d" and unit and dp.wino is not None:
+            if mode == "conv3d" and unit and CONV3D_SPLIT and dp.split3d() is not None:
+                rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
+                                                      B, H, W, D, pw.cout, Cin, 0, st)
+            elif mode == "conv3d" and unit and dp.wino is not None:
                 rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
                                             B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d":

@@ -215,3 +215,126 @@ def test_bench_frames_match_golden_split(fixtures_vox):
             lg = np.log(crop.astype(np.float64) / (1 - crop.astype(np.float64)))
             want = g["logits_%d" % k][c]
             assert np.abs(lg - want).max() <= 5e-4 * np.abs(want).max() + 1e-5, (k, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The fused 3x3x3 32 -> 32 kernel in bf16x3 (csrc/conv3d_wino_bf3.hip; opt-in: ops.CONV3D_SPLIT / RN_CONV3D_SPLIT=1).  The layers:
+# res_block_3d's two slim.conv3d [3,3,3] 32 -> 32 (tools/layer_util.py:60-75, RenderNet_Shader.py:61-68).
+C3_CASES = [
+    (1, 4, 32, 2),       # one item, D = 2: both slices have a padded neighbour
+    (1, 8, 32, 3),       # one full three-step turn of the accumulator ring
+    (2, 16, 64, 5),      # two column blocks, D % 3 == 2
+    (3, 10, 20, 4),      # ragged rows of tiles in W, D % 3 == 1
+    (1, 5, 7, 1),        # a single depth slice, odd H, W < 32
+    (1, 64, 64, 32),     # the res1 layer of the benched net
+    (2, 3, 70, 7),       # three column blocks, the last one 6 columns wide
+]
+
+
+def test_conv3d_split_pack_is_the_fp32_filter_transform_in_three_pieces():
+    """rn_conv3d_winograd_split_pack: [i][j][depth tap][piece][channel tile][lane = n % 16 + 16 (c / 8)][c % 8] holds
+    U = G g G^T over (k1, k2) of each depth tap, the three bf16 pieces summing EXACTLY to the fp32 value."""
+    from rendernet_amd import _lib as L, ops
+    rng = np.random.default_rng(5)
+    w = _xavier(rng, (3, 3, 3, 32, 32))
+    pw = ops.pack_conv(_dev(w))
+    us = pw.split3d()
+    assert us is not None and us.numel() == L.lib().rn_conv3d_winograd_split_packed_bytes(32, 32)
+    torch.cuda.synchronize()
+    u16 = us.cpu().numpy().view(np.uint16).reshape(4, 4, 3, 3, 2, 4, 16, 8)           # [i][j][dz][piece][nt][c/8][n%16][c%8]
+    p = _bf16_to_f64(u16)
+    got = (p[:, :, :, 0] + p[:, :, :, 1] + p[:, :, :, 2])                               # [i][j][dz][nt][c/8][n%16][c%8]
+    got = got.transpose(0, 1, 2, 4, 6, 3, 5).reshape(4, 4, 3, 32, 32)                   # [i][j][dz][c][n]
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    want = np.einsum("ip,jq,pqdcn->ijdcn", G, G, w.astype(np.float64)).astype(np.float32)
+    assert np.abs(got - want).max() <= 2.0 ** -22 * np.abs(want).max()
+    assert np.all(got == got.astype(np.float32))                                         # an fp32 value, exactly
+    assert np.all(np.abs(got - p[:, :, :, 0].transpose(0, 1, 2, 4, 6, 3, 5).reshape(got.shape)) <= 2.0 ** -8 * np.abs(got) + 1e-45)
+
+
+@pytest.mark.parametrize("case", C3_CASES)
+def test_conv3d_split(case, monkeypatch):
+    """Forward with every epilogue, against the oracle conv (oracle/layers.py) at the bar of the fp32 kernel, and the input
+    gradient (the flipped, channel-swapped filter through the same kernel) against the oracle's transposed conv."""
+    from rendernet_amd import _lib as L, ops
+    monkeypatch.setattr(ops, "CONV3D_SPLIT", True)
+    B, H, W, D = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((B, H, W, D, 32)).astype(np.float32)
+    w = _xavier(rng, (3, 3, 3, 32, 32))
+    b = (0.1 * rng.standard_normal(32)).astype(np.float32)
+    alpha = rng.uniform(0, 0.25, 32).astype(np.float32)
+    pw = ops.pack_conv(_dev(w))
+    assert pw.split3d() is not None
+    y0 = OL.conv3d(x, w, b, (1, 1, 1))
+    _close(ops.conv3d(_dev(x), pw, _dev(b)), y0, "split 3-D conv", rtol=2e-6)
+    _close(ops.conv3d(_dev(x), pw, None), OL.conv3d(x, w, None, (1, 1, 1)), "split 3-D conv, no bias", rtol=2e-6)
+    res = rng.standard_normal(y0.shape).astype(np.float32)
+    _close(ops.conv3d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res)), OL.prelu(y0, alpha) + torch.from_numpy(res), "split 3-D conv + PReLU + residual",
+           rtol=2e-6)
+    # the pre-activation tap of the training forward
+    xd, bd, ad = _dev(x), _dev(b), _dev(alpha)
+    y, z = torch.empty_like(xd), torch.empty_like(xd)
+    L.check(L.lib().rn_conv3d_winograd_split_fwd(L.ptr(xd), ctypes.c_void_p(pw.split3d().data_ptr()), L.ptr(bd), L.ptr(ad), None, L.ptr(y), L.ptr(z),
+                                                 B, H, W, D, 32, 32, L.RN_ACT_PRELU, L.stream_ptr()), "rn_conv3d_winograd_split_fwd")
+    _close(z, y0, "split 3-D pre-activation", rtol=2e-6)
+    _close(y, OL.prelu(y0, alpha), "split 3-D PReLU", rtol=2e-6)
+    # input gradient
+    dp = pw.dgrad_pack(True)
+    assert dp.split3d() is not None
+    dz = _dev(rng.standard_normal((B, H, W, D, 32)).astype(np.float32))
+    dx = torch.empty_like(dz)
+    L.check(L.lib().rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
+                                                 B, H, W, D, 32, 32, 0, L.stream_ptr()), "rn_conv3d_winograd_split_fwd (dgrad)")
+    _close(dx, OL.conv3d_transpose(dz.cpu().numpy(), w, None, (1, 1, 1)), "split 3-D dgrad", rtol=2e-6)
+
+
+class _TrainStub:
+    """What ops._Conv needs of a training context (rendernet_amd/train.py: Trainer): an autograd anchor, gradient views, `ready`."""
+    frozen = False
+
+    def __init__(self, *params):
+        self.anchor = torch.zeros(1, device="cuda", requires_grad=True)
+        self.g = {id(p): torch.zeros_like(p) for p in params}
+
+    def grad(self, t):
+        return self.g.get(id(t))
+
+    def ready(self, *ts):
+        pass
+
+
+def test_conv3d_split_through_autograd_matches_the_fp32_kernel(monkeypatch):
+    """ops.conv3d under autograd (forward with the saved pre-activation, input gradient through the split kernel, filter gradient
+    through the shared wgrad kernel) with the opt-in on, against the same layer with it off."""
+    from rendernet_amd import ops
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 12, 40, 6, 32)).astype(np.float32)
+    w = _xavier(rng, (3, 3, 3, 32, 32))
+    al = rng.uniform(0, 0.25, 32).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    out = {}
+    for on in (False, True):
+        monkeypatch.setattr(ops, "CONV3D_SPLIT", on)
+        xd, wd, ad, bd = _dev(x).requires_grad_(True), _dev(w), _dev(al), torch.zeros(32, device="cuda")
+        tc = _TrainStub(wd, ad, bd)
+        monkeypatch.setattr(ops, "TRAIN", tc)
+        y = ops.conv3d(xd, ops.pack_conv(wd), bd, ad)
+        y.backward(_dev(g))
+        torch.cuda.synchronize()
+        out[on] = (y.detach(), xd.grad, tc.grad(wd), tc.grad(ad))
+    monkeypatch.setattr(ops, "TRAIN", None)
+    for a_, b_, what in zip(out[False], out[True], ("y", "dx", "dw", "dalpha")):
+        assert float(a_.abs().max()) > 0, what
+        assert float((a_ - b_).abs().max()) <= 3e-6 * float(a_.abs().max()), what
+
+
+def test_conv3d_split_is_refused_for_other_widths():
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    assert lib.rn_conv3d_winograd_split_supported(32, 32) == 1
+    assert lib.rn_conv3d_winograd_split_supported(16, 16) == 0 and lib.rn_conv3d_winograd_split_supported(32, 64) == 0
+    x = torch.zeros((1, 4, 4, 4, 16), device="cuda")
+    us = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(us.data_ptr()), None, None, None, L.ptr(x), None, 1, 4, 4, 4, 16, 16, 0, L.stream_ptr())
+    assert rc != 0
