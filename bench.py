@@ -298,6 +298,8 @@ def train_main(args, world, rank, local_rank):
     from rendernet_amd.train import Trainer
     spec = ShaderSpec().check()
     weights = init_shader_weights(spec, seed=1234, perturb=True)
+    from rendernet_amd import ops
+    ops.WINO_GEMM = args.gemm                      # --gemm split: the whole run in split mode (profiling); no alt pass then
     tr = Trainer(spec, weights, device="cuda:%d" % local_rank)
     B, p = args.batch, args.patch
     vox_np, poses_np = synthetic_batch(B)
@@ -343,7 +345,7 @@ def train_main(args, world, rank, local_rank):
     # the same steps with the GEMM stage of the wide 2-D convs (forward AND input gradient; the filter gradient stays exact fp32)
     # on the bf16 pipe by operand splitting: a second trainer from the same initial weights, checked against the same golden
     alt = None
-    if not args.no_alt:
+    if not args.no_alt and args.gemm == "f32":
         del tr
         torch.cuda.empty_cache()
         ops.WINO_GEMM = "split"
@@ -373,17 +375,22 @@ def train_main(args, world, rank, local_rank):
             T, which = gemm_events[0][1][0], gemm_events[0][1][3]
             nxi, fname = WINO_SCHEMES[which]
             fl = 2.0 * nxi * T * spec.w_res2 * spec.w_res2
-            roof = {"kernel": "wino43_gemm_kernel (GEMM stage of Winograd %s) on the res2 3x3 %d->%d conv, forward and input "
-                              "gradient, T = %d tiles" % (fname, spec.w_res2, spec.w_res2, T),
-                    "bound": "mfma", "achieved": round(fl / (kern_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            split = args.gemm == "split"
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
+            roof = {"kernel": "%s (GEMM stage of Winograd %s) on the res2 3x3 %d->%d conv, forward and input "
+                              "gradient, T = %d tiles" % ("wino_gemm_bf3_kernel" if split else "wino43_gemm_kernel", fname, spec.w_res2,
+                                                          spec.w_res2, T),
+                    "bound": "mfma", "achieved": round(fl / (kern_ms * 1e-3) / 1e12, 2), "peak": round(peak, 2),
+                    "unit": "TFLOP/s", "frac": round(fl / (kern_ms * 1e-3) / 1e12 / peak, 4),
+                    **({"peak_name": "dense bf16 MFMA peak / 6 (six bf16 piece products per fp32 product)"} if split else {}),
                     "avg_launch_ms": round(kern_ms, 4), "launches_timed": len(gemm_events), "flop_per_launch": fl,
                     "flop_basis": "executed MFMA FLOPs = 2*%d*T*Cin*Cout" % nxi, "traffic": None}
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": args.rccl_ranks,
+            "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "bf16x3-split GEMM stages, fp32 accumulate; everything else f32",
+            "data": "synthetic", "rccl_ranks": args.rccl_ranks,
             "config": {"workload": "Phong shader training step (resampler+crop, forward, BCE, dgrad+wgrad, bucketed "
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},

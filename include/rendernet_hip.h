@@ -276,9 +276,9 @@ int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split
  * split entries above), fused in one launch (filter fragments register-resident, transforms in registers, 16-byte pixel
  * epilogue).  x, y [B,H,W,D,32]; w_split from rn_conv3d_winograd_split_pack (rn_conv3d_winograd_split_packed_bytes bytes;
  * w_tf = the TF filter [3,3,3,32,32]; transposed = 1: the input-gradient form -- taps flipped, channel roles swapped -- of
- * the same tensor); epilogue arguments as rn_conv3d_fwd_train.  Measured (MI355X, B = 24, 64x64x32 layer): 0.86 ms against
- * rn_conv3d_wino_fwd's 0.83 ms, error 2.4e-7 .. 3.8e-7 of max|y| against 3.2e-7 .. 4.9e-7 -- as accurate, not yet faster,
- * so the Python surface uses it only on request (RN_CONV3D_SPLIT=1; DESIGN.md section 4 has the analysis). */
+ * the same tensor); epilogue arguments as rn_conv3d_fwd_train.  Measured (MI355X, B = 24, 64x64x32 layer): 0.50 ms against
+ * rn_conv3d_wino_fwd's 0.82 ms, error 2.4e-7 .. 3.8e-7 of max|y| against 3.2e-7 .. 4.9e-7.  The Python surface uses it
+ * whenever the split multiply stage is selected (RN_WINO_GEMM=split; RN_CONV3D_SPLIT=0 | 1 overrides). */
 int rn_conv3d_winograd_split_supported(int Cin, int Cout);
 size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout);
 int rn_conv3d_winograd_split_pack(const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream);

@@ -489,10 +489,14 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
 # the 16x faster bf16 pipe with every fp32 operand as three bf16 pieces and six piece products, fp32 accumulation
 # (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
 WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
-# The fused 3x3x3 32 -> 32 kernel has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip).  It is as accurate as the fp32 kernel
-# (2.4e-7 .. 3.8e-7 of max|y| against 3.2e-7 .. 4.9e-7) but NOT faster yet (0.86 ms against 0.83 ms on the B = 24 64^3 layer:
-# DESIGN.md section 4), so it is opt-in and independent of WINO_GEMM.  env RN_CONV3D_SPLIT=1, or set ops.CONV3D_SPLIT.
-CONV3D_SPLIT = os.environ.get("RN_CONV3D_SPLIT", "0") not in ("", "0")
+# The fused 3x3x3 32 -> 32 kernel of the 3-D encoder has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip: 0.50 ms against 0.82 ms on
+# the B = 24 64x64x32 layer, error 2.4e-7 .. 3.8e-7 of max|y| against the fp32 kernel's 3.2e-7 .. 4.9e-7).  None: it follows
+# WINO_GEMM ("split" turns both on); True / False (env RN_CONV3D_SPLIT=1 / 0) force it independently.
+CONV3D_SPLIT = {"": None, "0": False}.get(os.environ.get("RN_CONV3D_SPLIT", ""), True)
+
+
+def _conv3d_split():
+    return WINO_GEMM == "split" if CONV3D_SPLIT is None else bool(CONV3D_SPLIT)
 
 
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
@@ -557,7 +561,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     unit = all(int(v) == 1 for v in stride)
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
-        if unit and CONV3D_SPLIT and pw.split3d() is not None:
+        if unit and _conv3d_split() and pw.split3d() is not None:
             return lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(pw.split3d().data_ptr()), *e, B, H, W, D, Cin, pw.cout, act, st)
         if unit and pw.wino is not None:
             return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
@@ -671,7 +675,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
-            if mode == "conv3d" and unit and CONV3D_SPLIT and dp.split3d() is not None:
+            if mode == "conv3d" and unit and _conv3d_split() and dp.split3d() is not None:
                 rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
                                                       B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d" and unit and dp.wino is not None:

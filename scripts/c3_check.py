@@ -38,7 +38,7 @@ def accuracy(B, H, W, D, seed=0):
             y = ops.conv3d(xd, pw, bd)
             yp = ops.conv3d(xd, pw, bd, ad, rd)
         out[mode] = (float((y.cpu().double() - want).abs().max()) / ymax, float((yp.cpu().double() - wantp).abs().max()) / ymax, y)
-    ops.CONV3D_SPLIT = False
+    ops.CONV3D_SPLIT = None
     print("B=%d %dx%dx%d: f32 %.2e / %.2e   split %.2e / %.2e   |f32-split| %.2e  (x max|y| = %.3g)"
           % (B, H, W, D, out["f32"][0], out["f32"][1], out["split"][0], out["split"][1],
              float((out["f32"][2] - out["split"][2]).abs().max()) / ymax, ymax), flush=True)
@@ -67,7 +67,7 @@ def timing(B, iters):
                 best = min(best, e0.elapsed_time(e1))
         fl = 2.0 * B * 64 * 64 * 32 * 32 * 32 * 12          # F(2x2,3x3) over (H,W) x 3 depth taps: 12 products per output
         print("B=%d res1 layer, %-5s %.3f ms  (%.1f TFLOP/s fp32-equivalent executed)" % (B, mode, best, fl / best / 1e9), flush=True)
-    ops.CONV3D_SPLIT = False
+    ops.CONV3D_SPLIT = None
 
 
 if __name__ == "__main__":

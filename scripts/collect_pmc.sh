@@ -2,6 +2,7 @@
 # Regenerate the counter evidence of the three roofline kernels on the CURRENT build (run on the GPU box):
 #   * the dominant conv  -- the three launches of the Winograd F(6x6,3x3) path on the res2 shape (scripts/wino_bench.py
 #     --shapes 64x1024 --only f63) and of F(4x4,3x3) on the same shape (--only f43; RN_NO_WINOGRAD63=1 runs the net on it)
+#   * the same shape with the split (bf16x3) input transform and GEMM stage (scripts/bf3_check.py --shapes 0)
 #   * the 3-D encoder layer (scripts/layer_bench.py --only res1): the direct depth-run kernel (RN_NO_WINOGRAD3D=1) and
 #     the Winograd kernel on the same layer
 #   * the resampler's three launches (scripts/layer_bench.py --only resample)
@@ -29,12 +30,13 @@ for tag in sq fetch write tcc; do
     esac
     run wino63 $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --only f63
     run wino43 $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --only f43
+    run bf3 $tag $C -- python "$R/scripts/bf3_check.py" --no-accuracy --iters 3 --shapes 0          # res2 shape, F(6x6,3x3): fp32 stages, then the split ones
     RN_NO_WINOGRAD3D=1 run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
     run res1w $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
     run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done
-for name in wino63 wino43 res1 res1w resample; do
-    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
+for name in wino63 wino43 bf3 res1 res1w resample; do
+    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = bf3 ] && flt=bf3; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
     : > "$OUT/$name.txt"
     for tag in sq fetch write tcc; do
         f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)
@@ -42,4 +44,4 @@ for name in wino63 wino43 res1 res1w resample; do
     done
 done
 python "$R/scripts/pmc_to_traffic.py" "$OUT" "$OUT/traffic.json"
-echo "wrote $OUT/{wino63,wino43,res1,res1w,resample}.txt and $OUT/traffic.json"
+echo "wrote $OUT/{wino63,wino43,bf3,res1,res1w,resample}.txt and $OUT/traffic.json"

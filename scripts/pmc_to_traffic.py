@@ -20,6 +20,9 @@ KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s),
     "wino63_gemm_res2": ("wino63", ["wino43_gemm_kernel<4, 3>", "wino43_gemm_kernel<2, 3>"], 64 * 2904 * (1024 + 1024) * 4 + 64 * 1024 * 1024 * 4),
     "wino63_input_res2": ("wino63", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 4),
     "wino63_output_res2": ("wino63", ["wino_output_kernel"], 64 * 2904 * 1024 * 4 + 24 * 64 * 64 * 1024 * 4),
+    # split (bf16x3) route, same shape: V and U are 6 bytes per element (three bf16 pieces), M stays fp32
+    "wino63_gemm_bf3_res2": ("bf3", ["wino_gemm_bf3_kernel<4, 2>", "wino_gemm_bf3_kernel<2, 2>"], 64 * 2904 * (1024 * 6 + 1024 * 4) + 64 * 1024 * 1024 * 6),
+    "wino63_input_bf3_res2": ("bf3", ["wino_input_bf3_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 6),
     "wino43_gemm_res2": ("wino43", ["wino43_gemm_kernel<4, 0>", "wino43_gemm_kernel<2, 0>"], 36 * 6144 * (1024 + 1024) * 4 + 36 * 1024 * 1024 * 4),
     "wino43_input_res2": ("wino43", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 36 * 6144 * 1024 * 4),
     "wino43_output_res2": ("wino43", ["wino_output_kernel"], 36 * 6144 * 1024 * 4 + 2 * 24 * 64 * 64 * 1024 * 4),

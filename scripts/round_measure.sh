@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's evidence under profiles/ comes from, in one pass on the GPU box (copy gpurun_out/$TAG_* to profiles/):
 #   bench lines of the four modes (un-profiled), rocprofv3 per-shape tables of render / texture / train, the batch sweep,
-#   the stage A/B and 3-D layer timings.   usage: gpurun -- "bash scripts/round_measure.sh r03c"
+#   the stage A/B and 3-D layer timings, the split (bf16x3) route's per-shape tables.   usage: gpurun -- "bash scripts/round_measure.sh r03c"
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-rXX}
@@ -19,22 +19,30 @@ RN_NO_WINOGRAD63=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$O
     python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('batch %3d  %8.2f frames/s  %8.2f ms/step  GEMM-stage frac %.3f' % ($b, d['value'], d['ms_per_step'], d['roofline']['frac']))"
+a = d.get('alt') or {}
+print('batch %3d  fp32 GEMM stage %8.2f frames/s  %8.2f ms/step  frac %.3f   |   split %8.2f frames/s  %8.2f ms/step  frac %.3f (of bf16 peak / 6)'
+      % ($b, d['value'], d['ms_per_step'], d['roofline']['frac'], a.get('value', 0), a.get('ms_per_step', 0), (a.get('roofline') or {}).get('frac', 0)))"
   done
 } > "$O/${TAG}_batch_sweep.txt"
 {
   echo "# scripts/wino_stage_bench.py / res1_bench.py / outin_bench.py, one MI355X, git ${GIT_REV:-?}"
   python scripts/wino_stage_bench.py --shapes 64x1024,64x512 --batch 24 2>&1 | grep -v amdgpu.ids
   python scripts/res1_bench.py 2>&1 | grep -v amdgpu.ids
+  echo "# scripts/bf3_check.py --no-accuracy: the three stages, exact-fp32 multiply stage vs bf16x3 split"
+  python scripts/bf3_check.py --no-accuracy --batch 24 2>&1 | grep -v amdgpu.ids
+  echo "# scripts/c3_check.py: fused 3x3x3 32 -> 32 kernel, fp32 vs bf16x3 split (opt-in)"
+  python scripts/c3_check.py 2>&1 | grep -v amdgpu.ids
   for l in e_conv7 e_conv8 e_conv9; do
     RN_NO_WINOGRAD_S2=1 python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (direct phase kernels)/'
     python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (F(2x2,2x2) per phase)/'
   done
 } > "$O/${TAG}_stage_ab.txt"
-bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_texture --mode texture --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_texture --mode texture --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_render_split --gemm split --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_train_split --mode train --gemm split --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline --no-alt > /dev/null 2>&1
 tail -3 "$O/${TAG}_bench.err"
 cut -c1-250 "$O/${TAG}_bench.json"
 cat "$O/${TAG}_batch_sweep.txt"

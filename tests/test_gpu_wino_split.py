@@ -218,7 +218,7 @@ def test_bench_frames_match_golden_split(fixtures_vox):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The fused 3x3x3 32 -> 32 kernel in bf16x3 (csrc/conv3d_wino_bf3.hip; opt-in: ops.CONV3D_SPLIT / RN_CONV3D_SPLIT=1).  The layers:
+# The fused 3x3x3 32 -> 32 kernel in bf16x3 (csrc/conv3d_wino_bf3.hip; on with ops.WINO_GEMM = "split", ops.CONV3D_SPLIT forces it).  The layers:
 # res_block_3d's two slim.conv3d [3,3,3] 32 -> 32 (tools/layer_util.py:60-75, RenderNet_Shader.py:61-68).
 C3_CASES = [
     (1, 4, 32, 2),       # one item, D = 2: both slices have a padded neighbour
