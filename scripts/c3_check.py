@@ -75,11 +75,13 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=24)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-timing", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
     args = ap.parse_args()
-    accuracy(1, 4, 32, 2)
-    accuracy(1, 8, 32, 3, 1)
-    accuracy(2, 16, 64, 5, 2)
-    accuracy(1, 64, 64, 32, 3)
-    accuracy(3, 10, 20, 4, 4)            # ragged: H % 4 != 0, W % 32 != 0
+    if not args.no_accuracy:
+        accuracy(1, 4, 32, 2)
+        accuracy(1, 8, 32, 3, 1)
+        accuracy(2, 16, 64, 5, 2)
+        accuracy(1, 64, 64, 32, 3)
+        accuracy(3, 10, 20, 4, 4)            # ragged: H % 4 != 0, W % 32 != 0
     if not args.no_timing:
         timing(args.batch, args.iters)
