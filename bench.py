@@ -321,12 +321,12 @@ def train_main(args, world, rank, local_rank):
         loss = tr.step(vox, poses, targets, patch_size=p, start_point=starts[i])
     # dominant kernel of the step: the GEMM stage of the F(4x4,3x3) path on the res2 trunk (forward and input-gradient
     # launches, 42 per step), bracketed by HIP events on the launch stream like in the render bench
-    gemm_events = []
+    gemm_events, wgrad_events = [], []
 
     def stage_hook(stage, tkn):
-        if stage == "gemm" and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+        if stage in ("gemm", "wgrad") and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            gemm_events.append((ev, tkn))
+            (gemm_events if stage == "gemm" else wgrad_events).append((ev, tkn))
             return ev
         return None
 
@@ -385,6 +385,20 @@ def train_main(args, world, rank, local_rank):
                     **({"peak_name": "dense bf16 MFMA peak / 6 (six bf16 piece products per fp32 product)"} if split else {}),
                     "avg_launch_ms": round(kern_ms, 4), "launches_timed": len(gemm_events), "flop_per_launch": fl,
                     "flop_basis": "executed MFMA FLOPs = 2*%d*T*Cin*Cout" % nxi, "traffic": None}
+        roof_w = None
+        if wgrad_events:
+            # the filter gradient of the same layers: four launches (x and dz transforms, 36 K-split GEMMs over the tiles, G^T dU G);
+            # executed FLOPs of the GEMM over the time of ALL four, against the exact-fp32 MFMA peak (this path has no split form)
+            w_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in wgrad_events]))
+            Tw = wgrad_events[0][1][0]
+            flw = 2.0 * 36 * Tw * spec.w_res2 * spec.w_res2
+            roof_w = {"kernel": "rn_conv2d_wino43_wgrad on the res2 3x3 %d->%d conv: wino_input_kernel + wino_dout_kernel + wino43_wgrad_gemm_kernel "
+                                "(+ reduce) + wino_dfilter_kernel, T = %d tiles" % (spec.w_res2, spec.w_res2, Tw),
+                      "bound": "mfma", "achieved": round(flw / (w_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(flw / (w_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "avg_ms_all_four_launches": round(w_ms, 4),
+                      "calls_timed": len(wgrad_events), "flop_per_call": flw,
+                      "flop_basis": "executed MFMA FLOPs of the GEMM stage = 2*36*T*Cin*Cout (direct count: 2*9*B*H*W*Cin*Cout = 4x that)",
+                      "traffic": None}
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -395,7 +409,8 @@ def train_main(args, world, rank, local_rank):
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
             "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
-            "roofline": roof, "final_loss": lossv, "parity": parity, **({"alt": alt} if alt is not None else {}),
+            "roofline": roof, **({"roofline_wgrad": roof_w} if roof_w is not None else {}),
+            "final_loss": lossv, "parity": parity, **({"alt": alt} if alt is not None else {}),
             **({"cpu_baseline": cpu_baseline_train(weights, p)} if (world == 1 and not args.no_cpu_baseline) else {}),
             **per_rank_fields(by_rank, [B] * world, args.steps)}), flush=True)
         if parity is not None and not parity["ok"]:

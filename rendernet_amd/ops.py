@@ -655,7 +655,12 @@ class _Conv(torch.autograd.Function):
         elif (mode == "conv2d" and unit and tuple(ksize) == (3, 3) and _use_wino43(pw, H, W)
               and lib.rn_conv2d_wino43_wgrad_supported(Cin, pw.cout)):
             ws = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, pw.cout), dtype=torch.float32, device=x.device)
+            wev = STAGE_HOOK("wgrad", (B * (-(-H // 4)) * (-(-W // 4)), Cin, pw.cout, "f43")) if STAGE_HOOK is not None else None
+            if wev is not None:
+                wev[0].record()
             rc = lib.rn_conv2d_wino43_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(ws), B, H, W, Cin, pw.cout, st)
+            if wev is not None:
+                wev[1].record()
         elif (mode == "conv2d" and unit and tuple(ksize) == (4, 4) and _use_wino43(pw, H, W)
               and lib.rn_conv2d_wino44_wgrad_supported(Cin, pw.cout)):
             ws = torch.empty(lib.rn_conv2d_wino44_wgrad_workspace_floats(B, H, W, Cin, pw.cout), dtype=torch.float32, device=x.device)
