@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 180            /* 0.1.8: + stride-2 transposed convs through F(2x2,2x2) per phase, fused output->input transform, brick resampler */
+#define RN_VERSION 190            /* 0.1.9: + the multiply stages on the bf16 pipe at fp32 accuracy (rn_winograd_split_*, rn_conv2d_winograd_split_fwd, rn_conv3d_winograd_split_*) */
 
 /* error codes */
 #define RN_OK              0

@@ -495,8 +495,12 @@ WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
 CONV3D_SPLIT = {"": None, "0": False}.get(os.environ.get("RN_CONV3D_SPLIT", ""), True)
 
 
-def _conv3d_split():
-    return WINO_GEMM == "split" if CONV3D_SPLIT is None else bool(CONV3D_SPLIT)
+def _conv3d_split(B=None, H=None, W=None):
+    """An item of the split kernel is a row of 16 tiles through ALL depth slices (B * ceil(H/2) * ceil(W/32) items): below about
+    three quarters of a round of 256 workgroups the fp32 kernel's finer items win (B = 1: 6.07 against 6.86 ms per frame)."""
+    if CONV3D_SPLIT is not None:
+        return bool(CONV3D_SPLIT)
+    return WINO_GEMM == "split" and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)
 
 
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
@@ -561,7 +565,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     unit = all(int(v) == 1 for v in stride)
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
-        if unit and _conv3d_split() and pw.split3d() is not None:
+        if unit and _conv3d_split(B, H, W) and pw.split3d() is not None:
             return lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(pw.split3d().data_ptr()), *e, B, H, W, D, Cin, pw.cout, act, st)
         if unit and pw.wino is not None:
             return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
@@ -680,7 +684,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
-            if mode == "conv3d" and unit and _conv3d_split() and dp.split3d() is not None:
+            if mode == "conv3d" and unit and _conv3d_split(B, H, W) and dp.split3d() is not None:
                 rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
                                                       B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d" and unit and dp.wino is not None:
