@@ -342,7 +342,7 @@ def train_main(args, world, rank, local_rank):
     elapsed = max(by_rank)
     lossv = float(loss.item())
     assert np.isfinite(lossv)
-    # the same steps with the GEMM stage of the wide 2-D convs (forward AND input gradient; the filter gradient stays exact fp32)
+    # the same steps with the multiply stages of the wide 2-D convs (forward, input gradient and, at >= 1024 channels, filter gradient) and of the 3-D encoder
     # on the bf16 pipe by operand splitting: a second trainer from the same initial weights, checked against the same golden
     alt = None
     if not args.no_alt and args.gemm == "f32":
@@ -354,6 +354,16 @@ def train_main(args, world, rank, local_rank):
             parity2 = train_parity(tr2, spec, world)
             for i in range(max(1, args.warmup)):
                 tr2.step(vox, poses, targets, patch_size=p, start_point=starts[i])
+            alt_events = {"gemm": [], "wgrad": []}
+
+            def alt_hook(stage, tkn):
+                if stage in alt_events and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    alt_events[stage].append((ev, tkn))
+                    return ev
+                return None
+
+            ops.STAGE_HOOK = alt_hook
             barrier()
             t0 = time.perf_counter()
             for i in range(args.steps):
@@ -362,9 +372,23 @@ def train_main(args, world, rank, local_rank):
             el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
         finally:
             ops.WINO_GEMM = "f32"
-        alt = {"dtype": "bf16x3-split, fp32 accumulate (forward and input-gradient GEMM stages of the wide 2-D convs; filter gradients exact fp32)",
+            ops.STAGE_HOOK = None
+        alt = {"dtype": "bf16x3-split, fp32 accumulate (forward, input-gradient and -- on the layers at least 1024 channels wide -- filter-gradient "
+                        "multiply stages of the wide 2-D convs, and the 3-D encoder's convs; everything else exact fp32)",
                "value": round(B * world * args.steps / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
                "speedup_vs_value": round(elapsed / el2, 4), "final_loss": float(loss2.item()), "parity": parity2}
+        peak6 = PEAK_BF16_MFMA_TFLOPS / 6.0
+        for stage, key, what in (("gemm", "roofline", "wino_gemm_bf3_kernel, forward and input gradient of the res2 layers"),
+                                 ("wgrad", "roofline_wgrad", "rn_conv2d_winograd_split_wgrad on the res2 layers: wino_input_bf3t + wino_dout_bf3t + "
+                                                              "wino_gemm_bf3 (rows = input channels, K = tiles) + wino_dfilter_bf3, all four launches")):
+            if alt_events[stage]:
+                ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in alt_events[stage]]))
+                Ta = alt_events[stage][0][1][0]
+                fla = 2.0 * 36 * Ta * spec.w_res2 * spec.w_res2
+                alt[key] = {"kernel": what, "bound": "mfma", "achieved": round(fla / (ms * 1e-3) / 1e12, 2), "peak": round(peak6, 2), "unit": "TFLOP/s",
+                            "frac": round(fla / (ms * 1e-3) / 1e12 / peak6, 4), "avg_ms": round(ms, 4), "calls_timed": len(alt_events[stage]),
+                            "peak_name": "dense bf16 MFMA peak / 6 (six bf16 piece products per fp32 product)",
+                            "flop_basis": "fp32-equivalent FLOPs = 2*36*T*Cin*Cout, T = %d tiles" % Ta, "traffic": None}
     if rank == 0:
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
         fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2

@@ -270,6 +270,14 @@ int rn_winograd_split_gemm(int scheme, const void* Vs, const void* w_split, floa
 int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
                                  const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
                                  int Cin, int Cout, int transposed, int act, void* stream);
+/* Filter gradient of the same layers (tf.nn.conv2d_backprop_filter of slim.conv2d [3,3] / [4,4], stride 1: tools/layer_util.py:101-104,
+ * RenderNet_Shader.py:71-103) with the reduction over the tiles on the bf16 pipe, same arithmetic: dw [R,R,Cin,Cout] += ...;
+ * scheme RN_WINO_F43 (3x3) or RN_WINO_F44 (4x4); x [B,H,W,Cin], dz [B,H,W,Cout]; workspace of
+ * rn_winograd_split_wgrad_workspace_bytes bytes.  The exact-fp32 counterpart is rn_conv2d_wino43_wgrad / rn_conv2d_wino44_wgrad. */
+int rn_winograd_split_wgrad_supported(int scheme, int Cin, int Cout);
+size_t rn_winograd_split_wgrad_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout);
+int rn_conv2d_winograd_split_wgrad(int scheme, const float* x, const float* dz, float* dw, void* workspace, int B, int H, int W,
+                                   int Cin, int Cout, void* stream);
 /* The 3x3x3, stride-1, 32 -> 32 channel convs of the 3-D encoder (res_block_3d, res1_skip: tools/layer_util.py:60-73 ->
  * tf.nn.conv3d :253; RenderNet_Shader.py:51-64) on the bf16 matrix pipe at fp32 accuracy: Winograd F(2x2,3x3) over (H, W),
  * direct over depth like rn_conv3d_wino_fwd, every product taken as six bf16 piece products with fp32 accumulation (see the

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "librendernet_hip.so"
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv_wino43.hip", "conv_wino_bf3.hip", "conv3d_wino_bf3.hip", "conv_wino43_wgrad.hip", "conv3d_drun.hip", "conv_direct.hip", "conv_tiled.hip", "resample.hip", "resample_tiled.hip", "misc_kernels.hip",
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv_wino43.hip", "conv_wino_bf3.hip", "conv_wino_bf3_wgrad.hip", "conv3d_wino_bf3.hip", "conv_wino43_wgrad.hip", "conv3d_drun.hip", "conv_direct.hip", "conv_tiled.hip", "resample.hip", "resample_tiled.hip", "misc_kernels.hip",
            "conv_wgrad.hip", "train_kernels.hip", "resample_bwd.hip"]
 HEADERS = ["rn_common.h", "wino_mats.h", os.path.join("..", "..", "include", "rendernet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -500,6 +500,18 @@ extern "C" int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const vo
 }
 
 // ---- the 3x3x3 32 -> 32 convs of the 3-D encoder on the bf16 matrix pipe at fp32 accuracy (conv3d_wino_bf3.hip)
+extern "C" int rn_winograd_split_wgrad_supported(int scheme, int Cin, int Cout) { return rn_wino_bf3_wgrad_supported(scheme, Cin, Cout) ? 1 : 0; }
+extern "C" size_t rn_winograd_split_wgrad_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)
+{
+    return rn_wino_bf3_wgrad_supported(scheme, Cin, Cout) ? rn_wino_bf3_wgrad_workspace_bytes(scheme, B, H, W, Cin, Cout) : 0;
+}
+extern "C" int rn_conv2d_winograd_split_wgrad(int scheme, const float* x, const float* dz, float* dw, void* workspace, int B, int H, int W,
+                                              int Cin, int Cout, void* stream)
+{
+    if (!x || !dz || !dw || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_wgrad: null pointer");
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_wgrad: bad sizes");
+    return rn_launch_conv_wino_bf3_wgrad(scheme, x, dz, dw, workspace, B, H, W, Cin, Cout, static_cast<hipStream_t>(stream));
+}
 extern "C" int rn_conv3d_winograd_split_supported(int Cin, int Cout) { return rn_conv3d_wino_bf3_supported(Cin, Cout) ? 1 : 0; }
 extern "C" size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout)
 {

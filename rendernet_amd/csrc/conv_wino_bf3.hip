@@ -265,7 +265,7 @@ struct Bf3GemmArgs {
 // WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles, 128
 // accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64 = 2 x 2 tiles): the launcher runs ragged row blocks, the
 // items of a last partial round and small batches as half items.
-// TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower)
+// TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower, 4: filter gradient)
 template <int WM, int TAG>
 __global__ __launch_bounds__(512, 2)
 void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
@@ -526,6 +526,7 @@ static int wino_gemm_bf3_launch_w(int tag, const Bf3GemmArgs& a, int begin, int 
     case 0: return wino_gemm_bf3_launch_t<WM, 0>(a, begin, end, parts, st);
     case 1: return wino_gemm_bf3_launch_t<WM, 1>(a, begin, end, parts, st);
     case 2: return wino_gemm_bf3_launch_t<WM, 2>(a, begin, end, parts, st);
+    case 4: return wino_gemm_bf3_launch_t<WM, 4>(a, begin, end, parts, st);
     default: return wino_gemm_bf3_launch_t<WM, 3>(a, begin, end, parts, st);
     }
 }
@@ -535,9 +536,14 @@ static int wino_gemm_bf3_launch(int wm, int tag, const Bf3GemmArgs& a, int begin
     return wm == 4 ? wino_gemm_bf3_launch_w<4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<2>(tag, a, begin, end, parts, st);
 }
 
-int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
+// nxi independent GEMMs  M[p] (T x Cout) = V[p] (T x Cin) . U[p] (Cin x Cout) on split operands:
+//   V [nxi][Cin/16][T][3][16], U [nxi][Cout/256][Cin/16][256][3][16], M [nxi][T][Cout] fp32; Cin % 16 == 0, Cout % 256 == 0.
+// The forward path calls it with (tiles, input channels, output channels); the filter gradient (conv_wino_bf3_wgrad.hip) with
+// (input channels, tiles of one K split, output channels) and nxi = planes x K splits.
+int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
 {
-    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    if (nxi < 1 || Cin < 16 || Cin % 16 != 0 || Cout < SB_BN || Cout % SB_BN != 0)
+        return rn_set_error(RN_E_UNSUPPORTED, "gemm_bf3: planes=%d K=%d N=%d", nxi, Cin, Cout);
     if (T < 1 || (T + SB_BM) * (long long)Cout * 4 >= 0xffffff00LL || T * (long long)Cout * 4 >= 0x7fffff00LL || (T + SB_BM) * (long long)SB_ROW >= 0x7fffff00LL)
         return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: a transform plane must stay below the 2 GiB buffer window");
     Bf3GemmArgs a;
@@ -546,8 +552,6 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
     a.v_step_bytes = (unsigned)(T * SB_ROW); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO_BF3_PROBE") ? atoi(getenv("RN_WINO_BF3_PROBE")) : 0; a.probe = probe; }
     static const bool notail = getenv("RN_WINO_BF3_NOTAIL") != nullptr;
-    const int nxi = rn_wino_scheme_nxi(scheme);
-    const int tag = scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
     const int full = (int)(T / SB_BM), ragged = (int)(T % SB_BM);    // whole 256-row blocks; rows of the last, partial one
     if ((long long)nxi * (full + 1) * a.nblocks * 2 > 0x3fffffff) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: too many items");
     a.mrows = SB_BM;
@@ -597,6 +601,13 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
         return wino_gemm_bf3_launch(wm, tag, a, 0, nxi * a.nblocks, parts, st);
     }
     return RN_OK;
+}
+
+int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
+{
+    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    const int tag = scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
+    return rn_launch_gemm_bf3_planes(rn_wino_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, st);
 }
 
 // x [B,H,W,Cin] -> y [B,H,W,Cout]; us from rn_launch_wino_pack_bf3; ws >= rn_wino_bf3_workspace_bytes(...) bytes

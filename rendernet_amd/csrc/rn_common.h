@@ -68,6 +68,10 @@ size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st);
 int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, hipStream_t st);
 int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st);
+int rn_launch_gemm_bf3_planes(int nplanes, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st);
+bool rn_wino_bf3_wgrad_supported(int scheme, int Cin, int Cout);                                          // conv_wino_bf3_wgrad.hip
+size_t rn_wino_bf3_wgrad_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout);
+int rn_launch_conv_wino_bf3_wgrad(int scheme, const float* x, const float* dz, float* dw, void* ws, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 int rn_launch_conv_wino_bf3(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
                             float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st);
 bool rn_conv3d_wino_bf3_supported(int Cin, int Cout);                                                     // conv3d_wino_bf3.hip

@@ -495,6 +495,10 @@ WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
 CONV3D_SPLIT = {"": None, "0": False}.get(os.environ.get("RN_CONV3D_SPLIT", ""), True)
 
 
+# The filter gradients of the wide 2-D convs in split mode too (RN_WGRAD_SPLIT=0: keep them on the exact-fp32 route)
+WGRAD_SPLIT = os.environ.get("RN_WGRAD_SPLIT", "1") not in ("", "0")
+
+
 def _conv3d_split(B=None, H=None, W=None):
     """An item of the split kernel is a row of 16 tiles through ALL depth slices (B * ceil(H/2) * ceil(W/32) items): below about
     three quarters of a round of 256 workgroups the fp32 kernel's finer items win (B = 1: 6.07 against 6.86 ms per frame)."""
@@ -656,6 +660,18 @@ class _Conv(torch.autograd.Function):
             rc = 0
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
+        elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and WINO_GEMM == "split" and WGRAD_SPLIT
+              and max(Cin, pw.cout) >= 1024              # measured at crop 64: 1024 -> 1024 1.10 -> 0.79 ms, 1024 -> 512 (4x4) 0.92 -> 0.65; 512 -> 512: no gain
+              and lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44, Cin, pw.cout)):
+            # the reduction over the tiles on the bf16 pipe (csrc/conv_wino_bf3_wgrad.hip)
+            sch = L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44
+            ws = torch.empty(lib.rn_winograd_split_wgrad_workspace_bytes(sch, B, H, W, Cin, pw.cout), dtype=torch.uint8, device=x.device)
+            wev = STAGE_HOOK("wgrad", (B * (-(-H // 4)) * (-(-W // 4)), Cin, pw.cout, "f43s" if ksize[0] == 3 else "f44s")) if STAGE_HOOK is not None else None
+            if wev is not None:
+                wev[0].record()
+            rc = lib.rn_conv2d_winograd_split_wgrad(sch, L.ptr(x), L.ptr(dz), L.ptr(dw), ctypes.c_void_p(ws.data_ptr()), B, H, W, Cin, pw.cout, st)
+            if wev is not None:
+                wev[1].record()
         elif (mode == "conv2d" and unit and tuple(ksize) == (3, 3) and _use_wino43(pw, H, W)
               and lib.rn_conv2d_wino43_wgrad_supported(Cin, pw.cout)):
             ws = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, pw.cout), dtype=torch.float32, device=x.device)

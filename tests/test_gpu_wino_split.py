@@ -338,3 +338,71 @@ def test_conv3d_split_is_refused_for_other_widths():
     us = torch.zeros(64, dtype=torch.uint8, device="cuda")
     rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(us.data_ptr()), None, None, None, L.ptr(x), None, 1, 4, 4, 4, 16, 16, 0, L.stream_ptr())
     assert rc != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Filter gradient of the wide 2-D convs with the reduction over the tiles on the bf16 pipe (csrc/conv_wino_bf3_wgrad.hip):
+# tf.nn.conv2d_backprop_filter of slim.conv2d [3,3] / [4,4] stride 1 (tools/layer_util.py:101-104, RenderNet_Shader.py:71-103).
+@pytest.mark.parametrize("k,B,H,W,Cin,Cout", [(3, 1, 8, 8, 256, 256), (3, 2, 16, 16, 256, 512), (3, 3, 13, 27, 512, 256), (3, 1, 37, 5, 256, 256),
+                                               (3, 6, 32, 32, 256, 256), (3, 1, 1, 1, 256, 256), (3, 24, 32, 32, 256, 256),
+                                               (4, 1, 8, 8, 256, 256), (4, 2, 16, 16, 512, 256), (4, 3, 13, 27, 256, 256)])
+def test_split_wgrad(k, B, H, W, Cin, Cout):
+    """vs autograd over the oracle conv, and vs the exact-fp32 Winograd filter gradient of the same layer (3e-5 / 1e-4 of max: same formulas,
+    fp32-class multiply); tile counts that are not multiples of 16, K splits, ragged planes, accumulation into dw."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    sch = L.RN_WINO_F43 if k == 3 else L.RN_WINO_F44
+    assert lib.rn_winograd_split_wgrad_supported(sch, Cin, Cout) == 1
+    assert lib.rn_winograd_split_wgrad_supported(sch, 128, 256) == 0
+    assert lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F63, Cin, Cout) == 0
+    rng = np.random.default_rng(B * 1000 + H * 31 + W + Cin + k)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    dz = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    wt = torch.zeros(k, k, Cin, Cout, requires_grad=True)
+    OL.conv2d(torch.from_numpy(x), wt).backward(torch.from_numpy(dz))
+    xd, dzd = _dev(x), _dev(dz)
+    dw = torch.zeros(k, k, Cin, Cout, device="cuda")
+    ws = torch.empty(lib.rn_winograd_split_wgrad_workspace_bytes(sch, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        L.check(lib.rn_conv2d_winograd_split_wgrad(sch, L.ptr(xd), L.ptr(dzd), L.ptr(dw), ctypes.c_void_p(ws.data_ptr()), B, H, W, Cin, Cout,
+                                                   L.stream_ptr()), "split wgrad")
+    _close(dw, 2 * wt.grad, "accumulated split dw vs oracle autograd")
+    ref = torch.zeros_like(dw)
+    if k == 3:
+        w2 = torch.empty(lib.rn_conv2d_wino43_wgrad_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+        L.check(lib.rn_conv2d_wino43_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(ref), L.ptr(w2), B, H, W, Cin, Cout, L.stream_ptr()), "wino43 wgrad")
+    else:
+        w2 = torch.empty(lib.rn_conv2d_wino44_wgrad_workspace_floats(B, H, W, Cin, Cout), device="cuda")
+        L.check(lib.rn_conv2d_wino44_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(ref), L.ptr(w2), B, H, W, Cin, Cout, L.stream_ptr()), "wino44 wgrad")
+    _close(dw, (2 * ref).cpu(), "split vs exact-fp32 Winograd wgrad", rtol=3e-5 if k == 3 else 1e-4)
+
+
+def test_split_wgrad_plan():
+    """The planner's choice for the res2 training shape: 36 x 16 blocks = 2.25 rounds of 256 workgroups, whose quarter round the GEMM
+    launcher runs as half items (4.5 half rounds of 5: 0.9) -- no K split; a shape with few blocks is split along the tiles."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    # res2 at crop 64: T = 24 * 8 * 8 = 1536 tiles: Vt + dMt + dUp
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 1024, 1024) == 36 * 1536 * 2048 * 6 + 36 * 1024 * 1024 * 4 + 256
+    # 256 -> 256 at T = 1536: 36 blocks = 0.28 half rounds; KS = 3 fills 0.84 of one round (KS = 4: 0.56 of two), Tk = 512
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 256, 256) == 108 * 512 * 512 * 6 + 108 * 256 * 256 * 4 + 256
+
+
+@pytest.mark.parametrize("mode", ["f32", "split"])
+def test_full_width_training_step_against_the_float64_golden(mode, monkeypatch):
+    """BASELINE configs[3] at full width (237M parameters, crop 64, two samples): loss, prediction and sampled gradient entries of all
+    166 variables against tests/golden/train_step_golden.npz (float64 torch-CPU autograd over the oracle graph) -- the check bench.py
+    runs on its train line, here for both multiply routes.  In split mode the forward, input-gradient, 3-D encoder and (>= 1024
+    channels) filter-gradient stages all run on the bf16 pipe; the bars are the same."""
+    import bench
+    from rendernet_amd import ops
+    from rendernet_amd.shader import ShaderSpec, init_shader_weights
+    from rendernet_amd.train import Trainer
+    monkeypatch.setattr(ops, "WINO_GEMM", mode)
+    spec = ShaderSpec().check()
+    tr = Trainer(spec, init_shader_weights(spec, seed=1234, perturb=True), device="cuda:0")
+    got = bench.train_parity(tr, spec, 1)
+    print(mode, {k: got[k] for k in ("loss_rel_err", "pred_max_abs_err", "filter_grad_max_rel_err", "bias_alpha_grad_max_rel_err", "worst_variables")})
+    assert got["ok"], got
+    del tr
+    torch.cuda.empty_cache()
