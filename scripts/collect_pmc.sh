@@ -33,10 +33,11 @@ for tag in sq fetch write tcc; do
     run bf3 $tag $C -- python "$R/scripts/bf3_check.py" --no-accuracy --iters 3 --shapes 0          # res2 shape, F(6x6,3x3): fp32 stages, then the split ones
     RN_NO_WINOGRAD3D=1 run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
     run res1w $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    RN_CONV3D_SPLIT=1 run res1s $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3        # the bf16x3 kernel on the same layer
     run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done
-for name in wino63 wino43 bf3 res1 res1w resample; do
-    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = bf3 ] && flt=bf3; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = resample ] && flt=resample_
+for name in wino63 wino43 bf3 res1 res1w res1s resample; do
+    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = bf3 ] && flt=bf3; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = res1s ] && flt=conv3d_wino_bf3; [ $name = resample ] && flt=resample_
     : > "$OUT/$name.txt"
     for tag in sq fetch write tcc; do
         f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)
@@ -44,4 +45,4 @@ for name in wino63 wino43 bf3 res1 res1w resample; do
     done
 done
 python "$R/scripts/pmc_to_traffic.py" "$OUT" "$OUT/traffic.json"
-echo "wrote $OUT/{wino63,wino43,bf3,res1,res1w,resample}.txt and $OUT/traffic.json"
+echo "wrote $OUT/{wino63,wino43,bf3,res1,res1w,res1s,resample}.txt and $OUT/traffic.json"

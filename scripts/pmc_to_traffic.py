@@ -28,6 +28,7 @@ KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s),
     "wino43_output_res2": ("wino43", ["wino_output_kernel"], 36 * 6144 * 1024 * 4 + 2 * 24 * 64 * 64 * 1024 * 4),
     "conv3d_drun_res1": ("res1", ["conv3d_k3_drun"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 27 * 32 * 32 * 4),
     "conv_wino_res1": ("res1w", ["conv_wino_kernel"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 16 * 3 * 32 * 32 * 4),
+    "conv3d_wino_bf3_res1": ("res1s", ["conv3d_wino_bf3_kernel"], 24 * 64 * 64 * 32 * 32 * 4 * 2 + 16 * 3 * 32 * 32 * 6),
     "resampler": ("resample", ["resample_prepare", "resample_classify", "resample_main"], 24 * 9437184),
 }
 
