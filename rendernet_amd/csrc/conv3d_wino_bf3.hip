@@ -124,6 +124,12 @@ __device__ __forceinline__ void c3_mfma_start(f32x4& c, const bf16x8& u, const b
     asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(u), "v"(p));
 }
 
+// A ds_read_b128 is conflict-free when the 16 lanes of a read group (here: the 16 tiles, at one channel quarter) hit 16 different
+// 16-byte bank groups of a 256-byte window.  A pixel is a 128-byte slot and a tile advances by two pixels, so the XOR swizzle of
+// the chunk index alone reaches only 8 of the 16: pixels 16..33 of a patch row additionally swap places with their neighbour
+// (slot = px ^ 1), which puts tiles 8..15 into the other half of the window (one 2-way collision is left in the columns b >= 2).
+__device__ __forceinline__ int c3_slot_swap(int px) { return ((px >> 4) | (px >> 5)) & 1; }
+
 #define C3_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // PROBE (timing experiments, wrong results; RN_C3_PROBE): 1 no DMA in the loop, 2 no arithmetic, 4 no epilogue, 8 no barriers
@@ -166,14 +172,15 @@ void conv3d_wino_bf3_kernel(const C3Args a)
     const int rowA = (0x1210 >> (4 * r)) & 3, rowB = (0x3122 >> (4 * r)) & 3;
     const float sgn = r == 1 ? 1.f : -1.f;
     // the wave needs patch columns b = c + k, k = 0..2, of each tile: pixel (py, px = 2 tx + b) sits at (py * 34 + px) * 128, the
-    // lane's 8 channels = logical 16-byte chunks 2 kq + h, physical chunk = logical ^ ((px >> 1) & 7) = logical ^ ((tx + (b >> 1)) & 7)
+    // lane's 8 channels = logical 16-byte chunks 2 kq + h, physical chunk = logical ^ ((px >> 1) & 7), in slot px ^ c3_slot_swap(px)
     unsigned fo[3][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int b = c + k;
-            fo[k][h] = (unsigned)((2 * tx + b) * 128) + ((((unsigned)(2 * kq + h)) ^ (unsigned)((tx + (b >> 1)) & 7)) << 4);
+            const int px = 2 * tx + b;
+            fo[k][h] = (unsigned)((px ^ c3_slot_swap(px)) * 128) + ((((unsigned)(2 * kq + h)) ^ (unsigned)((px >> 1) & 7)) << 4);
         }
     const unsigned offA = (unsigned)(rowA * C3PW * 128), offB = (unsigned)(rowB * C3PW * 128);
 
@@ -201,7 +208,8 @@ void conv3d_wino_bf3_kernel(const C3Args a)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int q = (wave + 8 * i) * 8 + (lane >> 3);
-            const int py = (q * 241) >> 13, px = q - py * C3PW;                        // q / 34 for q < 256
+            const int py = (q * 241) >> 13, pxs = q - py * C3PW;                       // q / 34 for q < 256; pxs: the SLOT's column
+            const int px = pxs ^ c3_slot_swap(pxs);                                    // the pixel that lives in it
             const bool ok = q < C3NPIX && (unsigned)(y0 + py) < (unsigned)a.H && (unsigned)(x0 + px) < (unsigned)a.W;
             roff[i] = ok ? base + (unsigned)(py * a.W + px) * pix_bytes + (unsigned)((((lane & 7) ^ ((px >> 1) & 7))) << 4) : C3OOB;
         }
