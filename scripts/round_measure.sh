@@ -30,7 +30,9 @@ print('batch %3d  fp32 GEMM stage %8.2f frames/s  %8.2f ms/step  frac %.3f   |  
   python scripts/res1_bench.py 2>&1 | grep -v amdgpu.ids
   echo "# scripts/bf3_check.py --no-accuracy: the three stages, exact-fp32 multiply stage vs bf16x3 split"
   python scripts/bf3_check.py --no-accuracy --batch 24 2>&1 | grep -v amdgpu.ids
-  echo "# scripts/c3_check.py: fused 3x3x3 32 -> 32 kernel, fp32 vs bf16x3 split (opt-in)"
+  echo "# scripts/wgrad_split_bench.py: F(4x4,3x3) / F(4x4,4x4) filter gradient at crop 64, exact fp32 vs split (all four launches)"
+  python scripts/wgrad_split_bench.py 2>&1 | grep -v amdgpu.ids
+  echo "# scripts/c3_check.py: fused 3x3x3 32 -> 32 kernel, fp32 vs bf16x3 split"
   python scripts/c3_check.py 2>&1 | grep -v amdgpu.ids
   for l in e_conv7 e_conv8 e_conv9; do
     RN_NO_WINOGRAD_S2=1 python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (direct phase kernels)/'
