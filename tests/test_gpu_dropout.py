@@ -99,12 +99,14 @@ def test_dropout_takes_unaligned_views_and_empty_tensors():
 
 
 def test_checkpoint_resume_continues_the_trajectory(tmp_path):
-    """Trainer.save_checkpoint / load_checkpoint carry weights, Adam moments and global_step: two steps + restart + one
-    step lands where three uninterrupted steps land (to within the run-to-run spread of the fp32-atomic filter
-    gradients), while a weights-only restart -- Adam at t = 1 with zero moments, the learning-rate staircase back at step
-    0 -- does not.  Distances are the 99th percentile of |delta parameter|, not the maximum: the net is piecewise linear, and
-    ONE pre-activation within 1e-6 of its PReLU kink taking the other branch in one of two runs (their filter gradients
-    differ in the last bits: atomics) moves ~0.05 % of the parameters by a full Adam step -- measured, not a defect."""
+    """Trainer.save_checkpoint / load_checkpoint carry weights, Adam moments and global_step: a trainer restarted from the
+    checkpoint and the trainer that wrote it take the SAME next step (to within the last bits the fp32-atomic filter gradients
+    leave), while a weights-only restart -- Adam at t = 1 with zero moments, the learning-rate staircase back at step 0 -- does
+    not.  The comparison is against the continuation of the very trainer that saved, not against a second run from scratch: Adam
+    turns the rounding noise of a (near-)zero gradient into a full +-lr step, so two from-scratch runs of three steps land on one
+    of two trajectories 1.5e-5 apart at the median, at random (measured in round 4: four trainers from the same weights, six
+    processes) -- that says nothing about checkpoints.  Distances are medians / a fraction, for the same reason: a handful of such parameters may flip in the one step
+    compared here too."""
     from rendernet_amd.shader import tiny_spec, init_shader_weights
     from rendernet_amd.train import Trainer
     spec = tiny_spec(1)
@@ -120,12 +122,6 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
             tr.step(vox, poses, tgt, patch_size=16, start_point=(i, 2 * i))
         return tr
 
-    ref = run(Trainer(spec, w, **kw), range(3))
-    ref2 = run(Trainer(spec, w, **kw), range(3))
-    def dist(p, q, quant=0.99):
-        return float(torch.quantile((p - q).abs()[::7].float(), quant))         # every 7th parameter: quantile() caps its input size
-
-    spread = dist(ref2.param, ref.param)                            # wgrad accumulates with atomics: order varies
     a = run(Trainer(spec, w, **kw), range(2))
     path = str(tmp_path / "ck.npz")
     a.save_checkpoint(path, epoch=7)
@@ -133,16 +129,15 @@ def test_checkpoint_resume_continues_the_trajectory(tmp_path):
     b = Trainer(spec, init_shader_weights(spec, seed=99), **kw)
     assert b.load_checkpoint(dict(np.load(path))) == 7 and b.global_step == 2
     assert torch.equal(b.param, a.param) and torch.equal(b.m, a.m) and torch.equal(b.v, a.v)
-    run(b, [2])
-    resumed = dist(b.param, ref.param)
     c = Trainer(spec, {k: v for k, v in a.state_dict().items()}, **kw)     # weights only: the round-1 checkpoint
+    before = a.param.clone()
+    run(a, [2])
+    run(b, [2])
     run(c, [2])
-    cold = dist(c.param, ref.param)
-    assert b.global_step == 3
-    # the weights-only restart is off for (nearly) EVERY parameter -- lr staircase back at step 0, Adam at t = 1 -- so the test
-    # compares MEDIANS: the kink crossings above reach a few per cent of the parameters in some runs (seen: 99th percentile of the
-    # resumed run 3.9e-4 against 1.5e-3 cold, with a run-to-run spread of 2e-5 in the same session), the median of a correct resume
-    # stays at the last-bits level (lr = 1e-3: a step that forgot its moments moves the median parameter by >= 4e-5)
-    cold_med, resumed_med, spread_med = dist(c.param, ref.param, 0.5), dist(b.param, ref.param, 0.5), dist(ref2.param, ref.param, 0.5)
-    assert resumed_med <= max(20 * spread_med, 2e-6), (resumed_med, spread_med, resumed, spread)
-    assert cold > resumed and cold_med > 10 * (resumed_med + 1e-7), (cold, resumed, cold_med, resumed_med)
+    assert b.global_step == 3 and a.global_step == 3
+    step = float((a.param - before).abs().median())                 # what one step moves the median parameter by
+    d_resumed, d_cold = (b.param - a.param).abs(), (c.param - a.param).abs()
+    assert step > 1e-5
+    assert float(d_resumed.median()) <= 1e-7 and float((d_resumed > 1e-6).float().mean()) <= 0.01, \
+        (float(d_resumed.median()), float((d_resumed > 1e-6).float().mean()), float(d_resumed.max()))
+    assert float(d_cold.median()) > 0.05 * step and float(d_cold.median()) > 100 * float(d_resumed.median()), (float(d_cold.median()), step)
