@@ -257,7 +257,9 @@ def train_parity(tr, spec, world):
         n += g.size
     per_var.sort(reverse=True)
     tr.grad.zero_()
-    tol = {"loss_rel": 1e-4, "filter_grad_rel_to_max": 1e-3, "bias_alpha_grad_rel_to_max": 5e-3, "pred": PARITY_TOL}
+    tol = {"loss_rel": 1e-4, "filter_grad_rel_to_max": 1e-3, "bias_alpha_grad_rel_to_max": 5e-3, "pred": PARITY_TOL,
+           "why_5e-3": "bias / PReLU-slope gradients are sums of ~1e5 mixed-sign terms that cancel to 1e-2..1e-3 of their magnitude sum: a float32 "
+                       "torch-CPU autograd of the same graph is 2.4e-3 away from the float64 golden on e_conv7's bias"}
     ok = (loss_rel <= tol["loss_rel"] and worst["filters"] <= tol["filter_grad_rel_to_max"]
           and worst["bias_alpha"] <= tol["bias_alpha_grad_rel_to_max"] and pred_err <= PARITY_TOL)
     return {"loss": loss, "loss_rel_err": loss_rel, "pred_max_abs_err": pred_err, "filter_grad_max_rel_err": worst["filters"],

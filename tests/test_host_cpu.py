@@ -470,3 +470,16 @@ def test_bench_golden_parity_indexing_and_per_rank_fields():
     assert bench.golden_parity("stress", outs, [0, 1])["max_abs_err"] == 0.0
     pr = bench.per_rank_fields([0.2, 0.1, 0.3], [3, 3, 3], 10)
     assert pr["ms_per_step_per_rank"] == {"min": 10.0, "mean": 20.0, "max": 30.0} and pr["per_rank"]["units_per_step"] == [3, 3, 3]
+
+
+def test_split_filter_gradient_planner_is_a_host_function():
+    """rn_winograd_split_wgrad_workspace_bytes plans K splits and tile padding on the host (csrc/conv_wino_bf3_wgrad.hip: wgrad_plan):
+    the res2 training shape (T = 1536 tiles, 576 blocks = 4.5 half rounds of 5) takes none; a 256 -> 256 layer is cut in three;
+    a single tile is padded to one even pair of K steps."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 1024, 1024) == 36 * 1536 * 2048 * 6 + 36 * 1024 * 1024 * 4 + 256
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 256, 256) == 108 * 512 * 512 * 6 + 108 * 256 * 256 * 4 + 256
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F44, 1, 1, 1, 256, 256) == 49 * 32 * 512 * 6 + 49 * 256 * 256 * 4 + 256
+    assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 128, 256) == 0           # unsupported widths
+    assert lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F63, 1024, 1024) == 0                            # 4x4-output schemes only
