@@ -406,3 +406,42 @@ def test_full_width_training_step_against_the_float64_golden(mode, monkeypatch):
     assert got["ok"], got
     del tr
     torch.cuda.empty_cache()
+
+
+def test_split_routes_batch_chunks(monkeypatch):
+    """The split launchers cut the batch like the exact ones when a transform plane would not fit one 2-GiB buffer window
+    (RN_WINO43_MAX_PLANE lowers the limit for the test): forward through F(4x4,3x3) and F(6x6,3x3) bit for bit equal to the unchunked
+    call, the filter gradient to rounding (dw accumulates chunk by chunk: another order)."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    B, H, W, Cin, Cout = 7, 8, 12, 256, 256
+    rng = np.random.default_rng(21)
+    x = _dev(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    dz = _dev(rng.standard_normal((B, H, W, Cout)).astype(np.float32))
+    w = _dev(_xavier(rng, (3, 3, Cin, Cout)))
+    st = L.stream_ptr()
+
+    def fwd(sch):
+        us = torch.empty(lib.rn_winograd_split_packed_bytes(sch, Cin, Cout), dtype=torch.uint8, device="cuda")
+        L.check(lib.rn_winograd_split_pack(sch, L.ptr(w), ctypes.c_void_p(us.data_ptr()), Cin, Cout, 0, st), "pack")
+        ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sch, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+        y = torch.empty((B, H, W, Cout), device="cuda")
+        L.check(lib.rn_conv2d_winograd_split_fwd(sch, L.ptr(x), ctypes.c_void_p(us.data_ptr()), None, None, None, L.ptr(y), None,
+                                                 ctypes.c_void_p(ws.data_ptr()), B, H, W, Cin, Cout, 0, 0, st), "split fwd")
+        return y
+
+    def wgrad():
+        dw = torch.zeros(3, 3, Cin, Cout, device="cuda")
+        ws = torch.empty(lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+        L.check(lib.rn_conv2d_winograd_split_wgrad(L.RN_WINO_F43, L.ptr(x), L.ptr(dz), L.ptr(dw), ctypes.c_void_p(ws.data_ptr()), B, H, W, Cin, Cout, st), "wgrad")
+        return dw
+
+    whole43, whole63, dw_whole = fwd(L.RN_WINO_F43), fwd(L.RN_WINO_F63), wgrad()
+    plane = 2 * 3 * 256 * 4                                       # F(4x4): tiles per image * channels * 4 B
+    monkeypatch.setenv("RN_WINO43_MAX_PLANE", str(2 * plane + plane // 2))          # forward: two images fit, three do not; filter gradient (6 B): one
+    chunk43, chunk63, dw_chunk = fwd(L.RN_WINO_F43), fwd(L.RN_WINO_F63), wgrad()
+    assert torch.equal(whole43, chunk43) and torch.equal(whole63, chunk63)
+    assert float((dw_whole - dw_chunk).abs().max()) <= 1e-5 * float(dw_whole.abs().max())
+    want = OL.conv2d(x.cpu().numpy(), w.cpu().numpy(), None, (1, 1))
+    _close(chunk43, want, "chunked split F(4x4,3x3)")
+    _close(chunk63, want, "chunked split F(6x6,3x3)")
