@@ -260,6 +260,12 @@ int rn_winograd_output_input_transform(int scheme, const float* M, const float* 
  *                                      memory; scheme RN_WINO_F43 | RN_WINO_F63 (3x3) | RN_WINO_F44 (4x4; transposed = 1 pads
  *                                      two before); epilogue arguments as rn_conv2d_fwd_train.
  * Needs Cin % 32 == 0, Cout % 256 == 0 (rn_winograd_split_supported); planes below 2 GiB as above. */
+/* Operand format of the split entries, OR-ed into `scheme`: 0 = three bf16 pieces per fp32 value, six piece products (above);
+ * RN_SPLIT_FMT_H2 = the value divided by a power-of-two scale of its tensor (from max|x| of the tensor, found by the transform's
+ * launcher itself, and the growth bound of the transform) as TWO fp16 pieces -- 22 mantissa bits for everything within 2^-18 of the
+ * scaled maximum -- and three piece products, fp32 accumulation, the scales multiplied back on the way out: half the matrix work,
+ * 4 instead of 6 bytes per operand element.  The buffers carry a 256-byte tail with the tensor's max|x|; sizes from the *_bytes entries. */
+#define RN_SPLIT_FMT_H2 0x100
 int rn_winograd_split_supported(int scheme, int Cin, int Cout);
 size_t rn_winograd_split_packed_bytes(int scheme, int Cin, int Cout);
 size_t rn_winograd_split_v_bytes(int scheme, long long T, int Cin);

@@ -33,8 +33,41 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+// Operand formats of the GEMM stage.  A row of an operand panel holds, per K step of 16, NP planes of 16 values (32 bytes each).
+//   B3: three bf16 pieces (exact sum = the fp32 value), six piece products i + j <= 2.  Rows of 96 bytes; the two 16-byte chunks
+//       of a plane are swapped in rows with bit 3 set.
+//   H2: the fp32 value divided by a power-of-two scale of its tensor, as two fp16 pieces (22-bit mantissa; values below 2^-18 of
+//       the scaled maximum lose relative, not absolute, precision), three products (h0 h0, h0 h1, h1 h0); the accumulators are
+//       multiplied by the two scales on the way out.  Rows of 64 bytes; the four chunks of a row are XORed with bits 2..3 of the
+//       row index.  Either way the 16 lanes of a ds_read_b128 group (16 consecutive rows) hit 16 different bank groups.
+struct FmtB3 {
+    static constexpr int NP = 3, ROW = 96, NPROD = 6, ID = 0;
+    typedef bf16x8 frag;
+    static constexpr int PU[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};        // smallest terms first
+    __device__ static __forceinline__ unsigned chunk(int row, int p, int hb) { return (unsigned)(p * 32) + ((((unsigned)hb) ^ (unsigned)((row >> 3) & 1)) << 4); }
+    __device__ static __forceinline__ f32x16 mfma(const frag& u, const frag& v, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(u, v, c, 0, 0, 0); }
+};
+struct FmtH2 {
+    static constexpr int NP = 2, ROW = 64, NPROD = 3, ID = 1;
+    typedef f16x8 frag;
+    static constexpr int PU[6] = {1, 0, 0, 0, 0, 0}, PV[6] = {0, 1, 0, 0, 0, 0};
+    __device__ static __forceinline__ unsigned chunk(int row, int p, int hb) { return (((unsigned)(p * 2 + hb)) ^ (unsigned)((row >> 2) & 3)) << 4; }
+    __device__ static __forceinline__ f32x16 mfma(const frag& u, const frag& v, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(u, v, c, 0, 0, 0); }
+};
+
+// the power-of-two scale of a tensor in format H2 from the largest magnitude of its UNtransformed values (0 -> 1)
+__host__ __device__ inline float h2_scale(float amax, float bound)
+{
+    const float t = amax * bound * (1.0f / 32768.0f);
+    if (!(t > 0.f)) return 1.f;
+    int e;
+    const float m = frexpf(t, &e);                  // t = m * 2^e, 0.5 <= m < 1
+    return ldexpf(1.f, m == 0.5f ? e - 1 : e);
+}
 
 constexpr int SB_ROW = 96;                                   // bytes per row and K step
 constexpr int SB_BM = 256, SB_BN = 256;
@@ -246,6 +279,218 @@ void wino_pack_bf3_kernel(const float* __restrict__ w_tf, char* __restrict__ us,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Format H2: the two transforms again, writing two fp16 pieces of value / scale in rows of 64 bytes ([2 planes][16]; the four
+// chunks of a row XORed with bits 2..3 of the row index).  The scale is a power of two derived from max|x| of the UNtransformed
+// tensor (absmax_kernel -> a device word) times the factor by which the transform can grow a value (the squared largest absolute
+// row sum of B^T, resp. G), so that every transformed value / scale is below 2^15: no overflow, and everything above 2^-18 of that
+// keeps 22 mantissa bits.
+template <class S> struct H2Bound {
+    static constexpr float bt()
+    {
+        float m = 0.f;
+        for (int i = 0; i < S::TA; ++i) { float r = 0.f; for (int k = 0; k < S::TA; ++k) r += S::BT(i, k) < 0.f ? -S::BT(i, k) : S::BT(i, k); m = r > m ? r : m; }
+        return m * m;
+    }
+    static constexpr float g()
+    {
+        double m = 0.0;
+        for (int i = 0; i < S::TA; ++i) { double r = 0.0; for (int k = 0; k < S::R; ++k) r += S::G(i, k) < 0.0 ? -S::G(i, k) : S::G(i, k); m = r > m ? r : m; }
+        return (float)(m * m);
+    }
+};
+
+// max |x| over n floats (n % 4 == 0, 16-byte aligned) into *out (bit pattern of a non-negative float: unsigned order = float order;
+// *out must be zero before the launch)
+__global__ __launch_bounds__(256)
+void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ out)
+{
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+__device__ __forceinline__ unsigned h2_word(float a, float b, unsigned& lo)
+{
+    // two scaled values -> the word of their first pieces (return) and of their second pieces (lo)
+    const _Float16 a0 = (_Float16)a, b0 = (_Float16)b;
+    const _Float16 a1 = (_Float16)(a - (float)a0), b1 = (_Float16)(b - (float)b0);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, a1) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+    return (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, b0) << 16);
+}
+
+constexpr int IH_ROW = 64, IH_SEG = IB_TILES * IH_ROW + 32;   // LDS bytes per (xi, K-step group) segment: 512 + 32
+
+template <class S>
+__global__ __launch_bounds__(256)
+void wino_input_h2_kernel(const float* __restrict__ x, char* __restrict__ Vs, const unsigned* __restrict__ amax, int H, int W, int C, int th, int tw,
+                          long long T, unsigned ncb, unsigned nwg, unsigned nblk8, int pad_lo)
+{
+    typedef float vec __attribute__((ext_vector_type(2)));
+    constexpr int A = S::TA;
+    constexpr int NSEG = A * 4, BUF = NSEG * IH_SEG, NCHUNK = NSEG * (IB_TILES * IH_ROW / 16);
+    __shared__ __attribute__((aligned(16))) char xch[2 * BUF];
+    const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
+    if (blk >= nwg) return;
+    const float inv = 1.f / h2_scale(__builtin_bit_cast(float, *amax), H2Bound<S>::bt());
+    const unsigned cb = blk % ncb;
+    const long long tg = blk / ncb;
+    const int tid = threadIdx.x, l32 = tid & 31, tl = tid >> 5;
+    const int c = (int)cb * 64 + l32 * 2;
+    const long long t0 = tg * IB_TILES, t = t0 + tl;
+    const bool live = t < T && c < C;
+    vec tt[A][A];                                              // (B^T d)[i][col]
+    {
+        const long long tc = live ? t : 0;
+        const int tx = (int)(tc % tw), ty = (int)((tc / tw) % th);
+        const long long b = tc / ((long long)tw * th);
+        const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
+        const float* xb = x + ((size_t)b * H * W) * C + (live ? c : 0);
+#pragma unroll
+        for (int col = 0; col < A; ++col) {
+            vec d[A];
+            const int ix = x0 + col;
+#pragma unroll
+            for (int r = 0; r < A; ++r) {
+                const int iy = y0 + r;
+                const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                vec acc = vec(0.f);
+#pragma unroll
+                for (int k = 0; k < A; ++k) {
+                    const float cf = S::BT(i, k);
+                    if (cf != 0.f) acc += cf * d[k];
+                }
+                tt[i][col] = acc;
+            }
+        }
+    }
+    // LDS position of this thread's word of plane q in segment (j = 0, its K-step group): row tl, logical chunk 2 q + (l32 % 8) / 4
+    // XORed with bits 2..3 of the tile index, word l32 % 4
+    const unsigned swz = (unsigned)((t >> 2) & 3);
+    const unsigned wbase = (unsigned)((l32 >> 3) * IH_SEG + tl * IH_ROW) + (unsigned)(l32 & 3) * 4;
+    const unsigned hbit = (unsigned)(l32 >> 2) & 1u;
+    const size_t xi_stride = (size_t)T * C * 4;                // bytes per xi: (C / 16) K steps x T rows x 64
+    const size_t step_stride = (size_t)T * IH_ROW;
+    char* vbase = Vs + ((size_t)cb * 4 * T + t0) * IH_ROW;
+    const int tiles_here = (int)((T - t0) < IB_TILES ? (T - t0) : IB_TILES);
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        char* buf = xch + (i & 1) * BUF;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            vec acc = vec(0.f);
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const float cf = S::BT(j, k);
+                if (cf != 0.f) acc += cf * tt[i][k];
+            }
+            unsigned lo;
+            const unsigned hi = h2_word(acc[0] * inv, acc[1] * inv, lo);
+            *reinterpret_cast<unsigned*>(buf + j * (4 * IH_SEG) + wbase + (((0u + hbit) ^ swz) << 4)) = hi;
+            *reinterpret_cast<unsigned*>(buf + j * (4 * IH_SEG) + wbase + (((2u + hbit) ^ swz) << 4)) = lo;
+        }
+        __syncthreads();
+        for (int q = tid; q < NCHUNK; q += 256) {
+            const int seg = q / 32, r = q - seg * 32;          // segment (j, K-step group), 16-byte chunk of its 512 bytes
+            if (r >= tiles_here * 4) continue;
+            const int j = seg >> 2, sg = seg & 3;
+            if ((int)cb * 4 + sg >= (C >> 4)) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + seg * IH_SEG + r * 16);
+            *reinterpret_cast<u32x4*>(vbase + (size_t)(i * A + j) * xi_stride + sg * step_stride + r * 16) = v;
+        }
+    }
+}
+
+// filter transform in format H2: Us [nxi][Cout/256][Cin/16][256][2][16] fp16 of U / scale; same workgroup shape and LDS exchange
+// as wino_pack_bf3_kernel (64 rows x 64 bytes = 4 KiB contiguous per xi)
+constexpr int PH_PITCH = 80;                                  // 64 + 16
+
+template <class S>
+__global__ __launch_bounds__(256)
+void wino_pack_h2_kernel(const float* __restrict__ w_tf, char* __restrict__ us, const unsigned* __restrict__ amax, int Cin, int Cout, int transposed)
+{
+    constexpr int A = S::TA, R = S::R, NXI = A * A;
+    __shared__ __attribute__((aligned(16))) char xch[PK_XB * PK_CO * PH_PITCH];
+    const float inv = 1.f / h2_scale(__builtin_bit_cast(float, *amax), H2Bound<S>::g());
+    const int ksteps = Cin / 16, nblocks = Cout / 256, cgroups = Cout / PK_CO;
+    const int cg = blockIdx.x % cgroups, s = blockIdx.x / cgroups;
+    const int tid = threadIdx.x, col = tid & 63, kgl = tid >> 6;            // a wave = 64 channels x one group of 4 input channels
+    const int co = cg * PK_CO + col, kg = s * 4 + kgl;
+    float g[R][R][4];
+#pragma unroll
+    for (int p_ = 0; p_ < R; ++p_)
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = kg * 4 + r;
+                g[p_][q][r] = transposed ? w_tf[((size_t)((R - 1 - p_) * R + (R - 1 - q)) * Cout + co) * Cin + c]
+                                         : w_tf[((size_t)(p_ * R + q) * Cin + c) * Cout + co];
+            }
+    double gg[A][R][4];                                     // (G g)[i][q]
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < R; ++p_) acc = __builtin_fma(S::G(i, p_), (double)g[p_][q][r], acc);
+                gg[i][q][r] = acc;
+            }
+    // this thread's 8 bytes of plane q inside its row: logical chunk 2 q + (4 kgl) / 8, XORed with bits 2..3 of the row (= channel within
+    // the 256-block), second half of the chunk for odd kgl
+    const int slot = co & 255, nb = co >> 8;
+    const unsigned swz = (unsigned)((slot >> 2) & 3), hbit = (unsigned)kgl >> 1;
+    const unsigned wbase = (unsigned)(col * PH_PITCH) + (unsigned)(kgl & 1) * 8;
+    const size_t plane = (size_t)nblocks * ksteps * 256 * IH_ROW;                                   // bytes per xi
+    char* ubase = us + (((size_t)nb * ksteps + s) * 256 + (slot - col)) * IH_ROW;
+    constexpr int NB = (NXI + PK_XB - 1) / PK_XB;
+#pragma unroll
+    for (int xb = 0; xb < NB; ++xb) {
+#pragma unroll
+        for (int e = 0; e < PK_XB; ++e) {
+            const int xi = xb * PK_XB + e;
+            if (xi >= NXI) continue;
+            const int i = xi / A, j = xi % A;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc = __builtin_fma(gg[i][q][r], S::G(j, q), acc);
+                o[r] = (float)acc * inv;
+            }
+            uint2 hi, lo;
+            hi.x = h2_word(o[0], o[1], lo.x);
+            hi.y = h2_word(o[2], o[3], lo.y);
+            *reinterpret_cast<uint2*>(xch + e * (PK_CO * PH_PITCH) + wbase + (((0u + hbit) ^ swz) << 4)) = hi;
+            *reinterpret_cast<uint2*>(xch + e * (PK_CO * PH_PITCH) + wbase + (((2u + hbit) ^ swz) << 4)) = lo;
+        }
+        __syncthreads();
+        // 4 xi x 64 rows x 4 chunks of 16 bytes = 1024 chunks: 4 per thread
+        for (int qd = tid; qd < PK_XB * PK_CO * 4; qd += 256) {
+            const int e = qd / (PK_CO * 4), rr = qd - e * (PK_CO * 4);
+            const int xi = xb * PK_XB + e;
+            if (xi >= NXI) continue;
+            const int row = rr / 4, ch = rr - row * 4;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xch + e * (PK_CO * PH_PITCH) + row * PH_PITCH + ch * 16);
+            *reinterpret_cast<u32x4*>(ubase + (size_t)xi * plane + rr * 16) = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 2. the GEMMs  M[xi] = V[xi] (T x Cin) . U[xi] (Cin x Cout) on split operands
 struct Bf3GemmArgs {
     const char* V; const char* U; float* M;
@@ -258,7 +503,10 @@ struct Bf3GemmArgs {
     unsigned v_step_bytes;          // T * 96: one (xi, K step) sub-plane of Vs
     unsigned m_bytes;               // one xi plane of M
     int probe;                      // RN_WINO_BF3_PROBE (timing experiments; results are wrong when set): 1 no DMA in the loop, 2 no stores
+    const unsigned* amax_v; const unsigned* amax_u;   // format H2: bit patterns of max|x| of the two tensors (device), and the factors that
+    float bound_v, bound_u;                           // bound the transformed values by them: scale = 2^ceil(log2(bound * max / 2^15))
 };
+
 
 #define BF3_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -266,14 +514,16 @@ struct Bf3GemmArgs {
 // accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64 = 2 x 2 tiles): the launcher runs ragged row blocks, the
 // items of a last partial round and small batches as half items.
 // TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower, 4: filter gradient)
-template <int WM, int TAG>
+template <class F, int WM, int TAG>
 __global__ __launch_bounds__(512, 2)
 void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename F::frag frag;
+    constexpr int NP = F::NP, SB_ROW = F::ROW, SB_UB = SB_BN * SB_ROW;  // (shadow the file constants: they are format B3's)
     constexpr int WN = 8 / WM, NT2 = 8 / WN;                          // 32-channel MFMA tiles per wave along channels (4 | 2)
-    constexpr int BM = WM * 64, VB = BM * SB_ROW, STAGE = VB + SB_UB;  // V 24 | 12 KiB + U 24 KiB per stage
-    constexpr int VP = VB / 1024;                                     // V DMA pieces per stage (24 | 12); U: 24
+    constexpr int BM = WM * 64, VB = BM * SB_ROW, STAGE = VB + SB_UB;  // B3: V 24 | 12 KiB + U 24 KiB per stage; H2: 16 | 8 + 16
+    constexpr int VP = VB / 1024, UPW = SB_UB / 8192;                 // V DMA pieces per stage (B3 24 | 12, H2 16 | 8); U pieces per wave (3 | 2)
     constexpr int NSTORE = 2 * NT2 * 4;                               // 16-byte stores of a wave's epilogue (32 | 16)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [stage][V BM x 96 | U 256 x 96]
     typedef __attribute__((address_space(3))) void lds_void;
@@ -281,9 +531,13 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hb = lane >> 5;                       // 32x32x16 MFMA: lane = (row / column, k group of 8)
     const int wm = wave / WN, wn = wave % WN;
-    const unsigned sw = (unsigned)((l32 >> 3) & 1);
-    const unsigned vfrag = (unsigned)((wm * 64 + l32) * SB_ROW) + (((unsigned)hb ^ sw) << 4);
-    const unsigned ufrag = (unsigned)(VB + (wn * (NT2 * 32) + l32) * SB_ROW) + (((unsigned)hb ^ sw) << 4);
+    // fragment of plane p: row l32 of the wave's tile (rows of a tile start at multiples of 32: the swizzle bits are l32's)
+    unsigned vfrag[NP], ufrag[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        vfrag[p] = (unsigned)((wm * 64 + l32) * SB_ROW) + F::chunk(l32, p, hb);
+        ufrag[p] = (unsigned)(VB + (wn * (NT2 * 32) + l32) * SB_ROW) + F::chunk(l32, p, hb);
+    }
     const unsigned dma_lane = (unsigned)(wave * 1024 + lane * 16);
     const bool vextra = wave < VP % 8;                                // this wave carries one V piece more than VP / 8 (WM = 2: waves 0..3)
 
@@ -306,8 +560,8 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     };
     // one K step of one item -> LDS stage `buf`: VP / 8 (+1) + 3 wave instructions of 1 KiB per wave.  Rows >= T of a V
     // sub-plane lie beyond its buffer window: zeros (their outputs are never stored).
-    // piece j of a stage's DMAs of this wave: j < NV the V pieces (the last one only on waves that carry it), then the 3 U pieces
-    constexpr int NV = (VP + 7) / 8, NPIECE = NV + 3;
+    // piece j of a stage's DMAs of this wave: j < NV the V pieces (the last one only on waves that carry it), then the UPW U pieces
+    constexpr int NV = (VP + 7) / 8, NPIECE = NV + UPW;
     auto issue_piece = [&](const Item& it, int s, int buf, int j) {
         char* sb = smem + buf * STAGE;
         if (j < NV) {
@@ -328,7 +582,11 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     // wait until all but the newest stage's DMAs of this wave (and, behind an item's end, its NSTORE stores) have landed, then the barrier
     auto wait_stage = [&](bool issued, bool after_store) {
         if (!issued) { BF3_WAIT_BARRIER(0); return; }
-        if constexpr (WM == 4) {
+        if constexpr (F::ID == 1) {                                   // H2: 2 + 2 | 1 + 2 DMAs per stage and wave, no uneven V share
+            static_assert(VP % 8 == 0, "format H2: every wave carries the same number of V pieces");
+            if constexpr (WM == 4) { if (after_store) BF3_WAIT_BARRIER(36); else BF3_WAIT_BARRIER(4); }
+            else                   { if (after_store) BF3_WAIT_BARRIER(19); else BF3_WAIT_BARRIER(3); }
+        } else if constexpr (WM == 4) {
             if (after_store) BF3_WAIT_BARRIER(38); else BF3_WAIT_BARRIER(6);
         } else {
             if (vextra) { if (after_store) BF3_WAIT_BARRIER(21); else BF3_WAIT_BARRIER(5); }
@@ -337,25 +595,24 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     };
 
     f32x16 acc[2][NT2];
-    auto ldv = [&](const char* sb, int mt, bf16x8 (&v)[3]) {
+    auto ldv = [&](const char* sb, int mt, frag (&v)[NP]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const bf16x8*>(sb + vfrag + mt * (32 * SB_ROW) + p * 32);
+        for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const frag*>(sb + vfrag[p] + mt * (32 * SB_ROW));
     };
-    auto ldu = [&](const char* sb, int nt, bf16x8 (&u)[3]) {
+    auto ldu = [&](const char* sb, int nt, frag (&u)[NP]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) u[p] = *reinterpret_cast<const bf16x8*>(sb + ufrag + nt * (32 * SB_ROW) + p * 32);
+        for (int p = 0; p < NP; ++p) u[p] = *reinterpret_cast<const frag*>(sb + ufrag[p] + nt * (32 * SB_ROW));
     };
-    // one 32 x 32 tile and K step: the six piece products with i + j <= 2, smallest terms first
-    auto grp = [&](const bf16x8 (&v)[3], const bf16x8 (&u)[3], f32x16& c) {
-        constexpr int PU[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};
+    // one 32 x 32 tile and K step: the piece products of the format (B3: the six with i + j <= 2; H2: three), smallest terms first
+    auto grp = [&](const frag (&v)[NP], const frag (&u)[NP], f32x16& c) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[PU[k]], v[PV[k]], c, 0, 0, 0);
+        for (int k = 0; k < F::NPROD; ++k) c = F::mfma(u[F::PU[k]], v[F::PV[k]], c);
     };
 
     Item cur, nxt;
     if (!decode(0, cur)) return;
     bool have_next = decode(1, nxt);
-    bf16x8 x0[3], x1[3], ua[3], ub[3];
+    frag x0[NP], x1[NP], ua[NP], ub[NP];
     issue(cur, 0, 0);
     issue(cur, 1, 1);
     wait_stage(true, false);
@@ -370,7 +627,7 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
     // last group); v1 is free.  Before the last group the next stage is waited for (counted: the stage after it stays in
     // flight), the barrier says every wave has finished reading this stage, and the next step's first operands are read into
     // the two sets that have just become free -- the next step runs with the roles of v0 / v1 swapped.
-    auto step = [&](int s, bf16x8 (&v0)[3], bf16x8 (&v1)[3]) {
+    auto step = [&](int s, frag (&v0)[NP], frag (&v1)[NP]) {
         const char* sb = smem + buf * STAGE;
         const int bn = buf == SB_NSTAGE - 1 ? 0 : buf + 1;
         const int b2 = bn == SB_NSTAGE - 1 ? 0 : bn + 1;
@@ -433,6 +690,13 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
         // D (32 x 32) = U-tile (rows: channels) x V-tile (cols: tile rows): register r of lane (l32, hb) is channel
         // (r & 3) + 8*(r >> 2) + 4*hb of the 32-channel tile, tile row l32 -> four 16-byte stores per MFMA tile
         if (!(a.probe & 2)) {
+            if constexpr (F::ID == 1) {                               // H2: back to the scale of the fp32 operands (powers of two: exact)
+                const float sc = h2_scale(__builtin_bit_cast(float, *a.amax_v), a.bound_v) * h2_scale(__builtin_bit_cast(float, *a.amax_u), a.bound_u);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) acc[mt][nt] *= sc;
+            }
             const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
             const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + l32) * a.Cout + cur.nb * SB_BN + wn * (NT2 * 32) + hb * 4) * 4);
 #pragma unroll
@@ -456,30 +720,73 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// `scheme` of the entry points below = Winograd scheme | operand format << 8 (RN_SPLIT_FMT_H2 = 0x100: two fp16 pieces of the scaled
+// value, three products; 0: three bf16 pieces, six products).
+namespace {
+inline int fmt_of(int scheme) { return (scheme >> 8) & 0xff; }
+inline int sch_of(int scheme) { return scheme & 0xff; }
+inline size_t h2_u_data(int sch, int Cin, int Cout) { return (size_t)rn_wino_scheme_nxi(sch) * Cin * Cout * 4; }
+inline size_t h2_v_data(int sch, long long T, int Cin) { return ((size_t)rn_wino_scheme_nxi(sch) * T * Cin * 4 + 255) / 256 * 256; }
+inline float h2_bound_v(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>::bt() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::bt() : H2Bound<WinoF63>::bt(); }
+inline float h2_bound_u(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>::g() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::g() : H2Bound<WinoF63>::g(); }
+
+// *out = bit pattern of max |x| over n floats (n % 4 == 0)
+int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
+{
+    if (n % 4 != 0) return rn_set_error(RN_E_INVALID, "absmax: %zu floats", n);
+    if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "absmax: memset failed");
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, out);
+    return rn_check_launch("absmax");
+}
+}  // namespace
+
 bool rn_wino_bf3_supported(int scheme, int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD_BF3") != nullptr;
-    return !off && rn_wino43_supported(scheme, Cin, Cout);
+    return !off && fmt_of(scheme) <= 1 && rn_wino43_supported(sch_of(scheme), Cin, Cout);
 }
 
-size_t rn_wino_bf3_packed_bytes(int scheme, int Cin, int Cout) { return (size_t)rn_wino_scheme_nxi(scheme) * Cin * Cout * 6; }
+// B3: 6 bytes per element.  H2: 4 bytes per element + a 256-byte tail whose first word is max|w| (bit pattern) of the filter.
+size_t rn_wino_bf3_packed_bytes(int scheme, int Cin, int Cout)
+{
+    if (fmt_of(scheme) == 1) return h2_u_data(sch_of(scheme), Cin, Cout) + 256;
+    return (size_t)rn_wino_scheme_nxi(scheme) * Cin * Cout * 6;
+}
 
-// workspace: Vs (nxi * T * Cin * 6 bytes, rounded up to 256) followed by M (nxi * T * Cout floats)
-size_t rn_wino_bf3_v_bytes(int scheme, long long T, int Cin) { return ((size_t)rn_wino_scheme_nxi(scheme) * T * Cin * 6 + 255) / 256 * 256; }
+// workspace: Vs (B3: nxi * T * Cin * 6 bytes, rounded up to 256; H2: ... * 4 + a 256-byte tail holding max|x|) followed by M (nxi * T * Cout floats)
+size_t rn_wino_bf3_v_bytes(int scheme, long long T, int Cin)
+{
+    if (fmt_of(scheme) == 1) return h2_v_data(sch_of(scheme), T, Cin) + 256;
+    return ((size_t)rn_wino_scheme_nxi(scheme) * T * Cin * 6 + 255) / 256 * 256;
+}
 
 size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)
 {
-    const int m = rn_wino_scheme_m(scheme);
+    const int m = rn_wino_scheme_m(sch_of(scheme));
     if (m == 0) return 0;
     const long long T = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
-    return rn_wino_bf3_v_bytes(scheme, T, Cin) + (size_t)rn_wino_scheme_nxi(scheme) * T * Cout * 4;
+    return rn_wino_bf3_v_bytes(scheme, T, Cin) + (size_t)rn_wino_scheme_nxi(sch_of(scheme)) * T * Cout * 4;
 }
 
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st)
 {
-    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_pack_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_pack_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    const int fmt = fmt_of(scheme);
+    scheme = sch_of(scheme);
     const unsigned nbw = (unsigned)((Cout / PK_CO) * (Cin / 16));
     char* u = static_cast<char*>(us);
+    if (fmt == 1) {
+        unsigned* amax = reinterpret_cast<unsigned*>(u + h2_u_data(scheme, Cin, Cout));
+        const int R = scheme == RN_WINO_F44 ? 4 : 3;
+        const int rc = launch_absmax(w_tf, (size_t)R * R * Cin * Cout, amax, st);
+        if (rc != RN_OK) return rc;
+        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
+        else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
+        else hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF63>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
+        return rn_check_launch("wino_pack_h2");
+    }
     if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF63>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
@@ -488,6 +795,8 @@ int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, in
 
 int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, hipStream_t st)
 {
+    const int fmt = fmt_of(scheme);
+    scheme = sch_of(scheme);
     const int m = rn_wino_scheme_m(scheme);
     if (m == 0 || C % 16 != 0) return rn_set_error(RN_E_INVALID, "wino_input_bf3: scheme %d, C %d", scheme, C);
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
@@ -497,6 +806,18 @@ int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H,
     if (n > 0x7fffff00ULL) return rn_set_error(RN_E_UNSUPPORTED, "wino_input_bf3: grid too large");
     const unsigned nwg = (unsigned)n, nblk8 = (unsigned)((n + 7) / 8 * 8);
     char* v = static_cast<char*>(Vs);
+    if (fmt == 1) {
+        unsigned* amax = reinterpret_cast<unsigned*>(v + h2_v_data(scheme, T, C));
+        const int rc = launch_absmax(x, (size_t)B * H * W * C, amax, st);
+        if (rc != RN_OK) return rc;
+        if (scheme == RN_WINO_F43)
+            hipLaunchKernelGGL((wino_input_h2_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        else if (scheme == RN_WINO_F44)
+            hipLaunchKernelGGL((wino_input_h2_kernel<WinoF44>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        else
+            hipLaunchKernelGGL((wino_input_h2_kernel<WinoF63>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        return rn_check_launch("wino_input_h2");
+    }
     if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
     else if (scheme == RN_WINO_F44)
@@ -507,41 +828,46 @@ int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H,
 }
 
 // items [begin, end) of the block range the args name, `parts` BM-row parts of each (0: all 4 / WM of them)
-template <int WM, int TAG>
+template <class F, int WM, int TAG>
 static int wino_gemm_bf3_launch_t(Bf3GemmArgs a, int begin, int end, int parts, hipStream_t st)
 {
     a.item_begin = begin; a.item_end = end; a.parts = parts > 0 ? parts : 4 / WM;
-    const size_t lds = (size_t)SB_NSTAGE * (WM * 64 * SB_ROW + SB_UB);
-    auto kern = wino_gemm_bf3_kernel<WM, TAG>;
+    const size_t lds = (size_t)SB_NSTAGE * (WM * 64 * F::ROW + SB_BN * F::ROW);
+    auto kern = wino_gemm_bf3_kernel<F, WM, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
     const int n = (end - begin) * a.parts;
     hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
     return rn_check_launch("wino_gemm_bf3");
 }
 
-template <int WM>
+template <class F, int WM>
 static int wino_gemm_bf3_launch_w(int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
 {
     switch (tag) {
-    case 0: return wino_gemm_bf3_launch_t<WM, 0>(a, begin, end, parts, st);
-    case 1: return wino_gemm_bf3_launch_t<WM, 1>(a, begin, end, parts, st);
-    case 2: return wino_gemm_bf3_launch_t<WM, 2>(a, begin, end, parts, st);
-    case 4: return wino_gemm_bf3_launch_t<WM, 4>(a, begin, end, parts, st);
-    default: return wino_gemm_bf3_launch_t<WM, 3>(a, begin, end, parts, st);
+    case 0: return wino_gemm_bf3_launch_t<F, WM, 0>(a, begin, end, parts, st);
+    case 1: return wino_gemm_bf3_launch_t<F, WM, 1>(a, begin, end, parts, st);
+    case 2: return wino_gemm_bf3_launch_t<F, WM, 2>(a, begin, end, parts, st);
+    case 4: return wino_gemm_bf3_launch_t<F, WM, 4>(a, begin, end, parts, st);
+    default: return wino_gemm_bf3_launch_t<F, WM, 3>(a, begin, end, parts, st);
     }
 }
 
-static int wino_gemm_bf3_launch(int wm, int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
+static int wino_gemm_bf3_launch(int fmt, int wm, int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
 {
-    return wm == 4 ? wino_gemm_bf3_launch_w<4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<2>(tag, a, begin, end, parts, st);
+    if (fmt == 1) return wm == 4 ? wino_gemm_bf3_launch_w<FmtH2, 4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<FmtH2, 2>(tag, a, begin, end, parts, st);
+    return wm == 4 ? wino_gemm_bf3_launch_w<FmtB3, 4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<FmtB3, 2>(tag, a, begin, end, parts, st);
 }
 
 // nxi independent GEMMs  M[p] (T x Cout) = V[p] (T x Cin) . U[p] (Cin x Cout) on split operands:
 //   V [nxi][Cin/16][T][3][16], U [nxi][Cout/256][Cin/16][256][3][16], M [nxi][T][Cout] fp32; Cin % 16 == 0, Cout % 256 == 0.
 // The forward path calls it with (tiles, input channels, output channels); the filter gradient (conv_wino_bf3_wgrad.hip) with
 // (input channels, tiles of one K split, output channels) and nxi = planes x K splits.
-int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
+// fmt 0: B3 (rows of 96 bytes); fmt 1: H2 (rows of 64 bytes; amax_v / amax_u = device words holding the bit patterns of max|x| of the
+// two untransformed tensors, bound_v / bound_u the factors by which the transforms can grow them: the kernel derives the two scales).
+static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout,
+                             const unsigned* amax_v, const unsigned* amax_u, float bound_v, float bound_u, hipStream_t st)
 {
+    const int SB_ROW = fmt == 1 ? FmtH2::ROW : FmtB3::ROW;
     if (nxi < 1 || Cin < 16 || Cin % 16 != 0 || Cout < SB_BN || Cout % SB_BN != 0)
         return rn_set_error(RN_E_UNSUPPORTED, "gemm_bf3: planes=%d K=%d N=%d", nxi, Cin, Cout);
     if (T < 1 || (T + SB_BM) * (long long)Cout * 4 >= 0xffffff00LL || T * (long long)Cout * 4 >= 0x7fffff00LL || (T + SB_BM) * (long long)SB_ROW >= 0x7fffff00LL)
@@ -551,6 +877,7 @@ int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, 
     a.nblocks = Cout / SB_BN; a.ksteps = Cin / 16;
     a.v_step_bytes = (unsigned)(T * SB_ROW); a.m_bytes = (unsigned)(T * Cout * 4);
     { static const int probe = getenv("RN_WINO_BF3_PROBE") ? atoi(getenv("RN_WINO_BF3_PROBE")) : 0; a.probe = probe; }
+    a.amax_v = amax_v; a.amax_u = amax_u; a.bound_v = bound_v; a.bound_u = bound_u;
     static const bool notail = getenv("RN_WINO_BF3_NOTAIL") != nullptr;
     const int full = (int)(T / SB_BM), ragged = (int)(T % SB_BM);    // whole 256-row blocks; rows of the last, partial one
     if ((long long)nxi * (full + 1) * a.nblocks * 2 > 0x3fffffff) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: too many items");
@@ -576,7 +903,7 @@ int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, 
         const int ucost = (int)((items + 255) / 256);
         if (ucost <= cost_split) {
             a.mb_begin = 0; a.mrows = 128; a.mblocks = (int)((T + 127) / 128);
-            return wino_gemm_bf3_launch(2, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
+            return wino_gemm_bf3_launch(fmt, 2, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
         }
     }
     if (full > 0) {
@@ -586,11 +913,11 @@ int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, 
         const bool half_tail = !notail && rem != 0 && tail_cost(rem) < 2;       // the last, partial round as half items: half a round
         const int tail = half_tail ? rem : 0;
         if (nitems - tail > 0) {
-            const int rc = wino_gemm_bf3_launch(4, tag, a, 0, nitems - tail, 0, st);
+            const int rc = wino_gemm_bf3_launch(fmt, 4, tag, a, 0, nitems - tail, 0, st);
             if (rc != RN_OK) return rc;
         }
         if (tail > 0) {
-            const int rc = wino_gemm_bf3_launch(2, tag, a, nitems - tail, nitems, 0, st);
+            const int rc = wino_gemm_bf3_launch(fmt, 2, tag, a, nitems - tail, nitems, 0, st);
             if (rc != RN_OK) return rc;
         }
     }
@@ -598,15 +925,27 @@ int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, 
         a.mb_begin = full; a.mblocks = 1;
         int wm, parts;
         ragged_plan(wm, parts);
-        return wino_gemm_bf3_launch(wm, tag, a, 0, nxi * a.nblocks, parts, st);
+        return wino_gemm_bf3_launch(fmt, wm, tag, a, 0, nxi * a.nblocks, parts, st);
     }
     return RN_OK;
 }
 
+int rn_launch_gemm_bf3_planes(int nxi, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
+{
+    return gemm_split_planes(0, nxi, tag, Vs, us, M, T, Cin, Cout, nullptr, nullptr, 1.f, 1.f, st);
+}
+
 int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st)
 {
-    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    const int fmt = fmt_of(scheme);
+    scheme = sch_of(scheme);
     const int tag = scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
+    if (fmt == 1) {
+        const unsigned* av = reinterpret_cast<const unsigned*>(static_cast<const char*>(Vs) + h2_v_data(scheme, T, Cin));
+        const unsigned* au = reinterpret_cast<const unsigned*>(static_cast<const char*>(us) + h2_u_data(scheme, Cin, Cout));
+        return gemm_split_planes(1, rn_wino_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, av, au, h2_bound_v(scheme), h2_bound_u(scheme), st);
+    }
     return rn_launch_gemm_bf3_planes(rn_wino_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, st);
 }
 
@@ -614,8 +953,8 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
 int rn_launch_conv_wino_bf3(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
                             float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st)
 {
-    if (!rn_wino43_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
-    const int m = rn_wino_scheme_m(scheme);
+    if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    const int m = rn_wino_scheme_m(sch_of(scheme));
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;
@@ -639,5 +978,5 @@ int rn_launch_conv_wino_bf3(int scheme, const float* x, const void* us, const fl
     if (rc != RN_OK) return rc;
     rc = rn_launch_wino_gemm_bf3(scheme, Vs, us, M, T, Cin, Cout, st);
     if (rc != RN_OK) return rc;
-    return rn_launch_wino_output(scheme, M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
+    return rn_launch_wino_output(sch_of(scheme), M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
 }

@@ -51,7 +51,7 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None,
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None, "wino43h": None, "wino63h": None,
                      "wino3ds": None}
         self._dirty = {k: True for k in self._buf}
         self._packed_on = {}              # form -> (stream, event recorded behind its last pack kernel)
@@ -93,8 +93,8 @@ class PackedWeight:
                 L.check(lib.rn_conv3d_winograd_split_pack(L.ptr(self.w_tf), ctypes.c_void_p(self._buf[which].data_ptr()), self.cin, self.cout,
                                                           1 if self.kind == L.RN_PACK_CONVT_S1 else 0, L.stream_ptr()),
                         "rn_conv3d_winograd_split_pack")
-            elif which.endswith("s"):
-                # the bf16x3 split form of the three-launch path (csrc/conv_wino_bf3.hip): `kind` is the scheme here
+            elif which.endswith("s") or which.endswith("h"):
+                # a split form of the three-launch path (csrc/conv_wino_bf3.hip): `kind` is the scheme (| the operand format flag) here
                 if self._buf[which] is None:
                     n = lib.rn_winograd_split_packed_bytes(kind, self.cin, self.cout)
                     if n == 0:
@@ -174,13 +174,15 @@ class PackedWeight:
             raise ValueError("the F(6x6,3x3) Winograd pack can only be switched off (set to None)")
         self._wino63_kind = None
 
-    def split(self, which):
-        """The bf16x3 split form (uint8 buffer) of scheme `which` ("f43" | "f44" | "f63") for the split GEMM stage, or None."""
+    def split(self, which, fmt=0):
+        """The split form (uint8 buffer) of scheme `which` ("f43" | "f44" | "f63") for the split GEMM stage, or None.  fmt: 0 = three
+        bf16 pieces, L.RN_SPLIT_FMT_H2 = two fp16 pieces of the scaled value."""
+        sfx = "h" if fmt else "s"
         if which == "f63":
-            return None if self._wino63_kind is None else self._packed("wino63s", L.RN_WINO_F63)
+            return None if self._wino63_kind is None else self._packed("wino63" + sfx, L.RN_WINO_F63 | fmt)
         if self._wino43_kind is None:
             return None
-        return self._packed("wino43s", L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43)
+        return self._packed("wino43" + sfx, (L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43) | fmt)
 
     def split3d(self):
         """The bf16x3 split form of a 3x3x3 32 -> 32 filter for rn_conv3d_winograd_split_fwd (uint8 buffer), or None."""
@@ -488,6 +490,8 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
 # Multiply stage of the three-launch path: "f32" = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = the same products on
 # the 16x faster bf16 pipe with every fp32 operand as three bf16 pieces and six piece products, fp32 accumulation
 # (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
+# "split16": the same stage with every operand as TWO fp16 pieces of value / (power-of-two scale of its tensor) and three products --
+# half the matrix work of "split"; 22-bit operands, fp32 accumulation (the accumulation error, which all three modes share, dominates).
 WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
 # The fused 3x3x3 32 -> 32 kernel of the 3-D encoder has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip: 0.50 ms against 0.82 ms on
 # the B = 24 64x64x32 layer, error 2.4e-7 .. 3.8e-7 of max|y| against the fp32 kernel's 3.2e-7 .. 4.9e-7).  None: it follows
@@ -504,7 +508,7 @@ def _conv3d_split(B=None, H=None, W=None):
     three quarters of a round of 256 workgroups the fp32 kernel's finer items win (B = 1: 6.07 against 6.86 ms per frame)."""
     if CONV3D_SPLIT is not None:
         return bool(CONV3D_SPLIT)
-    return WINO_GEMM == "split" and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)
+    return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)
 
 
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
@@ -515,8 +519,10 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
     T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
     scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
     st = L.stream_ptr()
-    if WINO_GEMM == "split" and lib.rn_winograd_split_supported(scheme, Cin, Cout):
-        us = ctypes.c_void_p(pw.split(which).data_ptr())
+    if WINO_GEMM in ("split", "split16") and lib.rn_winograd_split_supported(scheme, Cin, Cout):
+        fmt = L.RN_SPLIT_FMT_H2 if WINO_GEMM == "split16" else 0
+        us = ctypes.c_void_p(pw.split(which, fmt).data_ptr())
+        scheme |= fmt
         ws = torch.empty(lib.rn_winograd_split_workspace_bytes(scheme, B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
         wsp = ctypes.c_void_p(ws.data_ptr())
         ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
@@ -531,7 +537,7 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
         ev[1].record()
         if rc != 0:
             return rc
-        return lib.rn_winograd_output_transform(scheme, M, *e, B, H, W, Cout, act, st)
+        return lib.rn_winograd_output_transform(scheme & 0xff, M, *e, B, H, W, Cout, act, st)
     u = pw.wino63 if f63 else pw.wino43
     n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino63_workspace_floats if f63
          else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
@@ -660,7 +666,7 @@ class _Conv(torch.autograd.Function):
             rc = 0
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
-        elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and WINO_GEMM == "split" and WGRAD_SPLIT
+        elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and WINO_GEMM in ("split", "split16") and WGRAD_SPLIT
               and max(Cin, pw.cout) >= 1024              # measured at crop 64: 1024 -> 1024 1.10 -> 0.79 ms, 1024 -> 512 (4x4) 0.92 -> 0.65; 512 -> 512: no gain
               and lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44, Cin, pw.cout)):
             # the reduction over the tiles on the bf16 pipe (csrc/conv_wino_bf3_wgrad.hip)

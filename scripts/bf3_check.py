@@ -30,7 +30,7 @@ def accuracy(B, hw, cin, cout, k, seed=0, forced=None):
     ymax = float(want.abs().max())
     xd, wd = torch.as_tensor(x).cuda(), torch.as_tensor(w).cuda()
     out = {}
-    for mode in ("f32", "split"):
+    for mode in ("f32", "split", "split16"):
         ops.WINO_GEMM = mode
         pw = ops.pack_conv(wd)
         if forced:
@@ -40,8 +40,8 @@ def accuracy(B, hw, cin, cout, k, seed=0, forced=None):
         out[mode] = float((y.cpu().double() - want).abs().max()) / ymax
         out[mode + "_y"] = y
     d = float((out["f32_y"] - out["split_y"]).abs().max()) / ymax
-    print("B=%d %dx%d %d->%d k%d %s: f32 %.2e  split %.2e  |f32-split| %.2e  (x max|y| = %.3g)"
-          % (B, hw, hw, cin, cout, k, forced or ops._wino_scheme(pw, hw, hw), out["f32"], out["split"], d, ymax), flush=True)
+    print("B=%d %dx%d %d->%d k%d %s: f32 %.2e  split (bf16x3) %.2e  split16 (fp16x2) %.2e  |f32-split| %.2e  (x max|y| = %.3g)"
+          % (B, hw, hw, cin, cout, k, forced or ops._wino_scheme(pw, hw, hw), out["f32"], out["split"], out["split16"], d, ymax), flush=True)
     ops.WINO_GEMM = "f32"
     return out["f32"], out["split"]
 
@@ -59,7 +59,7 @@ def timing(B, hw, cin, cout, k, iters, forced=None):
     st = L.stream_ptr()
     y = torch.empty((B, hw, hw, cout), device="cuda")
     res = {}
-    for mode in ("f32", "split"):
+    for mode in ("f32", "split", "split16"):
         if mode == "f32":
             u = pw.wino63 if which == "f63" else pw.wino43
             ws = torch.empty(nxi * T * (cin + cout), device="cuda")
@@ -70,14 +70,16 @@ def timing(B, hw, cin, cout, k, iters, forced=None):
                 lambda: L.check(lib.rn_winograd_output_transform(scheme, M, L.ptr(b), None, None, L.ptr(y), None, B, hw, hw, cout, 0, st), "output"),
             ]
         else:
-            us = ctypes.c_void_p(pw.split(which).data_ptr())
-            ws = torch.empty(lib.rn_winograd_split_workspace_bytes(scheme, B, hw, hw, cin, cout), dtype=torch.uint8, device="cuda")
+            fmt = L.RN_SPLIT_FMT_H2 if mode == "split16" else 0
+            sf = scheme | fmt
+            us = ctypes.c_void_p(pw.split(which, fmt).data_ptr())
+            ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sf, B, hw, hw, cin, cout), dtype=torch.uint8, device="cuda")
             V = ctypes.c_void_p(ws.data_ptr())
-            M = ctypes.c_void_p(ws.data_ptr() + lib.rn_winograd_split_v_bytes(scheme, T, cin))
+            M = ctypes.c_void_p(ws.data_ptr() + lib.rn_winograd_split_v_bytes(sf, T, cin))
             stages = [
-                lambda: L.check(lib.rn_winograd_split_input_transform(scheme, L.ptr(x), V, B, hw, hw, cin, 1, st), "input"),
-                lambda: L.check(lib.rn_winograd_split_gemm(scheme, V, us, M, T, cin, cout, st), "gemm"),
-                lambda: L.check(lib.rn_winograd_output_transform(scheme, M, L.ptr(b), None, None, L.ptr(y), None, B, hw, hw, cout, 0, st), "output"),
+                lambda sf=sf, V=V: L.check(lib.rn_winograd_split_input_transform(sf, L.ptr(x), V, B, hw, hw, cin, 1, st), "input"),
+                lambda sf=sf, V=V, us=us, M=M: L.check(lib.rn_winograd_split_gemm(sf, V, us, M, T, cin, cout, st), "gemm"),
+                lambda M=M: L.check(lib.rn_winograd_output_transform(scheme, M, L.ptr(b), None, None, L.ptr(y), None, B, hw, hw, cout, 0, st), "output"),
             ]
         for f in stages * 2:
             f()
@@ -96,8 +98,10 @@ def timing(B, hw, cin, cout, k, iters, forced=None):
             print("  %-5s input %.3f ms  gemm %.3f ms (%.1f TFLOP/s fp32-equivalent, %.3f of the fp32 MFMA peak)  output %.3f ms  total %.3f ms"
                   % (mode, best[0], best[1], fl / best[1] / 1e9, fl / best[1] / 1e9 / 157.3, best[2], sum(best)), flush=True)
         else:
-            print("  %-5s input %.3f ms  gemm %.3f ms (%.1f TFLOP/s fp32-equivalent; 6 bf16 products: %.0f TFLOP/s = %.3f of the bf16 peak)  output %.3f ms  total %.3f ms"
-                  % (mode, best[0], best[1], fl / best[1] / 1e9, 6 * fl / best[1] / 1e9, 6 * fl / best[1] / 1e9 / 2500.0, best[2], sum(best)), flush=True)
+            npr = 3 if mode == "split16" else 6
+            print("  %-7s input %.3f ms  gemm %.3f ms (%.1f TFLOP/s fp32-equivalent; %d %s products: %.0f TFLOP/s = %.3f of the 16-bit peak)  output %.3f ms  total %.3f ms"
+                  % (mode, best[0], best[1], fl / best[1] / 1e9, npr, "fp16" if npr == 3 else "bf16", npr * fl / best[1] / 1e9,
+                     npr * fl / best[1] / 1e9 / 2500.0, best[2], sum(best)), flush=True)
         res[mode] = best
     return res
 

@@ -10,7 +10,7 @@ import torch
 
 from rendernet_amd import ops
 
-SCHEMES = ("direct", "f22", "f43", "f63", "f43s", "f63s")      # ...s: the split (bf16x3) GEMM stage of the same scheme
+SCHEMES = ("direct", "f22", "f43", "f63", "f43s", "f63s", "f43h", "f63h")      # ...s: the split (bf16x3) GEMM stage of the same scheme; ...h: fp16x2
 
 
 def xavier(rng, shape):
@@ -40,7 +40,7 @@ def hostile_inputs(rng, B, H, W, Cin, Cout):
 def conv_with_scheme(x, w, b, scheme, alpha=None, residual=None):
     """x [B,H,W,Cin], w [3,3,Cin,Cout] HIP tensors -> conv through the kernel family `scheme` forces."""
     pw = ops.pack_conv(w)
-    split = scheme.endswith("s")
+    split = {"s": "split", "h": "split16"}.get(scheme[-1]) if scheme[-1] in "sh" and scheme[:-1] in ("f43", "f63") else None
     if split:
         scheme = scheme[:-1]
     if scheme == "direct":
@@ -58,7 +58,7 @@ def conv_with_scheme(x, w, b, scheme, alpha=None, residual=None):
     else:
         raise ValueError(scheme)
     old = ops.WINO_GEMM
-    ops.WINO_GEMM = "split" if split else "f32"
+    ops.WINO_GEMM = split or "f32"
     try:
         with torch.no_grad():
             return ops.conv2d(x, pw, b, alpha, residual)

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from scripts import robust_util as RU
 
 pytestmark = pytest.mark.gpu
-BAR = {"direct": 3e-5, "f22": 3e-5, "f43": 3e-5, "f63": 1e-4, "f43s": 3e-5, "f63s": 1e-4}      # the split stage: the SAME bars
+BAR = {"direct": 3e-5, "f22": 3e-5, "f43": 3e-5, "f63": 1e-4, "f43s": 3e-5, "f63s": 1e-4, "f43h": 3e-5, "f63h": 1e-4}      # the split stages: the SAME bars
 C = 1024
 
 

@@ -110,13 +110,16 @@ CASES = [   # (which, B, H, W, Cin, Cout): ragged planes, 1 .. many tiles (below
 ]
 
 
+@pytest.mark.parametrize("smode", ["split", "split16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv2d_split_vs_oracle(case):
-    """ops.conv2d with ops.WINO_GEMM = "split" vs the oracle conv (bias / PReLU / residual / pre-activation / sigmoid
-    epilogues), vs the exact-fp32 route on the same filter, and the input gradient through the transposed pack."""
+def test_conv2d_split_vs_oracle(case, smode):
+    """ops.conv2d with ops.WINO_GEMM = "split" (three bf16 pieces, six products) and "split16" (two fp16 pieces of the scaled value,
+    three products) vs the oracle conv (bias / PReLU / residual / pre-activation / sigmoid epilogues), vs the exact-fp32 route on
+    the same filter, and the input gradient through the transposed pack."""
     from rendernet_amd import ops
     from rendernet_amd import _lib as L
     which, B, H, W, Cin, Cout = case
+    fmt = L.RN_SPLIT_FMT_H2 if smode == "split16" else 0
     sid, nxi, m, R = SCHEMES[which]
     rng = np.random.default_rng(hash(case) % 2**31)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
@@ -129,14 +132,14 @@ def test_conv2d_split_vs_oracle(case):
         y0 = OL.conv2d(x, w, b, (1, 1))
         res = rng.standard_normal(y0.shape).astype(np.float32)
         outs = {}
-        for mode in ("f32", "split"):
+        for mode in ("f32", smode):
             ops.WINO_GEMM = mode
             pw = ops.pack_conv(_dev(w))
             if which != "f44":
                 pw.force_scheme = which
             with torch.no_grad():
-                outs[mode] = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
-                if mode == "split":
+                outs["split" if mode == smode else mode] = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
+                if mode == smode:
                     _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "split %s" % which)
                     _close(ops.conv2d(_dev(x), pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "split+sigmoid")
         _close(outs["split"], OL.prelu(y0, alpha) + torch.from_numpy(res), "split %s +prelu+res" % which)
@@ -144,10 +147,10 @@ def test_conv2d_split_vs_oracle(case):
         assert not torch.equal(outs["split"], outs["f32"]) or Cin * H * W < 64       # (a different summation, not the same bits)
         # the C entry with the pre-activation output
         lib = L.lib()
-        ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sid, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sid | fmt, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
         yy, zz = torch.empty(y0.shape, device="cuda"), torch.empty(y0.shape, device="cuda")
         xd, bd, ad = _dev(x), _dev(b), _dev(alpha)
-        L.check(lib.rn_conv2d_winograd_split_fwd(sid, L.ptr(xd), ctypes.c_void_p(pw.split(which).data_ptr()), L.ptr(bd),
+        L.check(lib.rn_conv2d_winograd_split_fwd(sid | fmt, L.ptr(xd), ctypes.c_void_p(pw.split(which, fmt).data_ptr()), L.ptr(bd),
                                                  L.ptr(ad), None, L.ptr(yy), L.ptr(zz), ctypes.c_void_p(ws.data_ptr()),
                                                  B, H, W, Cin, Cout, 0, 1, L.stream_ptr()), "rn_conv2d_winograd_split_fwd")
         _close(zz, y0, "split preact")
@@ -158,7 +161,7 @@ def test_conv2d_split_vs_oracle(case):
             dx = torch.empty((B, H, W, Cin), device="cuda")
             if which != "f44":
                 dp.force_scheme = which
-            ops.WINO_GEMM = "split"
+            ops.WINO_GEMM = smode
             dzd = _dev(dz)
             L.check(ops._wino43_fwd(dzd, dp, (None, None, None, L.ptr(dx), None), B, H, W, Cout, Cin, 0), "split dgrad")
             _close(dx, OL.conv2d_transpose(dz, w, None, (1, 1)), "split dgrad vs oracle")
@@ -166,7 +169,8 @@ def test_conv2d_split_vs_oracle(case):
         ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
 
 
-def test_conv2d_transpose_s1_split():
+@pytest.mark.parametrize("smode", ["split", "split16"])
+def test_conv2d_transpose_s1_split(smode):
     """e_conv7_1-like stride-1 transposed 4x4 conv (slim.conv2d_transpose, RenderNet_Shader.py:109-111) through F(4x4,4x4) on
     the split stage (pad two before)."""
     from rendernet_amd import ops
@@ -176,7 +180,7 @@ def test_conv2d_transpose_s1_split():
     wt = _xavier(rng, (4, 4, Cout, Cin))
     b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
     old_min, old_mode = ops.WINO43_MIN_PIXELS, ops.WINO_GEMM
-    ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = 1, "split"
+    ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = 1, smode
     try:
         pt = ops.pack_conv_transpose(_dev(wt), 1)
         assert pt.split("f44") is not None
@@ -187,8 +191,9 @@ def test_conv2d_transpose_s1_split():
         ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
 
 
-def test_bench_frames_match_golden_split(fixtures_vox):
-    """The benched configuration with the split stage: the five golden frames of bench.py's batch (tests/golden/bench_frames.npz,
+@pytest.mark.parametrize("smode", ["split", "split16"])
+def test_bench_frames_match_golden_split(fixtures_vox, smode):
+    """The benched configuration with the split stage (either operand format): the five golden frames of bench.py's batch (tests/golden/bench_frames.npz,
     oracle output) at the bars of tests/test_gpu_net.py::test_bench_frames_match_golden -- sampled taps <= 2e-4 * max, image
     <= 1e-3, logits <= 5e-4 * max."""
     from rendernet_amd import ops
@@ -200,7 +205,7 @@ def test_bench_frames_match_golden_split(fixtures_vox):
     spec = ShaderSpec().check()
     r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True))
     old = ops.WINO_GEMM
-    ops.WINO_GEMM = "split"
+    ops.WINO_GEMM = smode
     try:
         taps = {}
         out = r.render(vox[idx], poses[idx], taps=taps).cpu().numpy()
