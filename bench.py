@@ -482,7 +482,20 @@ def build_workload(mode, device):
             "out_hw": 4 * spec.new_size, "out_ch": 6, "trunk": (spec.new_size // 2, spec.w_res2)}
 
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (fp16: the same rate)
+# the further timed passes of every line: (JSON block, ops.WINO_GEMM mode)
+ALT_MODES = (("alt", "split"), ("alt2", "split16"))
+ALT_DTYPE = {"split": "bf16x3-split, fp32 accumulate",
+             "split16": "fp16x2-split of value / power-of-two tensor scale (22-bit operands), fp32 accumulate"}
+ALT_WHAT = {
+    "split": "the same steps with the multiply stages of the wide stride-1 2-D convs (res2, res3, *_skip, e_conv5, e_conv6) and of the 3-D "
+             "encoder's 32-channel convs on the bf16 matrix pipe: every fp32 operand as three bf16 pieces (exact sum), six piece products "
+             "with i + j <= 2, fp32 accumulation (csrc/conv_wino_bf3.hip, conv3d_wino_bf3.hip); every other kernel unchanged (exact fp32)",
+    "split16": "as `alt`, but the wide 2-D convs take every operand as TWO fp16 pieces of value / scale (scale = a power of two from max|x| "
+               "of the tensor, gathered by the producing launch, and the transform's growth bound) and three piece products (h0h0, h0h1, "
+               "h1h0): half the matrix work; operands carry 22 mantissa bits, the fp32 accumulation all routes share dominates the error "
+               "(profiles: hostile-statistics table); the 3-D encoder as in `alt`",
+}
 
 
 def gemm_roofline(gemm_events, layer_events, wtrunk, hw, nloc, mode, gemm_mode):
@@ -506,7 +519,14 @@ def gemm_roofline(gemm_events, layer_events, wtrunk, hw, nloc, mode, gemm_mode):
         nxi, fname = WINO_SCHEMES[which]
         m = 6 if which == "f63" else 4
         exec_flop = 2.0 * nxi * T * wtrunk * wtrunk
-        if gemm_mode == "split":
+        if gemm_mode == "split16":
+            name = ("wino_gemm_bf3_kernel<FmtH2> (GEMM stage of Winograd %s on operands split into two fp16 pieces of value / tensor scale: "
+                    "256x256x16 blocks, three 32x32x16 fp16 MFMAs per fp32 product tile, fp32 accumulate, LDS-DMA 3 stages, persistent)" % fname)
+            basis = ("fp32-equivalent FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles; every one executed as 3 fp16 "
+                     "piece products (h0h0, h0h1, h1h0)" % (nxi, m, m))
+            peak, peak_name = PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 MFMA dense peak / 3 (three fp16 products per fp32 product)"
+            tkey = "wino63_gemm_h2_res2" if which == "f63" else "wino43_gemm_h2_res2"
+        elif gemm_mode == "split":
             name = ("wino_gemm_bf3_kernel (GEMM stage of Winograd %s on split operands: 256x256x16 blocks, six 32x32x16 bf16 MFMAs per "
                     "fp32 product tile, fp32 accumulate, LDS-DMA 3 stages, persistent)" % fname)
             basis = ("fp32-equivalent FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles; every one executed as 6 bf16 "
@@ -537,7 +557,7 @@ def gemm_roofline(gemm_events, layer_events, wtrunk, hw, nloc, mode, gemm_mode):
         "traffic": traffic, "traffic_source": tsrc}
     if peak_name:
         roof["peak_name"] = peak_name
-        roof["bf16_tflops_executed"] = round(6.0 * achieved, 1)
+        roof["mfma_tflops_executed"] = round((3.0 if gemm_mode == "split16" else 6.0) * achieved, 1)
     return roof
 
 
@@ -626,10 +646,10 @@ def render_main(args, world, rank, local_rank):
     out, elapsed, by_rank, ev = timed_pass(vox, aux, poses, args.gemm, args.steps, args.warmup)
     frames_by_rank = gather_per_rank(nloc, world, rank)
     # ---- the same steps with the multiply stage of the wide 2-D layers on the bf16 pipe (fp32 accuracy by operand splitting)
-    alt = None
+    alts = {}
     if not args.no_alt and args.gemm == "f32":
-        out_alt, el_alt, by_rank_alt, ev_alt = timed_pass(vox, aux, poses, "split", args.steps, max(1, args.warmup))
-        alt = (out_alt, el_alt, by_rank_alt, ev_alt)
+        for key, gm in ALT_MODES:
+            alts[key] = timed_pass(vox, aux, poses, gm, args.steps, max(1, args.warmup))
     # ---- N > 1: the other scaling regime as well (weak: every rank its own batch; strong: ONE batch split 24 -> 24/N)
     other = None
     if world > 1 and not args.no_other_scaling:
@@ -641,10 +661,11 @@ def render_main(args, world, rank, local_rank):
             other = {"scaling": oscal, "value": round(tot2 * args.steps / el2, 3), "unit": "frames/s",
                      "ms_per_step": round(1e3 * el2 / args.steps, 3), "global_batch": tot2,
                      **per_rank_fields(br2, fr2, args.steps)}
-            if alt is not None:
-                o3, el3, br3, _ = timed_pass(v2, a2, p2, "split", args.steps, 1)
-                other["alt_value"] = round(tot2 * args.steps / el3, 3)
-                other["alt_ms_per_step"] = round(1e3 * el3 / args.steps, 3)
+            for key, gm in ALT_MODES:
+                if key in alts:
+                    o3, el3, br3, _ = timed_pass(v2, a2, p2, gm, args.steps, 1)
+                    other[key + "_value"] = round(tot2 * args.steps / el3, 3)
+                    other[key + "_ms_per_step"] = round(1e3 * el3 / args.steps, 3)
             del v2, a2, p2, o2
     if rank != 0:
         return
@@ -672,7 +693,7 @@ def render_main(args, world, rank, local_rank):
         res["other_scaling"] = other
     roof = gemm_roofline(ev["gemm"], ev["layer"], wtrunk, hw, nloc, mode, args.gemm)
     if args.gemm != "f32":
-        res["dtype"] = "f32 (GEMM stage of the wide 2-D convs: bf16x3-split, fp32 accumulate)"
+        res["dtype"] = "f32 (multiply stages: %s)" % ALT_DTYPE[args.gemm]
     if roof is not None:
         res["roofline"] = roof
     rs_events = ev["resample"]
@@ -710,17 +731,16 @@ def render_main(args, world, rank, local_rank):
         res["parity_golden" if "parity" in res else "parity"] = gp
         if not gp["ok"]:
             failures.append("max|gpu - committed oracle render| = %g > %g (frames %s)" % (gp["max_abs_err"], PARITY_TOL, gp["frames"]))
-    if alt is not None:
-        out_alt, el_alt, by_rank_alt, ev_alt = alt
+    for key, gm in ALT_MODES:
+        if key not in alts:
+            continue
+        out_alt, el_alt, by_rank_alt, ev_alt = alts[key]
         fps_alt = total_frames * args.steps / el_alt
-        ablk = {"dtype": "bf16x3-split, fp32 accumulate",
-                "what": "the same steps with the GEMM stage of the wide stride-1 2-D convs (res2, res3, *_skip, e_conv5, e_conv6) on the "
-                        "bf16 matrix pipe: every fp32 operand as three bf16 pieces, six piece products with i + j <= 2, fp32 "
-                        "accumulation (csrc/conv_wino_bf3.hip); every other kernel unchanged (exact fp32)",
+        ablk = {"dtype": ALT_DTYPE[gm], "what": ALT_WHAT[gm],
                 "value": round(fps_alt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el_alt / args.steps, 3),
                 "steps": args.steps, "speedup_vs_value": round(fps_alt / fps, 4),
                 **per_rank_fields(by_rank_alt, frames_by_rank, args.steps)}
-        aroof = gemm_roofline(ev_alt["gemm"], ev_alt["layer"], wtrunk, hw, nloc, mode, "split")
+        aroof = gemm_roofline(ev_alt["gemm"], ev_alt["layer"], wtrunk, hw, nloc, mode, gm)
         if aroof is not None:
             ablk["roofline"] = aroof
         if want is not None:
@@ -728,14 +748,14 @@ def render_main(args, world, rank, local_rank):
             ablk["parity"] = {"frames": int(want.shape[0]), "max_abs_err": aerr, "tol": PARITY_TOL, "ok": aerr <= PARITY_TOL,
                               "reference": "the same live oracle render as `parity`"}
             if aerr > PARITY_TOL:
-                failures.append("alt (split): max|gpu - oracle| = %g > %g" % (aerr, PARITY_TOL))
+                failures.append("%s (%s): max|gpu - oracle| = %g > %g" % (key, gm, aerr, PARITY_TOL))
         agp = golden_parity(mode, out_alt, frame_ids)
         if agp is not None:
             ablk["parity_golden" if "parity" in ablk else "parity"] = agp
             if not agp["ok"]:
-                failures.append("alt (split): max|gpu - committed oracle render| = %g > %g" % (agp["max_abs_err"], PARITY_TOL))
+                failures.append("%s (%s): max|gpu - committed oracle render| = %g > %g" % (key, gm, agp["max_abs_err"], PARITY_TOL))
         ablk["max_abs_diff_vs_primary_output"] = float((out_alt - out).abs().max())
-        res["alt"] = ablk
+        res[key] = ablk
     print(json.dumps(res), flush=True)
     if failures:
         raise SystemExit("PARITY FAILURE: " + "; ".join(failures))
@@ -794,10 +814,10 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="run ONLY the full CPU-baseline protocol of BASELINE.md §3 (one B=24 pass + three B=1 passes of the oracle, all "
                          "cores and the best-of sweep; minutes) and print its record as one JSON line")
-    ap.add_argument("--gemm", choices=["f32", "split"], default="f32",
+    ap.add_argument("--gemm", choices=["f32", "split", "split16"], default="f32",
                     help="multiply stage of the wide 2-D convs in the PRIMARY pass: exact-fp32 MFMA (default; the split route is then timed as `alt`) "
                          "or the bf16x3 split route (profiling: no alt pass)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second timed pass (split bf16x3 GEMM stage) and its `alt` block")
+    ap.add_argument("--no-alt", action="store_true", help="skip the further timed passes (split GEMM stages: bf16x3 `alt`, fp16x2 `alt2`)")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the pass in the other scaling regime (`other_scaling`)")
     ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")
     args = ap.parse_args()

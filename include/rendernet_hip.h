@@ -276,6 +276,18 @@ int rn_winograd_split_gemm(int scheme, const void* Vs, const void* w_split, floa
 int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
                                  const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
                                  int Cin, int Cout, int transposed, int act, void* stream);
+/* ..._ex: format RN_SPLIT_FMT_H2 needs max|x| of every layer input.  A layer's launcher finds it with one pass over x -- or takes it
+ * from `amax_x`, a device word holding the bit pattern of max|x| (or of an upper bound), which the launch that PRODUCED x wrote as its
+ * `amax_y` (max over the tensor after the whole epilogue).  Both may be NULL; format 0 ignores amax_x.  rn_absmax: the stand-alone pass
+ * (n % 4 == 0 floats, 16-byte aligned). */
+int rn_conv2d_winograd_split_fwd_ex(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
+                                    const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
+                                    int Cin, int Cout, int transposed, int act, const void* amax_x, void* amax_y, void* stream);
+int rn_winograd_split_input_transform_ex(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo,
+                                         const void* amax_x, void* stream);
+int rn_winograd_output_transform_ex(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                    float* y, float* preact, int B, int H, int W, int C, int act, void* amax_y, void* stream);
+int rn_absmax(const float* x, long long n, void* amax, void* stream);
 /* Filter gradient of the same layers (tf.nn.conv2d_backprop_filter of slim.conv2d [3,3] / [4,4], stride 1: tools/layer_util.py:101-104,
  * RenderNet_Shader.py:71-103) with the reduction over the tiles on the bf16 pipe, same arithmetic: dw [R,R,Cin,Cout] += ...;
  * scheme RN_WINO_F43 (3x3) or RN_WINO_F44 (4x4); x [B,H,W,Cin], dz [B,H,W,Cout]; workspace of

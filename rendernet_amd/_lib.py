@@ -88,6 +88,10 @@ SIGNATURES = {
     "rn_winograd_split_input_transform": (_c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     "rn_winograd_split_gemm": (_c_int, [_c_int] + [_c_vp] * 3 + [ctypes.c_longlong, _c_int, _c_int, _c_vp]),
     "rn_conv2d_winograd_split_fwd": (_c_int, [_c_int] + [_c_vp] * 8 + [_c_int] * 7 + [_c_vp]),
+    "rn_conv2d_winograd_split_fwd_ex": (_c_int, [_c_int] + [_c_vp] * 8 + [_c_int] * 7 + [_c_vp] * 3),
+    "rn_winograd_split_input_transform_ex": (_c_int, [_c_int, _c_vp, _c_vp] + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "rn_winograd_output_transform_ex": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 5 + [_c_vp, _c_vp]),
+    "rn_absmax": (_c_int, [_c_vp, ctypes.c_longlong, _c_vp, _c_vp]),
     "rn_winograd_split_wgrad_supported": (_c_int, [_c_int, _c_int, _c_int]),
     "rn_winograd_split_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_int] * 6),
     "rn_conv2d_winograd_split_wgrad": (_c_int, [_c_int] + [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),

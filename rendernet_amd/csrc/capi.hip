@@ -499,6 +499,40 @@ extern "C" int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const vo
                                    (hipStream_t)stream);
 }
 
+extern "C" int rn_conv2d_winograd_split_fwd_ex(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
+                                               const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
+                                               int Cin, int Cout, int transposed, int act, const void* amax_x, void* amax_y, void* stream)
+{
+    if (!x || !w_split || !y || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: null pointer");
+    if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: PReLU needs alpha");
+    const int pad_lo = ((scheme & 0xff) == RN_WINO_F44 && transposed) ? 2 : 1;
+    return rn_launch_conv_wino_bf3_ex(scheme, x, w_split, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, pad_lo, act,
+                                      static_cast<const unsigned*>(amax_x), static_cast<unsigned*>(amax_y), (hipStream_t)stream);
+}
+extern "C" int rn_winograd_split_input_transform_ex(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo,
+                                                    const void* amax_x, void* stream)
+{
+    if (!x || !Vs) return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: null pointer");
+    if (rn_wino_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
+        return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: bad arguments");
+    return rn_launch_wino_input_bf3_ex(scheme, x, Vs, B, H, W, C, pad_lo, static_cast<const unsigned*>(amax_x), (hipStream_t)stream);
+}
+extern "C" int rn_winograd_output_transform_ex(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,
+                                               float* y, float* preact, int B, int H, int W, int C, int act, void* amax_y, void* stream)
+{
+    if (!M || !y) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: null pointer");
+    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: bad sizes");
+    if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: PReLU needs alpha");
+    if (amax_y && hipMemsetAsync(amax_y, 0, 4, (hipStream_t)stream) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "rn_winograd_output_transform_ex: memset failed");
+    return rn_launch_wino_output_amax(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, static_cast<unsigned*>(amax_y), (hipStream_t)stream);
+}
+extern "C" int rn_absmax(const float* x, long long n, void* amax, void* stream)
+{
+    if (!x || !amax || n < 4 || n % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_absmax: bad arguments");
+    return rn_launch_absmax(x, (size_t)n, static_cast<unsigned*>(amax), (hipStream_t)stream);
+}
+
 // ---- the 3x3x3 32 -> 32 convs of the 3-D encoder on the bf16 matrix pipe at fp32 accuracy (conv3d_wino_bf3.hip)
 extern "C" int rn_winograd_split_wgrad_supported(int scheme, int Cin, int Cout) { return rn_wino_bf3_wgrad_supported(scheme, Cin, Cout) ? 1 : 0; }
 extern "C" size_t rn_winograd_split_wgrad_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)

@@ -113,7 +113,7 @@ template <class S, int VW>
 __global__ __launch_bounds__(256)
 void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
                         const float* __restrict__ res, float* __restrict__ y, float* __restrict__ z,
-                        int H, int W, int C, int th, int tw, long long T, int act, unsigned nblk8)
+                        int H, int W, int C, int th, int tw, long long T, int act, unsigned nblk8, unsigned* __restrict__ amax)
 {
     typedef float vec __attribute__((ext_vector_type(VW)));
     constexpr int A = S::TA;
@@ -121,8 +121,13 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
     const long long idx = (long long)blk * 256 + threadIdx.x;
     const int CV = C / VW;
     const int cv = (int)(idx % CV);
-    const long long t = idx / CV;
-    if (t >= T) return;
+    const long long t_raw = idx / CV;
+    // amax != nullptr (the consumer is a split-format H2 layer): max |y| of the tensor is gathered on the way -- a wave reduction at
+    // the end, so the threads behind the last tile stay (they redo tile T - 1 and store nothing); otherwise they leave here
+    if (t_raw >= T && !amax) return;
+    const bool live = t_raw < T;
+    const long long t = live ? t_raw : T - 1;
+    float ymax = 0.f;
     const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
     const long long b = t / ((long long)tw * th);
     const float* mb = M + (size_t)t * C + cv * VW;
@@ -162,7 +167,7 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
                 if (c != 0.f) v += c * s[p_][j];
             }
             const size_t off = (((size_t)b * H + oy) * W + ox) * C + cv * VW;
-            if (z) *reinterpret_cast<vec*>(z + off) = v;
+            if (z && live) *reinterpret_cast<vec*>(z + off) = v;
             if (act & RN_ACT_PRELU) {
 #pragma unroll
                 for (int e = 0; e < VW; ++e) v[e] = fmaxf(v[e], 0.f) + av[e] * fminf(v[e], 0.f);
@@ -176,8 +181,19 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
 #pragma unroll
                 for (int e = 0; e < VW; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
             }
-            *reinterpret_cast<vec*>(y + off) = v;
+            if (live) *reinterpret_cast<vec*>(y + off) = v;
+            if (amax) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+            }
         }
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        // (a plain read first: once a few waves have reported, almost none exceeds the running maximum -- no atomic storm on one address)
+        const unsigned bits = __builtin_bit_cast(unsigned, ymax);
+        if ((threadIdx.x & 63) == 0 && bits > *reinterpret_cast<volatile unsigned*>(amax)) atomicMax(amax, bits);
     }
 }
 
@@ -705,6 +721,14 @@ int rn_launch_wino_gemm(int scheme, const float* V, const float* u, float* M, lo
 int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
                           float* preact, int B, int H, int W, int C, int act, hipStream_t st)
 {
+    return rn_launch_wino_output_amax(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, nullptr, st);
+}
+
+// ... with max |y| gathered into *amax (bit pattern of a non-negative float, for a consumer in split format H2): an atomic maximum
+// onto what the word holds -- the caller zeroes it (once, however many launches write one tensor)
+int rn_launch_wino_output_amax(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                               float* preact, int B, int H, int W, int C, int act, unsigned* amax, hipStream_t st)
+{
     const int m = rn_wino_scheme_m(scheme);
     if (m == 0) return rn_set_error(RN_E_INVALID, "wino_output: unknown scheme %d", scheme);
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
@@ -714,13 +738,13 @@ int rn_launch_wino_output(int scheme, const float* M, const float* bias, const f
     const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
     if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_output_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8);
+                           H, W, C, th, tw, T, act, nblk8, amax);
     else if (scheme == RN_WINO_F44)
         hipLaunchKernelGGL((wino_output_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8);
+                           H, W, C, th, tw, T, act, nblk8, amax);
     else
         hipLaunchKernelGGL((wino_output_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8);
+                           H, W, C, th, tw, T, act, nblk8, amax);
     return rn_check_launch("wino_output");
 }
 

@@ -731,7 +731,10 @@ inline float h2_bound_v(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>:
 inline float h2_bound_u(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>::g() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::g() : H2Bound<WinoF63>::g(); }
 
 // *out = bit pattern of max |x| over n floats (n % 4 == 0)
-int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
+int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st) { return rn_launch_absmax(x, n, out, st); }
+}  // namespace
+
+int rn_launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
 {
     if (n % 4 != 0) return rn_set_error(RN_E_INVALID, "absmax: %zu floats", n);
     if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "absmax: memset failed");
@@ -740,7 +743,7 @@ int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, out);
     return rn_check_launch("absmax");
 }
-}  // namespace
+
 
 bool rn_wino_bf3_supported(int scheme, int Cin, int Cout)
 {
@@ -795,6 +798,13 @@ int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, in
 
 int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, hipStream_t st)
 {
+    return rn_launch_wino_input_bf3_ex(scheme, x, Vs, B, H, W, C, pad_lo, nullptr, st);
+}
+
+// amax_x (format H2 only, may be null): a device word that already holds the bit pattern of max|x| (or of an upper bound of it), e.g.
+// from the launch that produced x -- copied into the tail of Vs instead of a pass over x
+int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, const unsigned* amax_x, hipStream_t st)
+{
     const int fmt = fmt_of(scheme);
     scheme = sch_of(scheme);
     const int m = rn_wino_scheme_m(scheme);
@@ -808,8 +818,12 @@ int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H,
     char* v = static_cast<char*>(Vs);
     if (fmt == 1) {
         unsigned* amax = reinterpret_cast<unsigned*>(v + h2_v_data(scheme, T, C));
-        const int rc = launch_absmax(x, (size_t)B * H * W * C, amax, st);
-        if (rc != RN_OK) return rc;
+        if (amax_x) {
+            if (hipMemcpyAsync(amax, amax_x, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "wino_input_h2: copy of max|x| failed");
+        } else {
+            const int rc = launch_absmax(x, (size_t)B * H * W * C, amax, st);
+            if (rc != RN_OK) return rc;
+        }
         if (scheme == RN_WINO_F43)
             hipLaunchKernelGGL((wino_input_h2_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
         else if (scheme == RN_WINO_F44)
@@ -953,7 +967,14 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
 int rn_launch_conv_wino_bf3(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
                             float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st)
 {
-    if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    return rn_launch_conv_wino_bf3_ex(scheme, x, us, bias, alpha, residual, y, preact, ws, B, H, W, Cin, Cout, pad_lo, act, nullptr, nullptr, st);
+}
+
+// amax_x: see rn_launch_wino_input_bf3_ex.  amax_y (may be null): receives the bit pattern of max|y|, for the next layer's amax_x.
+static int conv_wino_bf3_rec(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
+                             float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act,
+                             const unsigned* amax_x, unsigned* amax_y, hipStream_t st)
+{
     const int m = rn_wino_scheme_m(sch_of(scheme));
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
@@ -966,17 +987,26 @@ int rn_launch_conv_wino_bf3(int scheme, const float* x, const void* us, const fl
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = B - b0 < chunk ? B - b0 : chunk;
             const size_t xo = (size_t)b0 * H * W * Cin, yo = (size_t)b0 * H * W * Cout;
-            const int rc = rn_launch_conv_wino_bf3(scheme, x + xo, us, bias, alpha, residual ? residual + yo : nullptr, y + yo,
-                                                   preact ? preact + yo : nullptr, ws, nb, H, W, Cin, Cout, pad_lo, act, st);
+            const int rc = conv_wino_bf3_rec(scheme, x + xo, us, bias, alpha, residual ? residual + yo : nullptr, y + yo,
+                                             preact ? preact + yo : nullptr, ws, nb, H, W, Cin, Cout, pad_lo, act, amax_x, amax_y, st);
             if (rc != RN_OK) return rc;
         }
         return RN_OK;
     }
     char* Vs = static_cast<char*>(ws);
     float* M = reinterpret_cast<float*>(Vs + rn_wino_bf3_v_bytes(scheme, T, Cin));
-    int rc = rn_launch_wino_input_bf3(scheme, x, Vs, B, H, W, Cin, pad_lo, st);
+    int rc = rn_launch_wino_input_bf3_ex(scheme, x, Vs, B, H, W, Cin, pad_lo, amax_x, st);
     if (rc != RN_OK) return rc;
     rc = rn_launch_wino_gemm_bf3(scheme, Vs, us, M, T, Cin, Cout, st);
     if (rc != RN_OK) return rc;
-    return rn_launch_wino_output(sch_of(scheme), M, bias, alpha, residual, y, preact, B, H, W, Cout, act, st);
+    return rn_launch_wino_output_amax(sch_of(scheme), M, bias, alpha, residual, y, preact, B, H, W, Cout, act, amax_y, st);
+}
+
+int rn_launch_conv_wino_bf3_ex(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
+                               float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act,
+                               const unsigned* amax_x, unsigned* amax_y, hipStream_t st)
+{
+    if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
+    if (amax_y && hipMemsetAsync(amax_y, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "conv_wino_bf3: memset failed");
+    return conv_wino_bf3_rec(scheme, x, us, bias, alpha, residual, y, preact, ws, B, H, W, Cin, Cout, pad_lo, act, amax_x, amax_y, st);
 }

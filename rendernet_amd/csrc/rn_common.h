@@ -59,6 +59,8 @@ int rn_launch_wino_outin(int scheme, const float* M, const float* bias, const fl
                          float* V, int B, int H, int W, int C, int act, hipStream_t st);   // RN_E_UNSUPPORTED (no message) = does not apply
 int rn_launch_wino_output(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
                           float* preact, int B, int H, int W, int C, int act, hipStream_t st);
+int rn_launch_wino_output_amax(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
+                               float* preact, int B, int H, int W, int C, int act, unsigned* amax, hipStream_t st);
 int rn_launch_conv_wino43(int scheme, const float* x, const float* u, const float* bias, const float* alpha, const float* residual,
                           float* y, float* preact, float* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act, hipStream_t st);
 bool rn_wino_bf3_supported(int scheme, int Cin, int Cout);                                                // conv_wino_bf3.hip
@@ -67,6 +69,11 @@ size_t rn_wino_bf3_v_bytes(int scheme, long long T, int Cin);
 size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout);
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st);
 int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, hipStream_t st);
+int rn_launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st);                                           // *out = bits of max|x| (n % 4 == 0)
+int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, const unsigned* amax_x, hipStream_t st);
+int rn_launch_conv_wino_bf3_ex(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
+                               float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act,
+                               const unsigned* amax_x, unsigned* amax_y, hipStream_t st);
 int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st);
 int rn_launch_gemm_bf3_planes(int nplanes, int tag, const void* Vs, const void* us, float* M, long long T, int Cin, int Cout, hipStream_t st);
 bool rn_wino_bf3_wgrad_supported(int scheme, int Cin, int Cout);                                          // conv_wino_bf3_wgrad.hip

@@ -424,6 +424,7 @@ def training(ctx):
         TRAIN = old
 
 
+_LAST_AMAX = None      # the device word with max|y| of the launch just made (split format H2), picked up by _Conv.forward
 STAGE_HOOK = None      # bench.py: callable(stage, (T, Cin, Cout)) -> (start_event, end_event) | None, brackets the GEMM stage
 
 
@@ -520,16 +521,24 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
     scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
     st = L.stream_ptr()
     if WINO_GEMM in ("split", "split16") and lib.rn_winograd_split_supported(scheme, Cin, Cout):
+        global _LAST_AMAX
         fmt = L.RN_SPLIT_FMT_H2 if WINO_GEMM == "split16" else 0
         us = ctypes.c_void_p(pw.split(which, fmt).data_ptr())
         scheme |= fmt
         ws = torch.empty(lib.rn_winograd_split_workspace_bytes(scheme, B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
         wsp = ctypes.c_void_p(ws.data_ptr())
+        # format H2 scales every operand tensor by (a bound from) its max|x|: the launch that produced x left it in x._rn_amax (a device
+        # word); without one the launcher makes a pass over x.  This launch leaves max|y| for the next layer the same way.
+        ax = getattr(x, "_rn_amax", None) if fmt else None
+        ay = torch.empty(1, dtype=torch.int32, device=x.device) if fmt else None
+        axp = ctypes.c_void_p(ax.data_ptr()) if ax is not None else None
+        ayp = ctypes.c_void_p(ay.data_ptr()) if ay is not None else None
+        _LAST_AMAX = ay
         ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
         if ev is None:
-            return lib.rn_conv2d_winograd_split_fwd(scheme, L.ptr(x), us, *e, wsp, B, H, W, Cin, Cout, transposed, act, st)
+            return lib.rn_conv2d_winograd_split_fwd_ex(scheme, L.ptr(x), us, *e, wsp, B, H, W, Cin, Cout, transposed, act, axp, ayp, st)
         M = ctypes.c_void_p(ws.data_ptr() + lib.rn_winograd_split_v_bytes(scheme, T, Cin))
-        rc = lib.rn_winograd_split_input_transform(scheme, L.ptr(x), wsp, B, H, W, Cin, 2 if (f44 and transposed) else 1, st)
+        rc = lib.rn_winograd_split_input_transform_ex(scheme, L.ptr(x), wsp, B, H, W, Cin, 2 if (f44 and transposed) else 1, axp, st)
         if rc != 0:
             return rc
         ev[0].record()
@@ -537,7 +546,7 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
         ev[1].record()
         if rc != 0:
             return rc
-        return lib.rn_winograd_output_transform(scheme & 0xff, M, *e, B, H, W, Cout, act, st)
+        return lib.rn_winograd_output_transform_ex(scheme & 0xff, M, *e, B, H, W, Cout, act, ayp, st)
     u = pw.wino63 if f63 else pw.wino43
     n = (lib.rn_conv2d_wino44_workspace_floats if f44 else lib.rn_conv2d_wino63_workspace_floats if f63
          else lib.rn_conv2d_wino43_workspace_floats)(B, H, W, Cin, Cout)
@@ -627,7 +636,11 @@ class _Conv(torch.autograd.Function):
         if residual is not None and residual.shape != y.shape:
             raise L.RenderNetHipError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
         z = torch.empty_like(y) if (train and alpha is not None) else None
+        global _LAST_AMAX
+        _LAST_AMAX = None
         L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act), "rn_%s_fwd" % mode)
+        if _LAST_AMAX is not None:
+            y._rn_amax, _LAST_AMAX = _LAST_AMAX, None
         if ev is not None:
             ev[1].record()
         if train:
