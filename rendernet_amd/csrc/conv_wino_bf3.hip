@@ -35,8 +35,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-namespace {
-
 // Operand formats of the GEMM stage.  A row of an operand panel holds, per K step of 16, NP planes of 16 values (32 bytes each).
 //   B3: three bf16 pieces (exact sum = the fp32 value), six piece products i + j <= 2.  Rows of 96 bytes; the two 16-byte chunks
 //       of a plane are swapped in rows with bit 3 set.
@@ -44,6 +42,8 @@ namespace {
 //       the scaled maximum lose relative, not absolute, precision), three products (h0 h0, h0 h1, h1 h0); the accumulators are
 //       multiplied by the two scales on the way out.  Rows of 64 bytes; the four chunks of a row are XORed with bits 2..3 of the
 //       row index.  Either way the 16 lanes of a ds_read_b128 group (16 consecutive rows) hit 16 different bank groups.
+// (a named namespace: profiler tables then show wino_gemm_bf3_kernel<rnf::FmtH2, 4, 2>)
+namespace rnf {
 struct FmtB3 {
     static constexpr int NP = 3, ROW = 96, NPROD = 6, ID = 0;
     typedef bf16x8 frag;
@@ -58,6 +58,11 @@ struct FmtH2 {
     __device__ static __forceinline__ unsigned chunk(int row, int p, int hb) { return (((unsigned)(p * 2 + hb)) ^ (unsigned)((row >> 2) & 3)) << 4; }
     __device__ static __forceinline__ f32x16 mfma(const frag& u, const frag& v, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(u, v, c, 0, 0, 0); }
 };
+}  // namespace rnf
+using rnf::FmtB3;
+using rnf::FmtH2;
+
+namespace {
 
 // the power-of-two scale of a tensor in format H2 from the largest magnitude of its UNtransformed values (0 -> 1)
 __host__ __device__ inline float h2_scale(float amax, float bound)

@@ -37,7 +37,7 @@ for tag in sq fetch write tcc; do
     run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done
 for name in wino63 wino43 bf3 res1 res1w res1s resample; do
-    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = bf3 ] && flt=bf3; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = res1s ] && flt=conv3d_wino_bf3; [ $name = resample ] && flt=resample_
+    flt=""; [ $name = wino63 ] && flt=wino; [ $name = wino43 ] && flt=wino; [ $name = bf3 ] && flt=wino_; [ $name = res1 ] && flt=conv3d_k3; [ $name = res1w ] && flt=conv_wino; [ $name = res1s ] && flt=conv3d_wino_bf3; [ $name = resample ] && flt=resample_
     : > "$OUT/$name.txt"
     for tag in sq fetch write tcc; do
         f=$(find "$OUT/$name.$tag" -name "*counter_collection.csv" | head -1)

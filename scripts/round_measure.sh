@@ -20,8 +20,10 @@ RN_NO_WINOGRAD63=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$O
 import sys, json
 d = json.loads(sys.stdin.readline())
 a = d.get('alt') or {}
-print('batch %3d  fp32 GEMM stage %8.2f frames/s  %8.2f ms/step  frac %.3f   |   split %8.2f frames/s  %8.2f ms/step  frac %.3f (of bf16 peak / 6)'
-      % ($b, d['value'], d['ms_per_step'], d['roofline']['frac'], a.get('value', 0), a.get('ms_per_step', 0), (a.get('roofline') or {}).get('frac', 0)))"
+a2 = d.get('alt2') or {}
+print('batch %3d  fp32 GEMM stage %8.2f frames/s  %8.2f ms/step  frac %.3f   |   split (bf16x3) %8.2f frames/s  %8.2f ms/step  frac %.3f (of bf16 peak / 6)   |   split16 (fp16x2) %8.2f frames/s  %8.2f ms/step  frac %.3f (of fp16 peak / 3)'
+      % ($b, d['value'], d['ms_per_step'], d['roofline']['frac'], a.get('value', 0), a.get('ms_per_step', 0), (a.get('roofline') or {}).get('frac', 0),
+         a2.get('value', 0), a2.get('ms_per_step', 0), (a2.get('roofline') or {}).get('frac', 0)))"
   done
 } > "$O/${TAG}_batch_sweep.txt"
 {
@@ -43,6 +45,7 @@ bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseli
 bash scripts/profile_bench.sh ${TAG}_texture --mode texture --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_render_split --gemm split --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_render_split16 --gemm split16 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_train_split --mode train --gemm split --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline --no-alt > /dev/null 2>&1
 tail -3 "$O/${TAG}_bench.err"
