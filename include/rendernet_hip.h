@@ -310,6 +310,14 @@ size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout);
 int rn_conv3d_winograd_split_pack(const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream);
 int rn_conv3d_winograd_split_fwd(const float* x, const void* w_split, const float* bias, const float* alpha, const float* residual,
                                  float* y, float* preact, int B, int H, int W, int D, int Cin, int Cout, int act, void* stream);
+/* ..._ex: the operand format as a parameter (fmt 0 = three bf16 pieces; 1 = two fp16 pieces of value / tensor scale, see RN_SPLIT_FMT_H2)
+ * and the max|x| hand-over: amax_x = device word holding the bit pattern of max|x| (NULL: the launcher makes a pass over x into
+ * amax_scratch, a device word of the caller's); amax_y (may be NULL) receives max|y|. */
+size_t rn_conv3d_winograd_split_packed_bytes_ex(int fmt, int Cin, int Cout);
+int rn_conv3d_winograd_split_pack_ex(int fmt, const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream);
+int rn_conv3d_winograd_split_fwd_ex(int fmt, const float* x, const void* w_split, const float* bias, const float* alpha, const float* residual,
+                                    float* y, float* preact, int B, int H, int W, int D, int Cin, int Cout, int act,
+                                    const void* amax_x, void* amax_scratch, void* amax_y, void* stream);
 int rn_conv3d_wino_supported(int Cin, int Cout);
 /* rn_conv2d_wino4_fwd: the 4x4, stride-1 layers -- e_conv5, e_conv6 (slim.conv2d [4,4], RenderNet_Shader.py:86-88, :101-103;
  * transposed = 0, SAME padding (1,2)) and e_conv7_1 (slim.conv2d_transpose [4,4] stride 1, :109-111; transposed = 1: the

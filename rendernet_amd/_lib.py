@@ -96,6 +96,9 @@ SIGNATURES = {
     "rn_winograd_split_wgrad_workspace_bytes": (ctypes.c_size_t, [_c_int] * 6),
     "rn_conv2d_winograd_split_wgrad": (_c_int, [_c_int] + [_c_vp] * 4 + [_c_int] * 5 + [_c_vp]),
     "rn_conv3d_winograd_split_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv3d_winograd_split_packed_bytes_ex": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "rn_conv3d_winograd_split_pack_ex": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "rn_conv3d_winograd_split_fwd_ex": (_c_int, [_c_int] + [_c_vp] * 7 + [_c_int] * 7 + [_c_vp] * 4),
     "rn_conv3d_winograd_split_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "rn_conv3d_winograd_split_pack": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "rn_conv3d_winograd_split_fwd": (_c_int, [_c_vp] * 7 + [_c_int] * 7 + [_c_vp]),

@@ -546,6 +546,26 @@ extern "C" int rn_conv2d_winograd_split_wgrad(int scheme, const float* x, const 
     if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_wgrad: bad sizes");
     return rn_launch_conv_wino_bf3_wgrad(scheme, x, dz, dw, workspace, B, H, W, Cin, Cout, static_cast<hipStream_t>(stream));
 }
+// ..._ex: operand format as a parameter (0 | RN_SPLIT_FMT_H2 >> 8 = 1) and the max|x| hand-over of the 2-D entries
+extern "C" size_t rn_conv3d_winograd_split_packed_bytes_ex(int fmt, int Cin, int Cout)
+{
+    return (Cin == 32 && Cout == 32 && (fmt == 0 || fmt == 1)) ? rn_conv3d_wino_split_packed_bytes(fmt) : 0;
+}
+extern "C" int rn_conv3d_winograd_split_pack_ex(int fmt, const float* w_tf, void* w_split, int Cin, int Cout, int transposed, void* stream)
+{
+    if (!w_tf || !w_split) return rn_set_error(RN_E_INVALID, "rn_conv3d_winograd_split_pack_ex: null pointer");
+    if (Cin != 32 || Cout != 32 || fmt < 0 || fmt > 1) return rn_set_error(RN_E_UNSUPPORTED, "rn_conv3d_winograd_split_pack_ex: Cin=%d Cout=%d fmt=%d", Cin, Cout, fmt);
+    return rn_launch_conv3d_wino_split_pack(fmt, w_tf, w_split, transposed ? 1 : 0, (hipStream_t)stream);
+}
+extern "C" int rn_conv3d_winograd_split_fwd_ex(int fmt, const float* x, const void* w_split, const float* bias, const float* alpha, const float* residual,
+                                               float* y, float* preact, int B, int H, int W, int D, int Cin, int Cout, int act,
+                                               const void* amax_x, void* amax_scratch, void* amax_y, void* stream)
+{
+    if (!x || !w_split || !y) return rn_set_error(RN_E_INVALID, "rn_conv3d_winograd_split_fwd_ex: null pointer");
+    if (!rn_conv3d_wino_bf3_supported(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "rn_conv3d_winograd_split_fwd_ex: Cin=%d Cout=%d", Cin, Cout);
+    return rn_launch_conv3d_wino_split(fmt, x, w_split, bias, alpha, residual, y, preact, B, H, W, D, act, static_cast<const unsigned*>(amax_x),
+                                       static_cast<unsigned*>(amax_scratch), static_cast<unsigned*>(amax_y), (hipStream_t)stream);
+}
 extern "C" int rn_conv3d_winograd_split_supported(int Cin, int Cout) { return rn_conv3d_wino_bf3_supported(Cin, Cout) ? 1 : 0; }
 extern "C" size_t rn_conv3d_winograd_split_packed_bytes(int Cin, int Cout)
 {

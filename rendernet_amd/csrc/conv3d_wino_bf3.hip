@@ -39,6 +39,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
@@ -61,7 +63,33 @@ struct C3Args {
     int nitems;                 // B * bh * bw: an item is a row of 16 tiles through ALL depth slices
     int act;
     int probe;                  // RN_C3_PROBE (timing experiments, wrong results): 1 no DMA in the loop, 2 no compute, 4 no epilogue, 8 no barriers
+    const unsigned* amax_x; const unsigned* amax_u;   // format H2: bit patterns of max|x| of the input tensor and of the filter (device words)
+    unsigned* amax_y;                                 // either format, may be null: receives max|y| (atomic maximum onto a zeroed word)
 };
+
+// Operand formats (conv_wino_bf3.hip has the arithmetic): B3 = three bf16 pieces, six products; H2 = two fp16 pieces of value / scale,
+// three products, the scale a power of two from max|x| of the tensor times the growth bound of the transform (F(2x2,3x3): rows of
+// B^T sum to 2 -> 4 for the input, rows of G to 1.5 -> 2.25 for the filter), so that |value / scale| < 2^15.
+struct C3B3 {
+    static constexpr int NP = 3, NPROD = 6, ID = 0;
+    typedef bf16x8 frag;
+    static constexpr int PU[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};     // i + j <= 2, smallest terms first
+};
+struct C3H2 {
+    static constexpr int NP = 2, NPROD = 3, ID = 1;
+    typedef f16x8 frag;
+    static constexpr int PU[6] = {1, 0, 0, 0, 0, 0}, PV[6] = {0, 1, 0, 0, 0, 0};
+};
+constexpr float C3_BOUND_X = 4.f, C3_BOUND_U = 2.25f;
+
+__host__ __device__ inline float c3_h2_scale(float amax, float bound)
+{
+    const float t = amax * bound * (1.0f / 32768.0f);
+    if (!(t > 0.f)) return 1.f;
+    int e;
+    const float m = frexpf(t, &e);
+    return ldexpf(1.f, m == 0.5f ? e - 1 : e);
+}
 
 // filter transform U = G g G^T over (k1, k2) per depth tap (double), rounded to fp32, split into three bf16 pieces and stored
 // in MFMA A-fragment order: [xi row i][xi column j][depth tap][piece][channel tile nt][lane = (n % 16) + 16 (c / 8)][c % 8],
@@ -94,6 +122,32 @@ void conv3d_wino_pack_bf3_kernel(const float* __restrict__ w_tf, unsigned short*
         us[((((((size_t)i * 4 + j) * 3 + dz) * 3 + p) * 2 + nt) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, h[p]);
 }
 
+// ... in format H2: two fp16 pieces of U / scale, [i][j][depth tap][piece][channel tile][lane][8]
+__global__ __launch_bounds__(256)
+void conv3d_wino_pack_h2_kernel(const float* __restrict__ w_tf, unsigned short* __restrict__ us, const unsigned* __restrict__ amax, int transposed)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (xi, dz, c, n)
+    if (idx >= 16 * 3 * C3 * C3) return;
+    const float inv = 1.f / c3_h2_scale(__builtin_bit_cast(float, *amax), C3_BOUND_U);
+    const int n = idx % C3, c = (idx / C3) % C3, dz = (idx / (C3 * C3)) % 3, xi = idx / (C3 * C3 * 3);
+    const int i = xi >> 2, j = xi & 3;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    double acc = 0.0;
+    for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            const float w = transposed ? w_tf[((((size_t)(2 - p) * 3 + (2 - q)) * 3 + (2 - dz)) * C3 + n) * C3 + c]
+                                       : w_tf[((((size_t)p * 3 + q) * 3 + dz) * C3 + c) * C3 + n];
+            acc = __builtin_fma(G[i][p] * G[j][q], (double)w, acc);
+        }
+    const float u = (float)acc * inv;
+    const _Float16 h0 = (_Float16)u;
+    const _Float16 h1 = (_Float16)(u - (float)h0);
+    const _Float16 h[2] = {h0, h1};
+    const int lane = (n & 15) + 16 * (c >> 3), nt = n >> 4, e = c & 7;
+    for (int p = 0; p < 2; ++p)
+        us[((((((size_t)i * 4 + j) * 3 + dz) * 2 + p) * 2 + nt) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, h[p]);
+}
+
 // 8 fp32 values (two registers quads) -> three bf16x8 pieces, round to nearest even, remainders exact
 __device__ __forceinline__ void c3_split8(const f32x4 lo, const f32x4 hi, bf16x8 (&p)[3])
 {
@@ -111,17 +165,40 @@ __device__ __forceinline__ void c3_split8(const f32x4 lo, const f32x4 hi, bf16x8
     }
 }
 
+// ... scaled by inv (a power of two) -> two f16x8 pieces
+__device__ __forceinline__ void c3_split8(const f32x4 lo, const f32x4 hi, float inv, f16x8 (&p)[2])
+{
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        f32x2 v = (e < 4 ? f32x2{lo[e], lo[e + 1]} : f32x2{hi[e - 4], hi[e - 3]}) * inv;
+        const f16x2 h0 = __builtin_convertvector(v, f16x2);
+        v -= __builtin_convertvector(h0, f32x2);
+        const f16x2 h1 = __builtin_convertvector(v, f16x2);
+        p[0][e] = h0[0]; p[0][e + 1] = h0[1];
+        p[1][e] = h1[0]; p[1][e + 1] = h1[1];
+    }
+}
+__device__ __forceinline__ void c3_split8(const f32x4 lo, const f32x4 hi, float, bf16x8 (&p)[3]) { c3_split8(lo, hi, p); }
+
 // MFMA with the filter fragment pinned to the accumulator half of the register file ("a"); `s_nop 1`: the wait states between a
 // vector write and an MFMA operand read that the compiler would insert for a builtin.  _start: C = 0 (restarts a set).
+// Format B3: 36 fragments are 144 registers, the accumulator half of a wave at two waves per SIMD has 128 -- the four fragments
+// of (tap 0, piece 2), which the first product of a set takes, live in the vector half ("v").  Format H2: 24 fragments, all "a".
 __device__ __forceinline__ void c3_mfma(f32x4& c, const bf16x8& u, const bf16x8& p)
 {
     asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(u), "v"(p));
 }
-// (the first product of a set is (u2, v0): its filter fragment is one of the four that live in the vector half -- 36 fragments
-// are 144 registers, the accumulator half of a wave at two waves per SIMD has 128)
 __device__ __forceinline__ void c3_mfma_start(f32x4& c, const bf16x8& u, const bf16x8& p)
 {
     asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(u), "v"(p));
+}
+__device__ __forceinline__ void c3_mfma(f32x4& c, const f16x8& u, const f16x8& p)
+{
+    asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(u), "v"(p));
+}
+__device__ __forceinline__ void c3_mfma_start(f32x4& c, const f16x8& u, const f16x8& p)
+{
+    asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "a"(u), "v"(p));
 }
 
 // A ds_read_b128 is conflict-free when the 16 lanes of a read group (here: the 16 tiles, at one channel quarter) hit 16 different
@@ -133,10 +210,12 @@ __device__ __forceinline__ int c3_slot_swap(int px) { return ((px >> 4) | (px >>
 #define C3_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // PROBE (timing experiments, wrong results; RN_C3_PROBE): 1 no DMA in the loop, 2 no arithmetic, 4 no epilogue, 8 no barriers
-template <int PROBE>
+template <int PROBE, class F, bool AMAX>
 __global__ __launch_bounds__(512, 1)
 void conv3d_wino_bf3_kernel(const C3Args a)
 {
+    typedef typename F::frag frag;
+    constexpr int NP = F::NP;
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [patch stage 0 | 1 | 2][exchange 0 | 1][bias, alpha]
     typedef __attribute__((address_space(3))) void lds_void;
@@ -151,18 +230,26 @@ void conv3d_wino_bf3_kernel(const C3Args a)
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.x), 0, a.x_bytes, 0x00020000);
 
     // ---- this wave's filter fragments [column jj of its pair][tap][piece][channel tile], xi = (r, 2 c + jj)
-    bf16x8 U[2][3][3][2];
+    frag U[2][3][NP][2];
     {
-        const bf16x8* up = reinterpret_cast<const bf16x8*>(a.u) + (size_t)(r * 4 + 2 * c) * (3 * 3 * 2 * 64) + lane;
+        const frag* up = reinterpret_cast<const frag*>(a.u) + (size_t)(r * 4 + 2 * c) * (3 * NP * 2 * 64) + lane;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) U[jj][dz][p][nt] = up[(((jj * 3 + dz) * 3 + p) * 2 + nt) * 64];
+                    for (int nt = 0; nt < 2; ++nt) U[jj][dz][p][nt] = up[(((jj * 3 + dz) * NP + p) * 2 + nt) * 64];
     }
+    // format H2: 1 / scale of the input tensor for the split, scale_x * scale_u for the way out (powers of two: exact)
+    float inv_x = 1.f, out_scale = 1.f;
+    if constexpr (F::ID == 1) {
+        const float sx = c3_h2_scale(__builtin_bit_cast(float, *a.amax_x), C3_BOUND_X);
+        inv_x = 1.f / sx;
+        out_scale = sx * c3_h2_scale(__builtin_bit_cast(float, *a.amax_u), C3_BOUND_U);
+    }
+    float ymax = 0.f;                                                 // max |y| of this lane's outputs (a.amax_y)
     float* tab = reinterpret_cast<float*>(smem + C3NSTG * C3STAGE + 2 * C3XCH);
     if (tid < C3) {
         tab[tid] = a.bias ? a.bias[tid] : 0.f;
@@ -273,18 +360,18 @@ void conv3d_wino_bf3_kernel(const C3Args a)
                 }
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    bf16x8 p[3];
-                    c3_split8(v[jj][0], v[jj][1], p);
-                    constexpr int PU[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};     // i + j <= 2, smallest terms first
+                    frag p[NP];
+                    c3_split8(v[jj][0], v[jj][1], inv_x, p);
+                    // the piece products of the format, smallest terms first;
                     // input slice d is tap 2 of output d - 1, tap 1 of output d, tap 0 of output d + 1 (whose set it restarts)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
+                    for (int k = 0; k < F::NPROD; ++k)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
-                            c3_mfma(acc[SP][jj][nt], U[jj][2][PU[k]][nt], p[PV[k]]);
-                            c3_mfma(acc[S][jj][nt], U[jj][1][PU[k]][nt], p[PV[k]]);
-                            if (k == 0) c3_mfma_start(acc[SN][jj][nt], U[jj][0][PU[k]][nt], p[PV[k]]);
-                            else c3_mfma(acc[SN][jj][nt], U[jj][0][PU[k]][nt], p[PV[k]]);
+                            c3_mfma(acc[SP][jj][nt], U[jj][2][F::PU[k]][nt], p[F::PV[k]]);
+                            c3_mfma(acc[S][jj][nt], U[jj][1][F::PU[k]][nt], p[F::PV[k]]);
+                            if (k == 0) c3_mfma_start(acc[SN][jj][nt], U[jj][0][F::PU[k]][nt], p[F::PV[k]]);
+                            else c3_mfma(acc[SN][jj][nt], U[jj][0][F::PU[k]][nt], p[F::PV[k]]);
                         }
                 }
             }
@@ -312,7 +399,9 @@ void conv3d_wino_bf3_kernel(const C3Args a)
                 for (int k = 0; k < 3; ++k)
                     ci[k] = *reinterpret_cast<const f32x4*>(xch + (((((dy + k) * 2 + dx) * 2 + 0) * 2 + ent) * 64 + lane) * 16)
                           + *reinterpret_cast<const f32x4*>(xch + (((((dy + k) * 2 + dx) * 2 + 1) * 2 + ent) * 64 + lane) * 16);
-                f32x4 o = (dy == 0 ? (ci[0] + ci[1]) + ci[2] : (ci[0] - ci[1]) - ci[2]) + *reinterpret_cast<const f32x4*>(tab + nch);
+                f32x4 o = (dy == 0 ? (ci[0] + ci[1]) + ci[2] : (ci[0] - ci[1]) - ci[2]);
+                if constexpr (F::ID == 1) o *= out_scale;
+                o += *reinterpret_cast<const f32x4*>(tab + nch);
                 // (the slice offset goes into the VECTOR offset: with a scalar-register offset the compiler assumes that a 16-byte
                 // store's data registers may be overwritten by the very next instruction and puts no wait state behind the store --
                 // on gfx950 that lost the first dword of lanes 12..15 of every row, now and then)
@@ -333,6 +422,7 @@ void conv3d_wino_bf3_kernel(const C3Args a)
                     for (int e = 0; e < 4; ++e) o[e] = 1.f / (1.f + __expf(-o[e]));
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, so, 0, 0);
+                if (AMAX && ooff != C3OOB) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             }
         };
         // input slices 0 .. D-1, then one more pass (d = D) that only flushes output slice D - 1
@@ -344,6 +434,11 @@ void conv3d_wino_bf3_kernel(const C3Args a)
         // the next item's first fetch overwrites stage 0, which the last arithmetic step may still be read from by a slower
         // wave: every wave has passed the barrier of the flush-only pass, which comes after all arithmetic -- safe.
     }
+    if (AMAX) {                                                       // max |y| for a consumer in format H2: one atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        if (lane == 0) atomicMax(a.amax_y, __builtin_bit_cast(unsigned, ymax));
+    }
 #endif
 }
 
@@ -353,10 +448,26 @@ bool rn_conv3d_wino_bf3_supported(int Cin, int Cout)
     return !off && Cin == C3 && Cout == C3;
 }
 
+// fmt 0: three bf16 pieces (6 bytes per filter element); fmt 1: two fp16 pieces of U / scale (4 bytes) + a 256-byte tail whose first
+// word is max|w| (bit pattern)
 size_t rn_conv3d_wino_bf3_packed_bytes() { return (size_t)16 * 3 * C3 * C3 * 3 * 2; }
+size_t rn_conv3d_wino_split_packed_bytes(int fmt) { return fmt == 1 ? (size_t)16 * 3 * C3 * C3 * 2 * 2 + 256 : rn_conv3d_wino_bf3_packed_bytes(); }
 
 int rn_launch_conv3d_wino_pack_bf3(const float* w_tf, void* us, int transposed, hipStream_t st)
 {
+    return rn_launch_conv3d_wino_split_pack(0, w_tf, us, transposed, st);
+}
+
+int rn_launch_conv3d_wino_split_pack(int fmt, const float* w_tf, void* us, int transposed, hipStream_t st)
+{
+    if (fmt == 1) {
+        unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(us) + (size_t)16 * 3 * C3 * C3 * 2 * 2);
+        const int rc = rn_launch_absmax(w_tf, (size_t)27 * C3 * C3, amax, st);
+        if (rc != RN_OK) return rc;
+        hipLaunchKernelGGL(conv3d_wino_pack_h2_kernel, dim3((16 * 3 * C3 * C3 + 255) / 256), dim3(256), 0, st, w_tf,
+                           static_cast<unsigned short*>(us), amax, transposed);
+        return rn_check_launch("conv3d_wino_pack_h2");
+    }
     hipLaunchKernelGGL(conv3d_wino_pack_bf3_kernel, dim3((16 * 3 * C3 * C3 + 255) / 256), dim3(256), 0, st, w_tf,
                        static_cast<unsigned short*>(us), transposed);
     return rn_check_launch("conv3d_wino_pack_bf3");
@@ -365,24 +476,44 @@ int rn_launch_conv3d_wino_pack_bf3(const float* w_tf, void* us, int transposed, 
 int rn_launch_conv3d_wino_bf3(const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
                               float* y, float* preact, int B, int H, int W, int D, int act, hipStream_t st)
 {
+    return rn_launch_conv3d_wino_split(0, x, us, bias, alpha, residual, y, preact, B, H, W, D, act, nullptr, nullptr, nullptr, st);
+}
+
+// fmt 1 (H2): amax_x = device word with the bit pattern of max|x| (or of a bound), or null -> a pass over x into `scratch_amax` (a device
+// word the caller provides; required when amax_x is null).  amax_y (either format, may be null): receives max|y|.
+int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
+                                float* y, float* preact, int B, int H, int W, int D, int act, const unsigned* amax_x, unsigned* scratch_amax,
+                                unsigned* amax_y, hipStream_t st)
+{
     if (B < 1 || H < 1 || W < 1 || D < 1) return rn_set_error(RN_E_INVALID, "conv3d_wino_bf3: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "conv3d_wino_bf3: PReLU needs alpha");
+    if (fmt < 0 || fmt > 1) return rn_set_error(RN_E_INVALID, "conv3d_wino_bf3: operand format %d", fmt);
     const size_t per_image = (size_t)H * W * D * C3 * 4;
     if (per_image >= 0x7fffff00ULL) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: one image exceeds the 2 GiB buffer window");
     const int chunk = (int)(0x7fffff00ULL / per_image);              // images per launch: byte offsets stay below 2^31 (the top bit = zero fill)
     const size_t lds = (size_t)C3NSTG * C3STAGE + 2 * C3XCH + C3TAB;
     static const int probe = getenv("RN_C3_PROBE") ? atoi(getenv("RN_C3_PROBE")) : 0;
-    void (*kern)(const C3Args) = conv3d_wino_bf3_kernel<0>;
-    switch (probe) {
-        case 1: kern = conv3d_wino_bf3_kernel<1>; break;
-        case 2: kern = conv3d_wino_bf3_kernel<2>; break;
-        case 4: kern = conv3d_wino_bf3_kernel<4>; break;
-        case 6: kern = conv3d_wino_bf3_kernel<6>; break;
-        case 7: kern = conv3d_wino_bf3_kernel<7>; break;
-        case 15: kern = conv3d_wino_bf3_kernel<15>; break;
-        default: break;
+    void (*kern)(const C3Args) = fmt == 1 ? (amax_y ? conv3d_wino_bf3_kernel<0, C3H2, true> : conv3d_wino_bf3_kernel<0, C3H2, false>)
+                                          : (amax_y ? conv3d_wino_bf3_kernel<0, C3B3, true> : conv3d_wino_bf3_kernel<0, C3B3, false>);
+    if (probe && fmt == 0 && !amax_y) {
+        switch (probe) {
+            case 1: kern = conv3d_wino_bf3_kernel<1, C3B3, false>; break;
+            case 2: kern = conv3d_wino_bf3_kernel<2, C3B3, false>; break;
+            case 4: kern = conv3d_wino_bf3_kernel<4, C3B3, false>; break;
+            case 6: kern = conv3d_wino_bf3_kernel<6, C3B3, false>; break;
+            case 7: kern = conv3d_wino_bf3_kernel<7, C3B3, false>; break;
+            case 15: kern = conv3d_wino_bf3_kernel<15, C3B3, false>; break;
+            default: break;
+        }
     }
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+    if (fmt == 1 && !amax_x) {
+        if (!scratch_amax) return rn_set_error(RN_E_INVALID, "conv3d_wino_bf3: format H2 needs max|x| or a word to gather it in");
+        const int rc = rn_launch_absmax(x, (size_t)B * H * W * D * C3, scratch_amax, st);
+        if (rc != RN_OK) return rc;
+        amax_x = scratch_amax;
+    }
+    if (amax_y && hipMemsetAsync(amax_y, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "conv3d_wino_bf3: memset failed");
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t off = (size_t)b0 * H * W * D * C3;
@@ -396,6 +527,8 @@ int rn_launch_conv3d_wino_bf3(const float* x, const void* us, const float* bias,
         if (nitems > 0x7fffffff) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: too many blocks");
         a.nitems = (int)nitems; a.act = act;
         a.probe = probe;
+        a.amax_x = amax_x; a.amax_y = amax_y;
+        a.amax_u = fmt == 1 ? reinterpret_cast<const unsigned*>(static_cast<const char*>(us) + (size_t)16 * 3 * C3 * C3 * 2 * 2) : nullptr;
         const unsigned grid = nitems < 256 ? (unsigned)((nitems + 7) / 8 * 8) : 256u;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
         const int rc = rn_check_launch("conv3d_wino_bf3");

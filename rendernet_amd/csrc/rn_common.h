@@ -86,6 +86,11 @@ size_t rn_conv3d_wino_bf3_packed_bytes();
 int rn_launch_conv3d_wino_pack_bf3(const float* w_tf, void* us, int transposed, hipStream_t st);
 int rn_launch_conv3d_wino_bf3(const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
                               float* y, float* preact, int B, int H, int W, int D, int act, hipStream_t st);
+size_t rn_conv3d_wino_split_packed_bytes(int fmt);
+int rn_launch_conv3d_wino_split_pack(int fmt, const float* w_tf, void* us, int transposed, hipStream_t st);
+int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
+                                float* y, float* preact, int B, int H, int W, int D, int act, const unsigned* amax_x, unsigned* scratch_amax,
+                                unsigned* amax_y, hipStream_t st);
 bool rn_wino43_wgrad_supported(int scheme, int Cin, int Cout);                                            // conv_wino43_wgrad.hip
 size_t rn_wino43_wgrad_workspace_floats(int scheme, int B, int H, int W, int Cin, int Cout);
 int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, float* dw, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t st);

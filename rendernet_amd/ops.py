@@ -51,7 +51,7 @@ class PackedWeight:
         # Every packed form is built LAZILY, on first use after the master changed: a layer that runs the Winograd kernel
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
-        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None, "wino43h": None, "wino63h": None,
+        self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None, "wino43h": None, "wino63h": None, "wino3dh": None,
                      "wino3ds": None}
         self._dirty = {k: True for k in self._buf}
         self._packed_on = {}              # form -> (stream, event recorded behind its last pack kernel)
@@ -85,14 +85,15 @@ class PackedWeight:
     def _packed(self, which, kind):
         if self._dirty[which]:
             lib = L.lib()
-            if which == "wino3ds":
-                # the bf16x3 split form of the fused 3x3x3 32 -> 32 kernel (csrc/conv3d_wino_bf3.hip), in MFMA fragment order
+            if which in ("wino3ds", "wino3dh"):
+                # a split form of the fused 3x3x3 32 -> 32 kernel (csrc/conv3d_wino_bf3.hip), in MFMA fragment order: bf16x3 | fp16x2
+                fmt = 1 if which == "wino3dh" else 0
                 if self._buf[which] is None:
-                    self._buf[which] = torch.empty(lib.rn_conv3d_winograd_split_packed_bytes(self.cin, self.cout), dtype=torch.uint8,
+                    self._buf[which] = torch.empty(lib.rn_conv3d_winograd_split_packed_bytes_ex(fmt, self.cin, self.cout), dtype=torch.uint8,
                                                    device=self.w_tf.device)
-                L.check(lib.rn_conv3d_winograd_split_pack(L.ptr(self.w_tf), ctypes.c_void_p(self._buf[which].data_ptr()), self.cin, self.cout,
-                                                          1 if self.kind == L.RN_PACK_CONVT_S1 else 0, L.stream_ptr()),
-                        "rn_conv3d_winograd_split_pack")
+                L.check(lib.rn_conv3d_winograd_split_pack_ex(fmt, L.ptr(self.w_tf), ctypes.c_void_p(self._buf[which].data_ptr()), self.cin, self.cout,
+                                                             1 if self.kind == L.RN_PACK_CONVT_S1 else 0, L.stream_ptr()),
+                        "rn_conv3d_winograd_split_pack_ex")
             elif which.endswith("s") or which.endswith("h"):
                 # a split form of the three-launch path (csrc/conv_wino_bf3.hip): `kind` is the scheme (| the operand format flag) here
                 if self._buf[which] is None:
@@ -184,13 +185,14 @@ class PackedWeight:
             return None
         return self._packed("wino43" + sfx, (L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43) | fmt)
 
-    def split3d(self):
-        """The bf16x3 split form of a 3x3x3 32 -> 32 filter for rn_conv3d_winograd_split_fwd (uint8 buffer), or None."""
+    def split3d(self, fmt=0):
+        """A split form of a 3x3x3 32 -> 32 filter for rn_conv3d_winograd_split_fwd_ex (uint8 buffer), or None.  fmt 0: three bf16
+        pieces; 1: two fp16 pieces of the scaled value."""
         if self.ndim != 3 or self.kdims != [3, 3, 3] or self._wino_kind is None:
             return None
         if not L.lib().rn_conv3d_winograd_split_supported(self.cin, self.cout):
             return None
-        return self._packed("wino3ds", 0)
+        return self._packed("wino3dh" if fmt else "wino3ds", 0)
 
     @property
     def wino4(self):
@@ -424,6 +426,7 @@ def training(ctx):
         TRAIN = old
 
 
+AMAX_MISSES = None     # diagnostics: set to a list to record the split-format-H2 launches that had to make their own pass over x
 _LAST_AMAX = None      # the device word with max|y| of the launch just made (split format H2), picked up by _Conv.forward
 STAGE_HOOK = None      # bench.py: callable(stage, (T, Cin, Cout)) -> (start_event, end_event) | None, brackets the GEMM stage
 
@@ -530,6 +533,8 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
         # format H2 scales every operand tensor by (a bound from) its max|x|: the launch that produced x left it in x._rn_amax (a device
         # word); without one the launcher makes a pass over x.  This launch leaves max|y| for the next layer the same way.
         ax = getattr(x, "_rn_amax", None) if fmt else None
+        if fmt and ax is None and AMAX_MISSES is not None:
+            AMAX_MISSES.append(("conv2d", which, Cin, Cout, H, W))
         ay = torch.empty(1, dtype=torch.int32, device=x.device) if fmt else None
         axp = ctypes.c_void_p(ax.data_ptr()) if ax is not None else None
         ayp = ctypes.c_void_p(ay.data_ptr()) if ay is not None else None
@@ -578,6 +583,25 @@ def _use_wino43(pw, H, W):
 WINO43_MIN_PIXELS = int(os.environ.get("RN_WINO43_MIN_PIXELS", "64"))
 
 
+def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st):
+    """The fused 3x3x3 32 -> 32 kernel in the split format of the mode: bf16x3 ("split"), fp16x2 ("split16": max|x| from the producing
+    launch via x._rn_amax, else a pass; max|y| left for the consumer)."""
+    global _LAST_AMAX
+    lib = L.lib()
+    fmt = 1 if WINO_GEMM == "split16" else 0
+    us = ctypes.c_void_p(pw.split3d(fmt).data_ptr())
+    if not fmt:
+        return lib.rn_conv3d_winograd_split_fwd_ex(0, L.ptr(x), us, *e, B, H, W, D, Cin, Cout, act, None, None, None, st)
+    ax = getattr(x, "_rn_amax", None)
+    if ax is None and AMAX_MISSES is not None:
+        AMAX_MISSES.append(("conv3d", Cin, Cout, H, W, D))
+    words = torch.empty(2, dtype=torch.int32, device=x.device)       # [0]: max|y| for the consumer, [1]: scratch for a pass over x
+    _LAST_AMAX = words[:1]
+    return lib.rn_conv3d_winograd_split_fwd_ex(1, L.ptr(x), us, *e, B, H, W, D, Cin, Cout, act,
+                                               ctypes.c_void_p(ax.data_ptr()) if ax is not None else None,
+                                               ctypes.c_void_p(words.data_ptr() + 4), ctypes.c_void_p(words.data_ptr()), st)
+
+
 def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     lib, st = L.lib(), L.stream_ptr()
     e = (L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))          # the epilogue arguments of every entry
@@ -585,7 +609,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
         if unit and _conv3d_split(B, H, W) and pw.split3d() is not None:
-            return lib.rn_conv3d_winograd_split_fwd(L.ptr(x), ctypes.c_void_p(pw.split3d().data_ptr()), *e, B, H, W, D, Cin, pw.cout, act, st)
+            return _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, pw.cout, act, st)
         if unit and pw.wino is not None:
             return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
         return lib.rn_conv3d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
@@ -720,8 +744,7 @@ class _Conv(torch.autograd.Function):
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
             if mode == "conv3d" and unit and _conv3d_split(B, H, W) and dp.split3d() is not None:
-                rc = lib.rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
-                                                      B, H, W, D, pw.cout, Cin, 0, st)
+                rc = _conv3d_split_launch(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d" and unit and dp.wino is not None:
                 rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
                                             B, H, W, D, pw.cout, Cin, 0, st)

@@ -31,17 +31,17 @@ def accuracy(B, H, W, D, seed=0):
     ymax = float(want.abs().max())
     xd, wd, bd, ad, rd = (torch.as_tensor(a).cuda() for a in (x, w, b, al, res))
     out = {}
-    for mode in ("f32", "split"):
-        ops.CONV3D_SPLIT = mode == "split"
+    for mode in ("f32", "split", "split16"):
+        ops.CONV3D_SPLIT = mode != "f32"
+        ops.WINO_GEMM = mode
         pw = ops.pack_conv(wd)
         with torch.no_grad():
             y = ops.conv3d(xd, pw, bd)
             yp = ops.conv3d(xd, pw, bd, ad, rd)
         out[mode] = (float((y.cpu().double() - want).abs().max()) / ymax, float((yp.cpu().double() - wantp).abs().max()) / ymax, y)
-    ops.CONV3D_SPLIT = None
-    print("B=%d %dx%dx%d: f32 %.2e / %.2e   split %.2e / %.2e   |f32-split| %.2e  (x max|y| = %.3g)"
-          % (B, H, W, D, out["f32"][0], out["f32"][1], out["split"][0], out["split"][1],
-             float((out["f32"][2] - out["split"][2]).abs().max()) / ymax, ymax), flush=True)
+    ops.CONV3D_SPLIT, ops.WINO_GEMM = None, "f32"
+    print("B=%d %dx%dx%d: f32 %.2e / %.2e   split %.2e / %.2e   split16 %.2e / %.2e   (x max|y| = %.3g)"
+          % (B, H, W, D, out["f32"][0], out["f32"][1], out["split"][0], out["split"][1], out["split16"][0], out["split16"][1], ymax), flush=True)
 
 
 def timing(B, iters):
@@ -50,8 +50,14 @@ def timing(B, iters):
     w = torch.randn((3, 3, 3, 32, 32), device="cuda", generator=g) * 0.05
     b = torch.randn(32, device="cuda", generator=g) * 0.1
     al = torch.rand(32, device="cuda", generator=g) * 0.25
-    for mode in ("f32", "split"):
-        ops.CONV3D_SPLIT = mode == "split"
+    from rendernet_amd import _lib as L
+    import ctypes
+    ax = torch.zeros(1, dtype=torch.int32, device="cuda")          # max|x| as the producing layer would have left it (format H2)
+    L.check(L.lib().rn_absmax(L.ptr(x), x.numel(), ctypes.c_void_p(ax.data_ptr()), L.stream_ptr()), "rn_absmax")
+    x._rn_amax = ax
+    for mode in ("f32", "split", "split16"):
+        ops.CONV3D_SPLIT = mode != "f32"
+        ops.WINO_GEMM = mode
         pw = ops.pack_conv(w)
         with torch.no_grad():
             for _ in range(3):
@@ -66,8 +72,8 @@ def timing(B, iters):
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1))
         fl = 2.0 * B * 64 * 64 * 32 * 32 * 32 * 12          # F(2x2,3x3) over (H,W) x 3 depth taps: 12 products per output
-        print("B=%d res1 layer, %-5s %.3f ms  (%.1f TFLOP/s fp32-equivalent executed)" % (B, mode, best, fl / best / 1e9), flush=True)
-    ops.CONV3D_SPLIT = None
+        print("B=%d res1 layer, %-7s %.3f ms  (%.1f TFLOP/s fp32-equivalent executed)" % (B, mode, best, fl / best / 1e9), flush=True)
+    ops.CONV3D_SPLIT, ops.WINO_GEMM = None, "f32"
 
 
 if __name__ == "__main__":

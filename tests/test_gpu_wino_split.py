@@ -257,12 +257,16 @@ def test_conv3d_split_pack_is_the_fp32_filter_transform_in_three_pieces():
     assert np.all(np.abs(got - p[:, :, :, 0].transpose(0, 1, 2, 4, 6, 3, 5).reshape(got.shape)) <= 2.0 ** -8 * np.abs(got) + 1e-45)
 
 
+@pytest.mark.parametrize("smode", ["split", "split16"])
 @pytest.mark.parametrize("case", C3_CASES)
-def test_conv3d_split(case, monkeypatch):
+def test_conv3d_split(case, smode, monkeypatch):
     """Forward with every epilogue, against the oracle conv (oracle/layers.py) at the bar of the fp32 kernel, and the input
-    gradient (the flipped, channel-swapped filter through the same kernel) against the oracle's transposed conv."""
+    gradient (the flipped, channel-swapped filter through the same kernel) against the oracle's transposed conv; both operand
+    formats (split16: max|x| by a pass here -- the chained hand-over is what the bench-frame and training tests exercise)."""
     from rendernet_amd import _lib as L, ops
     monkeypatch.setattr(ops, "CONV3D_SPLIT", True)
+    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    fmt = 1 if smode == "split16" else 0
     B, H, W, D = case
     rng = np.random.default_rng(hash(case) % 2**31)
     x = rng.standard_normal((B, H, W, D, 32)).astype(np.float32)
@@ -270,7 +274,7 @@ def test_conv3d_split(case, monkeypatch):
     b = (0.1 * rng.standard_normal(32)).astype(np.float32)
     alpha = rng.uniform(0, 0.25, 32).astype(np.float32)
     pw = ops.pack_conv(_dev(w))
-    assert pw.split3d() is not None
+    assert pw.split3d(fmt) is not None
     y0 = OL.conv3d(x, w, b, (1, 1, 1))
     _close(ops.conv3d(_dev(x), pw, _dev(b)), y0, "split 3-D conv", rtol=2e-6)
     _close(ops.conv3d(_dev(x), pw, None), OL.conv3d(x, w, None, (1, 1, 1)), "split 3-D conv, no bias", rtol=2e-6)
@@ -280,17 +284,24 @@ def test_conv3d_split(case, monkeypatch):
     # the pre-activation tap of the training forward
     xd, bd, ad = _dev(x), _dev(b), _dev(alpha)
     y, z = torch.empty_like(xd), torch.empty_like(xd)
-    L.check(L.lib().rn_conv3d_winograd_split_fwd(L.ptr(xd), ctypes.c_void_p(pw.split3d().data_ptr()), L.ptr(bd), L.ptr(ad), None, L.ptr(y), L.ptr(z),
-                                                 B, H, W, D, 32, 32, L.RN_ACT_PRELU, L.stream_ptr()), "rn_conv3d_winograd_split_fwd")
+    words = torch.zeros(2, dtype=torch.int32, device="cuda")
+    L.check(L.lib().rn_conv3d_winograd_split_fwd_ex(fmt, L.ptr(xd), ctypes.c_void_p(pw.split3d(fmt).data_ptr()), L.ptr(bd), L.ptr(ad), None, L.ptr(y), L.ptr(z),
+                                                    B, H, W, D, 32, 32, L.RN_ACT_PRELU, None, ctypes.c_void_p(words.data_ptr() + 4),
+                                                    ctypes.c_void_p(words.data_ptr()), L.stream_ptr()), "rn_conv3d_winograd_split_fwd_ex")
+    # max|y| gathered by the launch (for the next layer's scale) and, in format H2, max|x| from the launcher's pass
+    assert words[:1].view(torch.float32).item() == float(y.abs().max())
+    if fmt:
+        assert words[1:].view(torch.float32).item() == float(xd.abs().max())
     _close(z, y0, "split 3-D pre-activation", rtol=2e-6)
     _close(y, OL.prelu(y0, alpha), "split 3-D PReLU", rtol=2e-6)
     # input gradient
     dp = pw.dgrad_pack(True)
-    assert dp.split3d() is not None
+    assert dp.split3d(fmt) is not None
     dz = _dev(rng.standard_normal((B, H, W, D, 32)).astype(np.float32))
     dx = torch.empty_like(dz)
-    L.check(L.lib().rn_conv3d_winograd_split_fwd(L.ptr(dz), ctypes.c_void_p(dp.split3d().data_ptr()), None, None, None, L.ptr(dx), None,
-                                                 B, H, W, D, 32, 32, 0, L.stream_ptr()), "rn_conv3d_winograd_split_fwd (dgrad)")
+    L.check(L.lib().rn_conv3d_winograd_split_fwd_ex(fmt, L.ptr(dz), ctypes.c_void_p(dp.split3d(fmt).data_ptr()), None, None, None, L.ptr(dx), None,
+                                                    B, H, W, D, 32, 32, 0, None, ctypes.c_void_p(words.data_ptr() + 4), None, L.stream_ptr()),
+            "rn_conv3d_winograd_split_fwd_ex (dgrad)")
     _close(dx, OL.conv3d_transpose(dz.cpu().numpy(), w, None, (1, 1, 1)), "split 3-D dgrad", rtol=2e-6)
 
 
