@@ -53,7 +53,7 @@ def build_parser():
                         help='.npz of weights keyed by TF variable names, or the reference\'s frozen graph `*.pb` '
                              '(its Const nodes are read without TensorFlow); default: seeded random initialisation')
     parser.add_argument('--batch', type=int, default=24, help='poses rendered per launch with --rotate')
-    parser.add_argument('--gemm', choices=['f32', 'split'], default='f32',
+    parser.add_argument('--gemm', choices=['f32', 'split', 'split16'], default='f32',
                         help='multiply stage of the wide 2-D convs: exact-fp32 MFMA, or the bf16x3 split route (fp32 accuracy on '
                              'the 16x faster bf16 matrix pipe; include/rendernet_hip.h, rn_conv2d_winograd_split_fwd)')
     parser.add_argument('--no_winograd_check', action='store_true',
