@@ -524,7 +524,7 @@ extern "C" int rn_winograd_output_transform_ex(int scheme, const float* M, const
     if (!M || !y) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: null pointer");
     if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 != 0) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_winograd_output_transform_ex: PReLU needs alpha");
-    if (amax_y && hipMemsetAsync(amax_y, 0, 4, (hipStream_t)stream) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "rn_winograd_output_transform_ex: memset failed");
+    if (amax_y) { const int rc = rn_launch_word(static_cast<unsigned*>(amax_y), nullptr, (hipStream_t)stream); if (rc != RN_OK) return rc; }
     return rn_launch_wino_output_amax(scheme, M, bias, alpha, residual, y, preact, B, H, W, C, act, static_cast<unsigned*>(amax_y), (hipStream_t)stream);
 }
 extern "C" int rn_absmax(const float* x, long long n, void* amax, void* stream)

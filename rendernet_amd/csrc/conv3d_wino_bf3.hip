@@ -513,7 +513,7 @@ int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const f
         if (rc != RN_OK) return rc;
         amax_x = scratch_amax;
     }
-    if (amax_y && hipMemsetAsync(amax_y, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "conv3d_wino_bf3: memset failed");
+    if (amax_y) { const int rc = rn_launch_word(amax_y, nullptr, st); if (rc != RN_OK) return rc; }
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t off = (size_t)b0 * H * W * D * C3;

@@ -304,6 +304,11 @@ template <class S> struct H2Bound {
     }
 };
 
+// *dst = src ? *src : 0.  The hand-over words are set and copied by a one-thread KERNEL, not by hipMemsetAsync / hipMemcpyAsync:
+// inside a captured hipGraph the memset / memcpy nodes of this ROCm were seen to run out of order with the kernels around them
+// (replays with new inputs used the previous replay's maxima: tests/test_gpu_wino_split.py::test_hipgraph_replay_of_the_split_routes).
+__global__ void word_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) { *dst = src ? *src : 0u; }
+
 // max |x| over n floats (n % 4 == 0, 16-byte aligned) into *out (bit pattern of a non-negative float: unsigned order = float order;
 // *out must be zero before the launch)
 __global__ __launch_bounds__(256)
@@ -739,10 +744,16 @@ inline float h2_bound_u(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>:
 int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st) { return rn_launch_absmax(x, n, out, st); }
 }  // namespace
 
+int rn_launch_word(unsigned* dst, const unsigned* src, hipStream_t st)
+{
+    hipLaunchKernelGGL(word_kernel, dim3(1), dim3(1), 0, st, dst, src);
+    return rn_check_launch("word");
+}
+
 int rn_launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
 {
     if (n % 4 != 0) return rn_set_error(RN_E_INVALID, "absmax: %zu floats", n);
-    if (hipMemsetAsync(out, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "absmax: memset failed");
+    { const int rc = rn_launch_word(out, nullptr, st); if (rc != RN_OK) return rc; }
     const size_t n4 = n / 4;
     const unsigned blocks = (unsigned)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, out);
@@ -824,7 +835,8 @@ int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int
     if (fmt == 1) {
         unsigned* amax = reinterpret_cast<unsigned*>(v + h2_v_data(scheme, T, C));
         if (amax_x) {
-            if (hipMemcpyAsync(amax, amax_x, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "wino_input_h2: copy of max|x| failed");
+            const int rc = rn_launch_word(amax, amax_x, st);
+            if (rc != RN_OK) return rc;
         } else {
             const int rc = launch_absmax(x, (size_t)B * H * W * C, amax, st);
             if (rc != RN_OK) return rc;
@@ -1012,6 +1024,6 @@ int rn_launch_conv_wino_bf3_ex(int scheme, const float* x, const void* us, const
                                const unsigned* amax_x, unsigned* amax_y, hipStream_t st)
 {
     if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "conv_wino_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
-    if (amax_y && hipMemsetAsync(amax_y, 0, 4, st) != hipSuccess) return rn_set_error(RN_E_LAUNCH, "conv_wino_bf3: memset failed");
+    if (amax_y) { const int rc = rn_launch_word(amax_y, nullptr, st); if (rc != RN_OK) return rc; }
     return conv_wino_bf3_rec(scheme, x, us, bias, alpha, residual, y, preact, ws, B, H, W, Cin, Cout, pad_lo, act, amax_x, amax_y, st);
 }

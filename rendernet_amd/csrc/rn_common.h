@@ -69,6 +69,7 @@ size_t rn_wino_bf3_v_bytes(int scheme, long long T, int Cin);
 size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout);
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st);
 int rn_launch_wino_input_bf3(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, hipStream_t st);
+int rn_launch_word(unsigned* dst, const unsigned* src, hipStream_t st);                                                   // *dst = src ? *src : 0, as a kernel (graph-safe)
 int rn_launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st);                                           // *out = bits of max|x| (n % 4 == 0)
 int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, const unsigned* amax_x, hipStream_t st);
 int rn_launch_conv_wino_bf3_ex(int scheme, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,

@@ -461,3 +461,26 @@ def test_split_routes_batch_chunks(monkeypatch):
     want = OL.conv2d(x.cpu().numpy(), w.cpu().numpy(), None, (1, 1))
     _close(chunk43, want, "chunked split F(4x4,3x3)")
     _close(chunk63, want, "chunked split F(6x6,3x3)")
+
+
+@pytest.mark.parametrize("smode", ["split", "split16"])
+def test_hipgraph_replay_of_the_split_routes(fixtures_vox, smode, monkeypatch):
+    """Renderer.capture at full width in the split modes: the memsets, the 4-byte max|x| copies and the atomic maxima of the fp16x2
+    route are stream operations like the kernels -- the captured graph replays to the bits of the eager launches, for new inputs too
+    (the maxima are order-independent, so the route is deterministic)."""
+    from rendernet_amd import ops
+    from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
+    from bench import synthetic_batch
+    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    spec = ShaderSpec().check()
+    r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True), device="cuda:0")
+    vox, poses = synthetic_batch(24)
+    r.render(vox[:2], poses[:2])                                   # packs (and the F(6x6,3x3) self-check) happen outside the capture
+    replay = r.capture(2)
+    for sl in (slice(0, 2), slice(7, 9)):
+        want = r.render(vox[sl], poses[sl])
+        got = replay(vox[sl], poses[sl])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    del r, replay
+    torch.cuda.empty_cache()
