@@ -532,7 +532,7 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
         wsp = ctypes.c_void_p(ws.data_ptr())
         # format H2 scales every operand tensor by (a bound from) its max|x|: the launch that produced x left it in x._rn_amax (a device
         # word); without one the launcher makes a pass over x.  This launch leaves max|y| for the next layer the same way.
-        ax = getattr(x, "_rn_amax", None) if fmt else None
+        ax = _amax_of(x) if fmt else None
         if fmt and ax is None and AMAX_MISSES is not None:
             AMAX_MISSES.append(("conv2d", which, Cin, Cout, H, W))
         ay = torch.empty(1, dtype=torch.int32, device=x.device) if fmt else None
@@ -583,6 +583,16 @@ def _use_wino43(pw, H, W):
 WINO43_MIN_PIXELS = int(os.environ.get("RN_WINO43_MIN_PIXELS", "64"))
 
 
+def _amax_of(x):
+    """The device word with max|x| that the launch which produced x left on it (split format H2) -- only while x is what that launch
+    wrote: an in-place change bumps the tensor's version counter and the word is ignored (the launcher then makes its own pass)."""
+    tag = getattr(x, "_rn_amax", None)
+    if tag is None:
+        return None
+    word, version = tag
+    return word if x._version == version else None
+
+
 def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st):
     """The fused 3x3x3 32 -> 32 kernel in the split format of the mode: bf16x3 ("split"), fp16x2 ("split16": max|x| from the producing
     launch via x._rn_amax, else a pass; max|y| left for the consumer)."""
@@ -592,7 +602,7 @@ def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st):
     us = ctypes.c_void_p(pw.split3d(fmt).data_ptr())
     if not fmt:
         return lib.rn_conv3d_winograd_split_fwd_ex(0, L.ptr(x), us, *e, B, H, W, D, Cin, Cout, act, None, None, None, st)
-    ax = getattr(x, "_rn_amax", None)
+    ax = _amax_of(x)
     if ax is None and AMAX_MISSES is not None:
         AMAX_MISSES.append(("conv3d", Cin, Cout, H, W, D))
     words = torch.empty(2, dtype=torch.int32, device=x.device)       # [0]: max|y| for the consumer, [1]: scratch for a pass over x
@@ -664,7 +674,7 @@ class _Conv(torch.autograd.Function):
         _LAST_AMAX = None
         L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act), "rn_%s_fwd" % mode)
         if _LAST_AMAX is not None:
-            y._rn_amax, _LAST_AMAX = _LAST_AMAX, None
+            y._rn_amax, _LAST_AMAX = (_LAST_AMAX, y._version), None
         if ev is not None:
             ev[1].record()
         if train:

@@ -54,7 +54,7 @@ def timing(B, iters):
     import ctypes
     ax = torch.zeros(1, dtype=torch.int32, device="cuda")          # max|x| as the producing layer would have left it (format H2)
     L.check(L.lib().rn_absmax(L.ptr(x), x.numel(), ctypes.c_void_p(ax.data_ptr()), L.stream_ptr()), "rn_absmax")
-    x._rn_amax = ax
+    x._rn_amax = (ax, x._version)
     for mode in ("f32", "split", "split16"):
         ops.CONV3D_SPLIT = mode != "f32"
         ops.WINO_GEMM = mode

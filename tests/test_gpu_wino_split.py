@@ -484,3 +484,29 @@ def test_hipgraph_replay_of_the_split_routes(fixtures_vox, smode, monkeypatch):
         assert torch.equal(got, want)
     del r, replay
     torch.cuda.empty_cache()
+
+
+def test_split16_amax_handover_and_its_guard(monkeypatch):
+    """fp16x2 route: a layer's launch leaves max|y| on its output (ops: y._rn_amax = (device word, tensor version)); the next layer takes
+    its scale from it instead of a pass over x -- unless the tensor was changed in place since, which the version counter shows."""
+    from rendernet_amd import ops
+    monkeypatch.setattr(ops, "WINO_GEMM", "split16")
+    monkeypatch.setattr(ops, "WINO43_MIN_PIXELS", 1)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 24, 24, 256)).astype(np.float32)
+    w1, w2 = _xavier(rng, (3, 3, 256, 256)), _xavier(rng, (3, 3, 256, 256))
+    misses = []
+    monkeypatch.setattr(ops, "AMAX_MISSES", misses)
+    with torch.no_grad():
+        h = ops.conv2d(_dev(x), ops.pack_conv(_dev(w1)))
+        word, version = h._rn_amax
+        assert word.view(torch.float32).item() == float(h.abs().max()) and version == h._version
+        assert len(misses) == 1                                       # x came from nowhere: one pass
+        y = ops.conv2d(h, ops.pack_conv(_dev(w2)))
+        assert len(misses) == 1                                       # h brought its maximum along
+        _close(y, OL.conv2d(h.cpu().numpy(), w2, None, (1, 1)), "chained split16 conv")
+        h.mul_(1000.0)                                                # 1000 x the recorded maximum: the stale scale would overflow fp16
+        y2 = ops.conv2d(h, ops.pack_conv(_dev(w2)))
+        assert len(misses) == 2                                       # version changed: the launcher looked again
+        assert bool(torch.isfinite(y2).all())
+        _close(y2, OL.conv2d(h.cpu().numpy(), w2, None, (1, 1)), "split16 conv after an in-place change")
