@@ -346,51 +346,58 @@ def train_main(args, world, rank, local_rank):
     assert np.isfinite(lossv)
     # the same steps with the multiply stages of the wide 2-D convs (forward, input gradient and, at >= 1024 channels, filter gradient) and of the 3-D encoder
     # on the bf16 pipe by operand splitting: a second trainer from the same initial weights, checked against the same golden
-    alt = None
+    alts = {}
     if not args.no_alt and args.gemm == "f32":
         del tr
-        torch.cuda.empty_cache()
-        ops.WINO_GEMM = "split"
-        try:
-            tr2 = Trainer(spec, weights, device="cuda:%d" % local_rank)
-            parity2 = train_parity(tr2, spec, world)
-            for i in range(max(1, args.warmup)):
-                tr2.step(vox, poses, targets, patch_size=p, start_point=starts[i])
-            alt_events = {"gemm": [], "wgrad": []}
+        for akey, gm in ALT_MODES:
+            torch.cuda.empty_cache()
+            ops.WINO_GEMM = gm
+            try:
+                tr2 = Trainer(spec, weights, device="cuda:%d" % local_rank)
+                parity2 = train_parity(tr2, spec, world)
+                for i in range(max(1, args.warmup)):
+                    tr2.step(vox, poses, targets, patch_size=p, start_point=starts[i])
+                alt_events = {"gemm": [], "wgrad": []}
 
-            def alt_hook(stage, tkn):
-                if stage in alt_events and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    alt_events[stage].append((ev, tkn))
-                    return ev
-                return None
+                def alt_hook(stage, tkn):
+                    if stage in alt_events and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        alt_events[stage].append((ev, tkn))
+                        return ev
+                    return None
 
-            ops.STAGE_HOOK = alt_hook
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                loss2 = tr2.step(vox, poses, targets, patch_size=p, start_point=starts[args.warmup + i])
-            barrier()
-            el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
-        finally:
-            ops.WINO_GEMM = "f32"
-            ops.STAGE_HOOK = None
-        alt = {"dtype": "bf16x3-split, fp32 accumulate (forward, input-gradient and -- on the layers at least 1024 channels wide -- filter-gradient "
-                        "multiply stages of the wide 2-D convs, and the 3-D encoder's convs; everything else exact fp32)",
-               "value": round(B * world * args.steps / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
-               "speedup_vs_value": round(elapsed / el2, 4), "final_loss": float(loss2.item()), "parity": parity2}
-        peak6 = PEAK_BF16_MFMA_TFLOPS / 6.0
-        for stage, key, what in (("gemm", "roofline", "wino_gemm_bf3_kernel, forward and input gradient of the res2 layers"),
-                                 ("wgrad", "roofline_wgrad", "rn_conv2d_winograd_split_wgrad on the res2 layers: wino_input_bf3t + wino_dout_bf3t + "
-                                                              "wino_gemm_bf3 (rows = input channels, K = tiles) + wino_dfilter_bf3, all four launches")):
-            if alt_events[stage]:
-                ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in alt_events[stage]]))
-                Ta = alt_events[stage][0][1][0]
-                fla = 2.0 * 36 * Ta * spec.w_res2 * spec.w_res2
-                alt[key] = {"kernel": what, "bound": "mfma", "achieved": round(fla / (ms * 1e-3) / 1e12, 2), "peak": round(peak6, 2), "unit": "TFLOP/s",
-                            "frac": round(fla / (ms * 1e-3) / 1e12 / peak6, 4), "avg_ms": round(ms, 4), "calls_timed": len(alt_events[stage]),
-                            "peak_name": "dense bf16 MFMA peak / 6 (six bf16 piece products per fp32 product)",
-                            "flop_basis": "fp32-equivalent FLOPs = 2*36*T*Cin*Cout, T = %d tiles" % Ta, "traffic": None}
+                ops.STAGE_HOOK = alt_hook
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    loss2 = tr2.step(vox, poses, targets, patch_size=p, start_point=starts[args.warmup + i])
+                barrier()
+                el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
+                loss2 = float(loss2.item())
+            finally:
+                ops.WINO_GEMM = "f32"
+                ops.STAGE_HOOK = None
+            del tr2
+            h2 = gm == "split16"
+            alt = {"dtype": ALT_DTYPE[gm] + " (forward and input-gradient multiply stages of the wide 2-D convs and of the 3-D encoder's convs"
+                            + ("; filter gradients of the layers at least 1024 channels wide: bf16x3-split" if h2 else
+                               "; filter gradients of the layers at least 1024 channels wide too") + "; everything else exact fp32)",
+                   "value": round(B * world * args.steps / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
+                   "speedup_vs_value": round(elapsed / el2, 4), "final_loss": loss2, "parity": parity2}
+            for stage, key, what, nprod in (
+                    ("gemm", "roofline", "wino_gemm_bf3_kernel<%s>, forward and input gradient of the res2 layers" % ("rnf::FmtH2" if h2 else "rnf::FmtB3"), 3 if h2 else 6),
+                    ("wgrad", "roofline_wgrad", "rn_conv2d_winograd_split_wgrad on the res2 layers: wino_input_bf3t + wino_dout_bf3t + "
+                                                "wino_gemm_bf3 (rows = input channels, K = tiles) + wino_dfilter_bf3, all four launches", 6)):
+                if alt_events[stage]:
+                    ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in alt_events[stage]]))
+                    Ta = alt_events[stage][0][1][0]
+                    fla = 2.0 * 36 * Ta * spec.w_res2 * spec.w_res2
+                    pk = PEAK_BF16_MFMA_TFLOPS / nprod
+                    alt[key] = {"kernel": what, "bound": "mfma", "achieved": round(fla / (ms * 1e-3) / 1e12, 2), "peak": round(pk, 2), "unit": "TFLOP/s",
+                                "frac": round(fla / (ms * 1e-3) / 1e12 / pk, 4), "avg_ms": round(ms, 4), "calls_timed": len(alt_events[stage]),
+                                "peak_name": "dense 16-bit MFMA peak / %d (%d piece products per fp32 product)" % (nprod, nprod),
+                                "flop_basis": "fp32-equivalent FLOPs = 2*36*T*Cin*Cout, T = %d tiles" % Ta, "traffic": None}
+            alts[akey] = alt
     if rank == 0:
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
         fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2
@@ -436,13 +443,14 @@ def train_main(args, world, rank, local_rank):
                        "global_batch": B * world, "patch": p, "parallelism": "data-parallel x%d, RCCL sum all-reduce" % world},
             "direct_equiv_tflops_per_gpu": round(3.0 * fwd_tflop * sps / world, 2),
             "roofline": roof, **({"roofline_wgrad": roof_w} if roof_w is not None else {}),
-            "final_loss": lossv, "parity": parity, **({"alt": alt} if alt is not None else {}),
+            "final_loss": lossv, "parity": parity, **alts,
             **({"cpu_baseline": cpu_baseline_train(weights, p)} if (world == 1 and not args.no_cpu_baseline) else {}),
             **per_rank_fields(by_rank, [B] * world, args.steps)}), flush=True)
         if parity is not None and not parity["ok"]:
             raise SystemExit("PARITY FAILURE (training step): %s" % json.dumps(parity))
-        if alt is not None and not alt["parity"]["ok"]:
-            raise SystemExit("PARITY FAILURE (training step, split GEMM stage): %s" % json.dumps(alt["parity"]))
+        for akey, ablk in alts.items():
+            if not ablk["parity"]["ok"]:
+                raise SystemExit("PARITY FAILURE (training step, %s): %s" % (akey, json.dumps(ablk["parity"])))
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -7,7 +7,9 @@
 // input channels (the three depth taps), done as Winograd F(2x2,3x3) over (H,W): Y = A^T [ sum_{dz,c} U[xi][dz][c][n] .* V[xi][dz][c] ] A,
 // 16 xi planes, V = B^T d B of the 4x4 input tile.  What changes is the multiply: every fp32 V and U value is the exact sum of
 // three bf16 pieces and a product is the six piece products with i + j <= 2 on v_mfma_f32_16x16x32_bf16, fp32 accumulate
-// (conv_wino_bf3.hip explains the arithmetic; same error class as an fp32 FMA chain).
+// (conv_wino_bf3.hip explains the arithmetic; same error class as an fp32 FMA chain).  The kernel is a template on the operand
+// format: C3B3 as described, C3H2 = two fp16 pieces of value / power-of-two tensor scale and three products (24 filter fragments per
+// wave, all in the accumulator half; 36 MFMAs per step; scales from max|x| of the tensor, handed over by the producing launch).
 //
 // Design for gfx950 -- what is different from the fp32 kernel and why:
 //   * K is only 96 and N only 32, so per MFMA the FILTER fragments are as large as the data fragments: streaming U through

@@ -674,7 +674,7 @@ class _Conv(torch.autograd.Function):
         _LAST_AMAX = None
         L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act), "rn_%s_fwd" % mode)
         if _LAST_AMAX is not None:
-            y._rn_amax, _LAST_AMAX = (_LAST_AMAX, y._version), None
+            y._rn_amax = (_LAST_AMAX, y._version)                    # (_conv_apply repeats this on what autograd hands back)
         if ev is not None:
             ev[1].record()
         if train:
@@ -799,7 +799,12 @@ def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, elu=
         # inference: no graph to record -- skip the autograd.Function machinery (at batch 1 the 80 launches of a render
         # are host-bound; this is a fifth of the per-launch cost)
         return _Conv.forward(None, x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, None, elu)
-    return _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu)
+    global _LAST_AMAX
+    out = _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu)
+    if _LAST_AMAX is not None and getattr(out, "_rn_amax", None) is None:
+        out._rn_amax = (_LAST_AMAX, out._version)                   # autograd returned another tensor object for the same storage
+    _LAST_AMAX = None
+    return out
 
 
 def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False, elu=False):

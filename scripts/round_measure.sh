@@ -47,6 +47,7 @@ bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 --n
 bash scripts/profile_bench.sh ${TAG}_render_split --gemm split --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_render_split16 --gemm split16 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_train_split --mode train --gemm split --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_train_split16 --mode train --gemm split16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline --no-alt > /dev/null 2>&1
 tail -3 "$O/${TAG}_bench.err"
 cut -c1-250 "$O/${TAG}_bench.json"

@@ -404,12 +404,12 @@ def test_split_wgrad_plan():
     assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 256, 256) == 108 * 512 * 512 * 6 + 108 * 256 * 256 * 4 + 256
 
 
-@pytest.mark.parametrize("mode", ["f32", "split"])
+@pytest.mark.parametrize("mode", ["f32", "split", "split16"])
 def test_full_width_training_step_against_the_float64_golden(mode, monkeypatch):
     """BASELINE configs[3] at full width (237M parameters, crop 64, two samples): loss, prediction and sampled gradient entries of all
     166 variables against tests/golden/train_step_golden.npz (float64 torch-CPU autograd over the oracle graph) -- the check bench.py
-    runs on its train line, here for both multiply routes.  In split mode the forward, input-gradient, 3-D encoder and (>= 1024
-    channels) filter-gradient stages all run on the bf16 pipe; the bars are the same."""
+    runs on its train line, here for all three multiply routes.  In the split modes the forward, input-gradient, 3-D encoder and (>= 1024
+    channels) filter-gradient stages all run on the 16-bit pipe; the bars are the same."""
     import bench
     from rendernet_amd import ops
     from rendernet_amd.shader import ShaderSpec, init_shader_weights
