@@ -502,7 +502,7 @@ ALT_WHAT = {
     "split16": "as `alt`, but the wide 2-D convs take every operand as TWO fp16 pieces of value / scale (scale = a power of two from max|x| "
                "of the tensor, gathered by the producing launch, and the transform's growth bound) and three piece products (h0h0, h0h1, "
                "h1h0): half the matrix work; operands carry 22 mantissa bits, the fp32 accumulation all routes share dominates the error "
-               "(profiles: hostile-statistics table); the 3-D encoder as in `alt`",
+               "(profiles: hostile-statistics table); the 3-D encoder's convs in the same format (csrc/conv3d_wino_bf3.hip, C3H2)",
 }
 
 
