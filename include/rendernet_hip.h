@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 190            /* 0.1.9: + the multiply stages on the bf16 pipe at fp32 accuracy (rn_winograd_split_*, rn_conv2d_winograd_split_fwd, rn_conv3d_winograd_split_*) */
+#define RN_VERSION 191            /* 0.1.91: + the multiply stages on the 16-bit pipe at fp32-class accuracy (rn_winograd_split_*, rn_conv2d_winograd_split_fwd / _wgrad, rn_conv3d_winograd_split_*; RN_SPLIT_FMT_H2, the *_ex entries, rn_absmax) */
 
 /* error codes */
 #define RN_OK              0
