@@ -53,9 +53,11 @@ def build_parser():
                         help='.npz of weights keyed by TF variable names, or the reference\'s frozen graph `*.pb` '
                              '(its Const nodes are read without TensorFlow); default: seeded random initialisation')
     parser.add_argument('--batch', type=int, default=24, help='poses rendered per launch with --rotate')
-    parser.add_argument('--gemm', choices=['f32', 'split', 'split16'], default='f32',
-                        help='multiply stage of the wide 2-D convs: exact-fp32 MFMA, or the bf16x3 split route (fp32 accuracy on '
-                             'the 16x faster bf16 matrix pipe; include/rendernet_hip.h, rn_conv2d_winograd_split_fwd)')
+    parser.add_argument('--gemm', choices=['f32', 'split', 'split16'], default=None,
+                        help='multiply stage of the wide convs: default = the library default (`split`: every fp32 operand as three '
+                             'bf16 pieces that sum exactly to it, six piece products, fp32 accumulation -- fp32-class error on the '
+                             '16x faster bf16 matrix pipe; include/rendernet_hip.h, rn_conv2d_winograd_split_fwd; env RN_WINO_GEMM); '
+                             '`f32` = exact-fp32 MFMA everywhere; `split16` = two fp16 pieces of value / tensor scale (22-bit operands)')
     parser.add_argument('--no_winograd_check', action='store_true',
                         help='weights given with --weights are checked once against F(4x4,3x3) where the net would take F(6x6,3x3) '
                              '(Renderer.validate_winograd, tolerance 2e-4 of max|y| per layer); this flag skips the check')
@@ -109,7 +111,8 @@ def main(argv=None):
         weights = init_shader_weights(spec, seed=1234)
     renderer = Renderer(spec, weights)
     from rendernet_amd import ops
-    ops.WINO_GEMM = args.gemm
+    if args.gemm is not None:
+        ops.WINO_GEMM = args.gemm
 
     if not os.path.exists(args.render_dir):
         os.makedirs(args.render_dir)

@@ -290,6 +290,46 @@ def cpu_baseline_train(weights, patch):
                       "237M parameters on %d threads of a %d-core host: %.1f s (loss %.1f)" % (patch, cores, ncpu, dt, loss)}
 
 
+TRAIN_DTYPE = {
+    "f32": "f32",
+    "split": "f32 (forward and input-gradient multiply stages of the wide 2-D convs and of the 3-D encoder's convs, and the filter gradients of the "
+             "layers at least 1024 channels wide: bf16x3-split operands, fp32 accumulate; everything else exact fp32)",
+    "split16": "f32 (forward and input-gradient multiply stages of the wide 2-D convs and of the 3-D encoder's convs: fp16x2-split operands of value / "
+               "tensor scale, 22-bit, fp32 accumulate; filter gradients of the layers at least 1024 channels wide: bf16x3-split; everything else exact fp32)"}
+
+
+def train_stage_roofline(events, stage, gemm_mode, width):
+    """`roofline` (stage "gemm": the GEMM stage of the forward / input-gradient launches on the res2 layers) or `roofline_wgrad` (stage
+    "wgrad": ALL launches of the filter gradient of the same layers) of one timed training pass, priced per mode: exact fp32 against the fp32
+    MFMA peak; bf16x3 against bf16 peak / 6; fp16x2 against fp16 peak / 3 (the filter gradient has no fp16x2 form: bf16x3 in both split modes)."""
+    if not events:
+        return None
+    ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in events]))
+    T, which = events[0][1][0], events[0][1][3]
+    nxi, fname = WINO_SCHEMES.get(which.rstrip("s"), (36, "F(4x4,3x3)"))
+    fl = 2.0 * nxi * T * width * width
+    if stage == "wgrad":
+        nprod = 6 if gemm_mode in ("split", "split16") else 0
+        kern = ("rn_conv2d_winograd_split_wgrad: wino_input_bf3t + wino_dout_bf3t + wino_gemm_bf3 (rows = input channels, K = tiles) + wino_dfilter_bf3, "
+                "all four launches" if nprod else
+                "rn_conv2d_wino43_wgrad: wino_input_kernel + wino_dout_kernel + wino43_wgrad_gemm_kernel (+ reduce) + wino_dfilter_kernel, all launches")
+    else:
+        nprod = {"f32": 0, "split": 6, "split16": 3}[gemm_mode]
+        kern = {"f32": "wino43_gemm_kernel (exact-fp32 MFMA)", "split": "wino_gemm_bf3_kernel<rnf::FmtB3>",
+                "split16": "wino_gemm_bf3_kernel<rnf::FmtH2>"}[gemm_mode] + ", GEMM stage of the forward and input-gradient launches"
+    peak = PEAK_BF16_MFMA_TFLOPS / nprod if nprod else PEAK_FP32_MFMA_TFLOPS
+    ach = fl / (ms * 1e-3) / 1e12
+    r = {"kernel": "%s; Winograd %s on the res2 3x3 %d->%d conv, T = %d tiles" % (kern, fname, width, width, T),
+         "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 2), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+         "avg_ms": round(ms, 4), "calls_timed": len(events), "flop_per_call": fl,
+         "flop_basis": ("fp32-equivalent FLOPs = 2*%d*T*Cin*Cout, each executed as %d 16-bit piece products" % (nxi, nprod)) if nprod
+                       else "executed MFMA FLOPs = 2*%d*T*Cin*Cout" % nxi,
+         "traffic": None}
+    if nprod:
+        r["peak_name"] = "dense 16-bit MFMA peak / %d (%d piece products per fp32 product)" % (nprod, nprod)
+    return r
+
+
 # ----------------------------------------------------------------------------------------------------------------
 def train_main(args, world, rank, local_rank):
     """BASELINE configs[3]: Phong-shader training step, batch 24 per GPU (global batch 24*N), crop `--patch`,
@@ -301,7 +341,8 @@ def train_main(args, world, rank, local_rank):
     spec = ShaderSpec().check()
     weights = init_shader_weights(spec, seed=1234, perturb=True)
     from rendernet_amd import ops
-    ops.WINO_GEMM = args.gemm                      # --gemm split: the whole run in split mode (profiling); no alt pass then
+    LIB_DEFAULT_MODE = ops.WINO_GEMM
+    ops.WINO_GEMM = args.gemm                      # the primary mode (default: the library default, "split")
     tr = Trainer(spec, weights, device="cuda:%d" % local_rank)
     B, p = args.batch, args.patch
     vox_np, poses_np = synthetic_batch(B)
@@ -347,9 +388,9 @@ def train_main(args, world, rank, local_rank):
     # the same steps with the multiply stages of the wide 2-D convs (forward, input gradient and, at >= 1024 channels, filter gradient) and of the 3-D encoder
     # on the bf16 pipe by operand splitting: a second trainer from the same initial weights, checked against the same golden
     alts = {}
-    if not args.no_alt and args.gemm == "f32":
+    if not args.no_alt:
         del tr
-        for akey, gm in ALT_MODES:
+        for akey, gm in other_modes(args.gemm):
             torch.cuda.empty_cache()
             ops.WINO_GEMM = gm
             try:
@@ -375,68 +416,28 @@ def train_main(args, world, rank, local_rank):
                 el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
                 loss2 = float(loss2.item())
             finally:
-                ops.WINO_GEMM = "f32"
+                ops.WINO_GEMM = LIB_DEFAULT_MODE
                 ops.STAGE_HOOK = None
             del tr2
-            h2 = gm == "split16"
-            alt = {"dtype": ALT_DTYPE[gm] + " (forward and input-gradient multiply stages of the wide 2-D convs and of the 3-D encoder's convs"
-                            + ("; filter gradients of the layers at least 1024 channels wide: bf16x3-split" if h2 else
-                               "; filter gradients of the layers at least 1024 channels wide too") + "; everything else exact fp32)",
+            alt = {"dtype": TRAIN_DTYPE[gm], "gemm_mode": gm,
                    "value": round(B * world * args.steps / el2, 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
                    "speedup_vs_value": round(elapsed / el2, 4), "final_loss": loss2, "parity": parity2}
-            for stage, key, what, nprod in (
-                    ("gemm", "roofline", "wino_gemm_bf3_kernel<%s>, forward and input gradient of the res2 layers" % ("rnf::FmtH2" if h2 else "rnf::FmtB3"), 3 if h2 else 6),
-                    ("wgrad", "roofline_wgrad", "rn_conv2d_winograd_split_wgrad on the res2 layers: wino_input_bf3t + wino_dout_bf3t + "
-                                                "wino_gemm_bf3 (rows = input channels, K = tiles) + wino_dfilter_bf3, all four launches", 6)):
-                if alt_events[stage]:
-                    ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in alt_events[stage]]))
-                    Ta = alt_events[stage][0][1][0]
-                    fla = 2.0 * 36 * Ta * spec.w_res2 * spec.w_res2
-                    pk = PEAK_BF16_MFMA_TFLOPS / nprod
-                    alt[key] = {"kernel": what, "bound": "mfma", "achieved": round(fla / (ms * 1e-3) / 1e12, 2), "peak": round(pk, 2), "unit": "TFLOP/s",
-                                "frac": round(fla / (ms * 1e-3) / 1e12 / pk, 4), "avg_ms": round(ms, 4), "calls_timed": len(alt_events[stage]),
-                                "peak_name": "dense 16-bit MFMA peak / %d (%d piece products per fp32 product)" % (nprod, nprod),
-                                "flop_basis": "fp32-equivalent FLOPs = 2*36*T*Cin*Cout, T = %d tiles" % Ta, "traffic": None}
+            for stage, key in (("gemm", "roofline"), ("wgrad", "roofline_wgrad")):
+                r = train_stage_roofline(alt_events[stage], stage, gm, spec.w_res2)
+                if r is not None:
+                    alt[key] = r
             alts[akey] = alt
     if rank == 0:
         # forward MACs scale with the crop area; backward = dgrad + wgrad ~ 2x forward
         fwd_tflop = 2e-3 * GMAC_PER_FRAME["render"] * (p / float(spec.new_size)) ** 2
         sps = B * world * args.steps / elapsed
-        roof = None
-        if gemm_events:
-            kern_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in gemm_events]))
-            T, which = gemm_events[0][1][0], gemm_events[0][1][3]
-            nxi, fname = WINO_SCHEMES[which]
-            fl = 2.0 * nxi * T * spec.w_res2 * spec.w_res2
-            split = args.gemm == "split"
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS
-            roof = {"kernel": "%s (GEMM stage of Winograd %s) on the res2 3x3 %d->%d conv, forward and input "
-                              "gradient, T = %d tiles" % ("wino_gemm_bf3_kernel" if split else "wino43_gemm_kernel", fname, spec.w_res2,
-                                                          spec.w_res2, T),
-                    "bound": "mfma", "achieved": round(fl / (kern_ms * 1e-3) / 1e12, 2), "peak": round(peak, 2),
-                    "unit": "TFLOP/s", "frac": round(fl / (kern_ms * 1e-3) / 1e12 / peak, 4),
-                    **({"peak_name": "dense bf16 MFMA peak / 6 (six bf16 piece products per fp32 product)"} if split else {}),
-                    "avg_launch_ms": round(kern_ms, 4), "launches_timed": len(gemm_events), "flop_per_launch": fl,
-                    "flop_basis": "executed MFMA FLOPs = 2*%d*T*Cin*Cout" % nxi, "traffic": None}
-        roof_w = None
-        if wgrad_events:
-            # the filter gradient of the same layers: four launches (x and dz transforms, 36 K-split GEMMs over the tiles, G^T dU G);
-            # executed FLOPs of the GEMM over the time of ALL four, against the exact-fp32 MFMA peak (this path has no split form)
-            w_ms = float(np.mean([a.elapsed_time(b) for (a, b), _ in wgrad_events]))
-            Tw = wgrad_events[0][1][0]
-            flw = 2.0 * 36 * Tw * spec.w_res2 * spec.w_res2
-            roof_w = {"kernel": "rn_conv2d_wino43_wgrad on the res2 3x3 %d->%d conv: wino_input_kernel + wino_dout_kernel + wino43_wgrad_gemm_kernel "
-                                "(+ reduce) + wino_dfilter_kernel, T = %d tiles" % (spec.w_res2, spec.w_res2, Tw),
-                      "bound": "mfma", "achieved": round(flw / (w_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(flw / (w_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "avg_ms_all_four_launches": round(w_ms, 4),
-                      "calls_timed": len(wgrad_events), "flop_per_call": flw,
-                      "flop_basis": "executed MFMA FLOPs of the GEMM stage = 2*36*T*Cin*Cout (direct count: 2*9*B*H*W*Cin*Cout = 4x that)",
-                      "traffic": None}
+        roof = train_stage_roofline(gemm_events, "gemm", args.gemm, spec.w_res2)
+        roof_w = train_stage_roofline(wgrad_events, "wgrad", args.gemm, spec.w_res2)
         print(json.dumps({
             "metric": "training samples/sec, Phong shader forward+backward+Adam, crop %d of 128^3, batch 24 per GPU" % p,
             "value": round(sps, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "bf16x3-split GEMM stages, fp32 accumulate; everything else f32",
+            "vs_baseline": None, "dtype": TRAIN_DTYPE[args.gemm], "gemm_mode": args.gemm,
             "data": "synthetic", "rccl_ranks": args.rccl_ranks,
             "config": {"workload": "Phong shader training step (resampler+crop, forward, BCE, dgrad+wgrad, bucketed "
                                    "gradient all-reduce, Adam), 237.3M params", "batch_per_gpu": B,
@@ -491,11 +492,24 @@ def build_workload(mode, device):
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (fp16: the same rate)
-# the further timed passes of every line: (JSON block, ops.WINO_GEMM mode)
-ALT_MODES = (("alt", "split"), ("alt2", "split16"))
-ALT_DTYPE = {"split": "bf16x3-split, fp32 accumulate",
+# Every line times the PRIMARY mode (--gemm; default = the library default, "split") and then the other two multiply-stage modes as
+# named blocks of the same JSON line: mode -> block key
+MODE_BLOCK = {"f32": "exact", "split": "alt", "split16": "alt2"}
+
+
+def other_modes(primary):
+    """(block key, ops.WINO_GEMM mode) of the further timed passes, exact first."""
+    return tuple((MODE_BLOCK[m], m) for m in ("f32", "split", "split16") if m != primary)
+
+
+ALT_DTYPE = {"f32": "exact fp32 everywhere (fp32 MFMA multiply stages)",
+             "split": "bf16x3-split operands (three bf16 pieces that sum exactly to the fp32 value: 24-bit operands), fp32 accumulate",
              "split16": "fp16x2-split of value / power-of-two tensor scale (22-bit operands), fp32 accumulate"}
+LINE_DTYPE = {"f32": "f32", "split": "f32 (multiply stages: bf16x3-split operands, fp32 accumulate)",
+              "split16": "f32 (multiply stages: fp16x2-split operands of value / tensor scale -- 22-bit, fp32 accumulate)"}
 ALT_WHAT = {
+    "f32": "the same steps with every multiply stage on the exact-fp32 MFMA pipe (v_mfma_f32_32x32x2_f32 / 16x16x4_f32; RN_WINO_GEMM=f32): the "
+           "fallback mode, the product default until round 4, and what a filter rejected by the F(6x6,3x3) self-check is demoted to",
     "split": "the same steps with the multiply stages of the wide stride-1 2-D convs (res2, res3, *_skip, e_conv5, e_conv6) and of the 3-D "
              "encoder's 32-channel convs on the bf16 matrix pipe: every fp32 operand as three bf16 pieces (exact sum), six piece products "
              "with i + j <= 2, fp32 accumulation (csrc/conv_wino_bf3.hip, conv3d_wino_bf3.hip); every other kernel unchanged (exact fp32)",
@@ -576,6 +590,7 @@ def render_main(args, world, rank, local_rank):
     from rendernet_amd.parallel import shard_range
 
     mode = args.mode
+    LIB_DEFAULT_MODE = ops.WINO_GEMM
     wl = build_workload(mode, "cuda:%d" % local_rank)
     B = args.batch
     hw, wtrunk = wl["trunk"]
@@ -640,7 +655,7 @@ def render_main(args, world, rank, local_rank):
             barrier()
             elapsed = time.perf_counter() - t0
             ops.LAUNCH_HOOK = ops.STAGE_HOOK = None
-        ops.WINO_GEMM = "f32"
+        ops.WINO_GEMM = LIB_DEFAULT_MODE
         if isinstance(out, (tuple, list)):
             out = torch.cat(list(out), dim=3)          # after the timed region: the checks below index one [n,H,W,6] tensor
         assert out.shape == (vox.shape[0], wl["out_hw"], wl["out_hw"], wl["out_ch"])
@@ -648,14 +663,15 @@ def render_main(args, world, rank, local_rank):
         by_rank = gather_per_rank(elapsed, world, rank)
         return out, max(by_rank), by_rank, ev
 
-    # ---- the primary pass: exact-fp32 MFMA everywhere
+    # ---- the primary pass: the mode of --gemm (default: the product default, the bf16x3 split multiply stages)
     vox, aux, poses, total_frames = shard(args.scaling)
     nloc = vox.shape[0]
     out, elapsed, by_rank, ev = timed_pass(vox, aux, poses, args.gemm, args.steps, args.warmup)
     frames_by_rank = gather_per_rank(nloc, world, rank)
-    # ---- the same steps with the multiply stage of the wide 2-D layers on the bf16 pipe (fp32 accuracy by operand splitting)
+    # ---- the same steps in the other two multiply-stage modes (exact fp32; the other split format)
+    ALT_MODES = other_modes(args.gemm)
     alts = {}
-    if not args.no_alt and args.gemm == "f32":
+    if not args.no_alt:
         for key, gm in ALT_MODES:
             alts[key] = timed_pass(vox, aux, poses, gm, args.steps, max(1, args.warmup))
     # ---- N > 1: the other scaling regime as well (weak: every rank its own batch; strong: ONE batch split 24 -> 24/N)
@@ -686,7 +702,8 @@ def render_main(args, world, rank, local_rank):
     res = {
         "metric": metric, "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": args.rccl_ranks,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": LINE_DTYPE[args.gemm], "gemm_mode": args.gemm, "data": "synthetic",
+        "rccl_ranks": args.rccl_ranks,
         "config": {"workload": wl["name"], "batch_per_gpu": nloc if args.scaling == "weak" else "%d split over %d" % (B, world),
                    "global_batch": total_frames,
                    "parallelism": "batch-sharded x%d, no data-path collective (RCCL: timing barrier + max-reduce only)" % world},
@@ -700,8 +717,6 @@ def render_main(args, world, rank, local_rank):
     if other is not None:
         res["other_scaling"] = other
     roof = gemm_roofline(ev["gemm"], ev["layer"], wtrunk, hw, nloc, mode, args.gemm)
-    if args.gemm != "f32":
-        res["dtype"] = "f32 (multiply stages: %s)" % ALT_DTYPE[args.gemm]
     if roof is not None:
         res["roofline"] = roof
     rs_events = ev["resample"]
@@ -744,7 +759,7 @@ def render_main(args, world, rank, local_rank):
             continue
         out_alt, el_alt, by_rank_alt, ev_alt = alts[key]
         fps_alt = total_frames * args.steps / el_alt
-        ablk = {"dtype": ALT_DTYPE[gm], "what": ALT_WHAT[gm],
+        ablk = {"dtype": ALT_DTYPE[gm], "gemm_mode": gm, "what": ALT_WHAT[gm],
                 "value": round(fps_alt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el_alt / args.steps, 3),
                 "steps": args.steps, "speedup_vs_value": round(fps_alt / fps, 4),
                 **per_rank_fields(by_rank_alt, frames_by_rank, args.steps)}
@@ -822,10 +837,11 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="run ONLY the full CPU-baseline protocol of BASELINE.md §3 (one B=24 pass + three B=1 passes of the oracle, all "
                          "cores and the best-of sweep; minutes) and print its record as one JSON line")
-    ap.add_argument("--gemm", choices=["f32", "split", "split16"], default="f32",
-                    help="multiply stage of the wide 2-D convs in the PRIMARY pass: exact-fp32 MFMA (default; the split route is then timed as `alt`) "
-                         "or the bf16x3 split route (profiling: no alt pass)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the further timed passes (split GEMM stages: bf16x3 `alt`, fp16x2 `alt2`)")
+    ap.add_argument("--gemm", choices=["f32", "split", "split16"], default=None,
+                    help="multiply-stage mode of the PRIMARY pass (`value`): default = the library default (rendernet_amd.ops.WINO_GEMM: `split`, "
+                         "bf16x3 operands, unless RN_WINO_GEMM says otherwise); the other two modes are then timed as the blocks `exact` (f32), "
+                         "`alt` (split), `alt2` (split16)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the further timed passes (the two other multiply-stage modes)")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the pass in the other scaling regime (`other_scaling`)")
     ap.add_argument("--patch", type=int, default=64, help="train mode: crop size on the 128^3 grid (RenderNet_Shader.py:204-207)")
     args = ap.parse_args()
@@ -843,6 +859,9 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU render path)")
+    if args.gemm is None:
+        from rendernet_amd import ops as _ops
+        args.gemm = _ops.WINO_GEMM
     ndev = torch.cuda.device_count()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:

@@ -279,7 +279,11 @@ int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const void* w_split
 /* ..._ex: format RN_SPLIT_FMT_H2 needs max|x| of every layer input.  A layer's launcher finds it with one pass over x -- or takes it
  * from `amax_x`, a device word holding the bit pattern of max|x| (or of an upper bound), which the launch that PRODUCED x wrote as its
  * `amax_y` (max over the tensor after the whole epilogue).  Both may be NULL; format 0 ignores amax_x.  rn_absmax: the stand-alone pass
- * (n % 4 == 0 floats, 16-byte aligned). */
+ * (n % 4 == 0 floats, 16-byte aligned).
+ * CONTRACT: a caller-supplied amax_x MUST be >= max|x| of the tensor the launch reads.  It is trusted, not re-checked: an understated
+ * word gives a scale that is too small and the fp16 pieces of the larger values overflow to inf -- results are then undefined (inf / NaN
+ * in the affected outputs, no error code).  Pass NULL when in doubt.  A non-finite max|x| (an activation that already overflowed fp32)
+ * selects the largest power-of-two scale: the output then carries inf / NaN like the exact-fp32 route's, deterministically. */
 int rn_conv2d_winograd_split_fwd_ex(int scheme, const float* x, const void* w_split, const float* bias, const float* alpha,
                                     const float* residual, float* y, float* preact, void* workspace, int B, int H, int W,
                                     int Cin, int Cout, int transposed, int act, const void* amax_x, void* amax_y, void* stream);

@@ -68,7 +68,11 @@ namespace {
 __host__ __device__ inline float h2_scale(float amax, float bound)
 {
     const float t = amax * bound * (1.0f / 32768.0f);
-    if (!(t > 0.f)) return 1.f;
+    if (!(t > 0.f)) return 1.f;                     // 0, and NaN (the max reduction drops NaNs; a NaN word itself lands here too)
+    // max|x| = inf (an overflowed activation) or a product beyond the fp32 range: frexpf(inf) leaves the exponent unspecified.  The largest
+    // power-of-two scale is used instead -- finite values then shrink towards 0, the inf itself stays inf in the fp16 piece and the output
+    // is inf / NaN like the fp32 route's: deterministic, never an arbitrary scale.
+    if (!(t <= 3.0e38f)) return 8.507059e37f;       // 2^126
     int e;
     const float m = frexpf(t, &e);                  // t = m * 2^e, 0.5 <= m < 1
     return ldexpf(1.f, m == 0.5f ? e - 1 : e);

@@ -185,12 +185,15 @@ class PackedWeight:
             return None
         return self._packed("wino43" + sfx, (L.RN_WINO_F44 if self.kdims == [4, 4] else L.RN_WINO_F43) | fmt)
 
+    def has_split3d(self):
+        """Whether this filter has a split form for the fused 3-D kernel -- a pure predicate: nothing is packed or allocated."""
+        return (self.ndim == 3 and self.kdims == [3, 3, 3] and self._wino_kind is not None
+                and bool(L.lib().rn_conv3d_winograd_split_supported(self.cin, self.cout)))
+
     def split3d(self, fmt=0):
         """A split form of a 3x3x3 32 -> 32 filter for rn_conv3d_winograd_split_fwd_ex (uint8 buffer), or None.  fmt 0: three bf16
         pieces; 1: two fp16 pieces of the scaled value."""
-        if self.ndim != 3 or self.kdims != [3, 3, 3] or self._wino_kind is None:
-            return None
-        if not L.lib().rn_conv3d_winograd_split_supported(self.cin, self.cout):
+        if not self.has_split3d():
             return None
         return self._packed("wino3dh" if fmt else "wino3ds", 0)
 
@@ -223,6 +226,7 @@ class PackedWeight:
             self._dgrad = PackedWeight(self.w_tf, kind, self.ndim)
             if getattr(self, "_wino63_demoted", False):
                 self._dgrad.wino63 = None                     # the forward pack was demoted by the F(6x6,3x3) self-check
+                self._dgrad._gemm_f32 = True
         return self._dgrad
 
 
@@ -405,10 +409,17 @@ class TrainContext:
             raise L.RenderNetHipError("no gradient buffer registered for a parameter of shape %s" % (tuple(t.shape),))
         return g
 
+    def grad_if_param(self, t):
+        """The gradient view of t, or None when t is not a registered parameter -- a CONSTANT that rides in a parameter slot (the all-zero
+        PReLU slope that makes the pretrained res blocks' ReLU, tools/layer_util.py:_relu_slope): no gradient is produced for it."""
+        if self.frozen or t is None:
+            return None
+        return self.grad_of.get(t.data_ptr())
+
     def ready(self, *ts):
         if self.on_ready is not None:
             for t in ts:
-                if t is not None:
+                if t is not None and t.data_ptr() in self.grad_of:
                     self.on_ready(t.data_ptr())
 
 
@@ -427,7 +438,6 @@ def training(ctx):
 
 
 AMAX_MISSES = None     # diagnostics: set to a list to record the split-format-H2 launches that had to make their own pass over x
-_LAST_AMAX = None      # the device word with max|y| of the launch just made (split format H2), picked up by _Conv.forward
 STAGE_HOOK = None      # bench.py: callable(stage, (T, Cin, Cout)) -> (start_event, end_event) | None, brackets the GEMM stage
 
 
@@ -462,33 +472,39 @@ WINO63_CHECK_TOL = float(os.environ["RN_WINO63_CHECK_TOL"]) if os.environ.get("R
 WINO63_DEMOTED = []
 
 
-def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
+def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None, amax_out=None):
     """rn_conv2d_wino43_fwd / _wino63_fwd / _wino44_fwd with the workspace (V and M planes) from torch's caching allocator.
     pw: the PackedWeight whose .wino43 / .wino63 form the launch reads (a stride-1 transposed 4x4 pack pads two pixels before).
-    y_t: the output tensor behind e[3] (needed by the F(6x6,3x3) self-check only)."""
+    y_t: the output tensor behind e[3] (needed by the F(6x6,3x3) self-check only).  amax_out: a list that receives the device word
+    with max|y| when the launch produced one (split format H2)."""
     which = _wino_scheme(pw, H, W)
     if (which == "f63" and WINO63_CHECK_TOL is not None and y_t is not None and getattr(pw, "_wino63_verdict", None) is None
             and getattr(pw, "force_scheme", None) is None and not torch.cuda.is_current_stream_capturing()):
         # Both schemes on the same input with NO epilogue (no bias, activation or residual): the residual of a res block or a
         # *_skip conv would inflate max|y| and hide a conv error well above tol * max|conv| (ADVICE r03).  Then the real launch.
+        # The candidate is the route this launch would take (F(6x6,3x3) in the ACTIVE multiply-stage mode: bf16x3 by default); the
+        # yardstick is F(4x4,3x3) on the exact-fp32 MFMA stage, the most accurate three-launch route there is -- so the check covers
+        # the transform's rounding and the operand split in one comparison.
         raw = (None, None, None)
         y63, y43 = torch.empty_like(y_t), torch.empty_like(y_t)
         rc = _wino43_run(x, pw, raw + (L.ptr(y63), None), B, H, W, Cin, Cout, 0, "f63")
         if rc != 0:
             return rc
-        rc = _wino43_run(x, pw, raw + (L.ptr(y43), None), B, H, W, Cin, Cout, 0, "f43")
+        rc = _wino43_run(x, pw, raw + (L.ptr(y43), None), B, H, W, Cin, Cout, 0, "f43", gemm="f32")
         if rc != 0:
             return rc
         diff, ref = float((y63 - y43).abs().max()), float(y43.abs().max())
         pw._wino63_verdict = diff <= WINO63_CHECK_TOL * ref
         if not pw._wino63_verdict:
-            WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30)})
-            pw.wino63 = None                                  # this filter takes F(4x4,3x3) from now on ...
+            WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30), "mode": WINO_GEMM})
+            pw.wino63 = None                                  # this filter takes F(4x4,3x3) on the exact-fp32 stage from now on ...
+            pw._gemm_f32 = True
             if pw._dgrad is not None:
                 pw._dgrad.wino63 = None                       # ... and so does its input-gradient pack
+                pw._dgrad._gemm_f32 = True
             pw._wino63_demoted = True
             which = "f43"
-    return _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which)
+    return _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, amax_out=amax_out)
 
 
 # Multiply stage of the three-launch path: "f32" = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = the same products on
@@ -496,7 +512,14 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None):
 # (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
 # "split16": the same stage with every operand as TWO fp16 pieces of value / (power-of-two scale of its tensor) and three products --
 # half the matrix work of "split"; 22-bit operands, fp32 accumulation (the accumulation error, which all three modes share, dominates).
-WINO_GEMM = os.environ.get("RN_WINO_GEMM", "f32")
+# DEFAULT since round 5: "split" -- the bf16x3 form carries the full 24-bit significand of every fp32 operand (the three pieces sum
+# EXACTLY to the fp32 value) and accumulates in fp32, its error against float64 equals the exact route's on every case of the hostile-
+# statistics suite, and it is 1.3x faster end to end.  RN_WINO_GEMM=f32 restores the exact-fp32 MFMA stage everywhere (it is also what a
+# filter is demoted to when the F(6x6,3x3) self-check below rejects it); "split16" is the opt-in fast mode.
+GEMM_MODES = ("f32", "split", "split16")
+WINO_GEMM = os.environ.get("RN_WINO_GEMM", "split")
+if WINO_GEMM not in GEMM_MODES:
+    raise ValueError("RN_WINO_GEMM=%r: expected one of %s" % (WINO_GEMM, ", ".join(GEMM_MODES)))
 # The fused 3x3x3 32 -> 32 kernel of the 3-D encoder has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip: 0.50 ms against 0.82 ms on
 # the B = 24 64x64x32 layer, error 2.4e-7 .. 3.8e-7 of max|y| against the fp32 kernel's 3.2e-7 .. 4.9e-7).  None: it follows
 # WINO_GEMM ("split" turns both on); True / False (env RN_CONV3D_SPLIT=1 / 0) force it independently.
@@ -515,17 +538,25 @@ def _conv3d_split(B=None, H=None, W=None):
     return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)
 
 
-def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
+def _gemm_mode(pw, gemm=None):
+    """The multiply-stage mode of a launch of this filter: the per-call override, else exact fp32 for a filter the self-check demoted,
+    else the module-wide mode."""
+    if gemm is not None:
+        return gemm
+    return "f32" if getattr(pw, "_gemm_f32", False) else WINO_GEMM
+
+
+def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, gemm=None, amax_out=None):
     lib = L.lib()
+    gmode = _gemm_mode(pw, gemm)
     f44, f63 = which == "f44", which == "f63"
     transposed = 1 if pw.kind == L.RN_PACK_CONVT_S1 else 0
     m = 6 if f63 else 4
     T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
     scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
     st = L.stream_ptr()
-    if WINO_GEMM in ("split", "split16") and lib.rn_winograd_split_supported(scheme, Cin, Cout):
-        global _LAST_AMAX
-        fmt = L.RN_SPLIT_FMT_H2 if WINO_GEMM == "split16" else 0
+    if gmode in ("split", "split16") and lib.rn_winograd_split_supported(scheme, Cin, Cout):
+        fmt = L.RN_SPLIT_FMT_H2 if gmode == "split16" else 0
         us = ctypes.c_void_p(pw.split(which, fmt).data_ptr())
         scheme |= fmt
         ws = torch.empty(lib.rn_winograd_split_workspace_bytes(scheme, B, H, W, Cin, Cout), dtype=torch.uint8, device=x.device)
@@ -538,7 +569,8 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which):
         ay = torch.empty(1, dtype=torch.int32, device=x.device) if fmt else None
         axp = ctypes.c_void_p(ax.data_ptr()) if ax is not None else None
         ayp = ctypes.c_void_p(ay.data_ptr()) if ay is not None else None
-        _LAST_AMAX = ay
+        if ay is not None and amax_out is not None:
+            amax_out.append(ay)
         ev = STAGE_HOOK("gemm", (T, Cin, Cout, which)) if STAGE_HOOK is not None and T * max(Cin, Cout) * 4 < 0x7fffff00 else None
         if ev is None:
             return lib.rn_conv2d_winograd_split_fwd_ex(scheme, L.ptr(x), us, *e, wsp, B, H, W, Cin, Cout, transposed, act, axp, ayp, st)
@@ -590,15 +622,33 @@ def _amax_of(x):
     if tag is None:
         return None
     word, version = tag
-    return word if x._version == version else None
+    return word if _version_of(x) == version else None
 
 
-def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st):
+def _version_of(t):
+    """t._version, or None where the counter does not exist (tensors created under torch.inference_mode() raise on access): such a
+    tensor gets no tag and the launcher makes its own pass over it."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def _tag_amax(y, word):
+    v = _version_of(y)
+    if word is not None and v is not None:
+        y._rn_amax = (word, v)
+
+
+def _conv3d_split_fmt():
+    return 1 if WINO_GEMM == "split16" else 0
+
+
+def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st, amax_out=None):
     """The fused 3x3x3 32 -> 32 kernel in the split format of the mode: bf16x3 ("split"), fp16x2 ("split16": max|x| from the producing
-    launch via x._rn_amax, else a pass; max|y| left for the consumer)."""
-    global _LAST_AMAX
+    launch via x._rn_amax, else a pass; max|y| left for the consumer in amax_out)."""
     lib = L.lib()
-    fmt = 1 if WINO_GEMM == "split16" else 0
+    fmt = _conv3d_split_fmt()
     us = ctypes.c_void_p(pw.split3d(fmt).data_ptr())
     if not fmt:
         return lib.rn_conv3d_winograd_split_fwd_ex(0, L.ptr(x), us, *e, B, H, W, D, Cin, Cout, act, None, None, None, st)
@@ -606,27 +656,28 @@ def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st):
     if ax is None and AMAX_MISSES is not None:
         AMAX_MISSES.append(("conv3d", Cin, Cout, H, W, D))
     words = torch.empty(2, dtype=torch.int32, device=x.device)       # [0]: max|y| for the consumer, [1]: scratch for a pass over x
-    _LAST_AMAX = words[:1]
+    if amax_out is not None:
+        amax_out.append(words[:1])
     return lib.rn_conv3d_winograd_split_fwd_ex(1, L.ptr(x), us, *e, B, H, W, D, Cin, Cout, act,
                                                ctypes.c_void_p(ax.data_ptr()) if ax is not None else None,
                                                ctypes.c_void_p(words.data_ptr() + 4), ctypes.c_void_p(words.data_ptr()), st)
 
 
-def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
+def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act, amax_out=None):
     lib, st = L.lib(), L.stream_ptr()
     e = (L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), L.ptr(z))          # the epilogue arguments of every entry
     unit = all(int(v) == 1 for v in stride)
     if mode == "conv3d":
         B, H, W, D, Cin = x.shape
-        if unit and _conv3d_split(B, H, W) and pw.split3d() is not None:
-            return _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, pw.cout, act, st)
+        if unit and _conv3d_split(B, H, W) and pw.has_split3d():
+            return _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, pw.cout, act, st, amax_out)
         if unit and pw.wino is not None:
             return lib.rn_conv3d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, D, Cin, pw.cout, act, st)
         return lib.rn_conv3d_fwd_train(L.ptr(x), L.ptr(pw.data), *e, B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), act, st)
     if mode == "conv2d":
         B, H, W, Cin = x.shape
         if unit and _use_wino43(pw, H, W):
-            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act, y)
+            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act, y, amax_out)
         if unit and pw.wino is not None:
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
         if unit and pw.wino4 is not None:
@@ -635,7 +686,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act):
     if mode == "conv2d_transpose":
         B, H, W, Cin = x.shape
         if unit and _use_wino43(pw, H, W):
-            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act)
+            return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act, None, amax_out)
         if unit and pw.wino4 is not None:
             return lib.rn_conv2d_wino4_fwd(L.ptr(x), L.ptr(pw.wino4), *e, B, H, W, Cin, pw.cout, 1, act, st)
         if (not unit) and int(stride[0]) == 2 and pw.kind == L.RN_PACK_CONVT_S2 and pw.wino4 is not None:
@@ -659,7 +710,7 @@ class _Conv(torch.autograd.Function):
     forward (plus the saved pre-activation when training), three backward (epilogue, dgrad, wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False):
+    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False, amax_box=None):
         _chk_dev(x, pw.w_tf, bias, alpha, residual)
         ev = LAUNCH_HOOK(mode, tuple(x.shape), pw) if LAUNCH_HOOK is not None else None
         if ev is not None:
@@ -670,11 +721,12 @@ class _Conv(torch.autograd.Function):
         if residual is not None and residual.shape != y.shape:
             raise L.RenderNetHipError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
         z = torch.empty_like(y) if (train and alpha is not None) else None
-        global _LAST_AMAX
-        _LAST_AMAX = None
-        L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act), "rn_%s_fwd" % mode)
-        if _LAST_AMAX is not None:
-            y._rn_amax = (_LAST_AMAX, y._version)                    # (_conv_apply repeats this on what autograd hands back)
+        # split format H2: the launch leaves the device word with max|y| in `amax`; it travels to the consumer as a tag on y (the
+        # caller's box carries it across _Conv.apply, which may hand back another tensor object for the same storage)
+        amax = [] if amax_box is None else amax_box
+        L.check(_launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act, amax), "rn_%s_fwd" % mode)
+        if amax:
+            _tag_amax(y, amax[-1])
         if ev is not None:
             ev[1].record()
         if train:
@@ -695,7 +747,7 @@ class _Conv(torch.autograd.Function):
         if act or (bias is not None and not tc.frozen):
             L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), L.ptr(y), L.ptr(alpha), L.ptr(dz) if act else None,
                                         L.ptr(tc.grad(bias)) if bias is not None else None,
-                                        L.ptr(tc.grad(alpha)) if alpha is not None else None,
+                                        L.ptr(tc.grad_if_param(alpha)),
                                         M, C, act, st), "rn_epilogue_bwd")
         d_res = None
         if has_res and ctx.needs_input_grad[4]:
@@ -753,7 +805,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
-            if mode == "conv3d" and unit and _conv3d_split(B, H, W) and dp.split3d() is not None:
+            if mode == "conv3d" and unit and _conv3d_split(B, H, W) and dp.has_split3d():
                 rc = _conv3d_split_launch(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, D, pw.cout, Cin, 0, st)
             elif mode == "conv3d" and unit and dp.wino is not None:
                 rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
@@ -783,7 +835,7 @@ class _Conv(torch.autograd.Function):
             L.check(rc, "rn_%s_dgrad" % mode)
         if not tc.frozen:
             tc.ready(pw.w_tf, bias, alpha)
-        return dx, None, None, None, d_res, None, None, None, None, None, None
+        return dx, None, None, None, d_res, None, None, None, None, None, None, None
 
 
 def _prep(x, pw, mode_cin):
@@ -799,11 +851,10 @@ def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, elu=
         # inference: no graph to record -- skip the autograd.Function machinery (at batch 1 the 80 launches of a render
         # are host-bound; this is a fifth of the per-launch cost)
         return _Conv.forward(None, x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, None, elu)
-    global _LAST_AMAX
-    out = _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu)
-    if _LAST_AMAX is not None and getattr(out, "_rn_amax", None) is None:
-        out._rn_amax = (_LAST_AMAX, out._version)                   # autograd returned another tensor object for the same storage
-    _LAST_AMAX = None
+    box = []
+    out = _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu, box)
+    if box and getattr(out, "_rn_amax", None) is None:
+        _tag_amax(out, box[-1])                                     # autograd returned another tensor object for the same storage
     return out
 
 

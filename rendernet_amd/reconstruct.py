@@ -165,12 +165,17 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
         e_conv4_e_conv4_*, e_conv4_alpha), not the slim projection_unit;
       * head layers: e_conv6_h (conv 4x4), e_conv7_h / e_conv8_h / e_conv9_h (conv_transpose 4x4 s2), e_conv11_h
         (conv_transpose 4x4 s1 + sigmoid), h = 1 under "Image", 2 under "Normal" (:226-301); there is no e_conv10;
-      * tf.nn.dropout(x, prob) sites (:133, :140, :147, :181, :203, :233, :240, :247, :272, :279, :286, :293) are the identity at
-        the prob = 1.0 the script passes (:367); other values raise here (a frozen net is not trained with dropout).
+      * tf.nn.dropout(x, prob) at the reference's sites (:131, :138, :145, :179, :208, :233, :240, :247, :271, :278, :285, :292 -- behind
+        e_conv1..5, e_conv6_h..e_conv8_h and, in the Normal head only, e_conv9_2): the identity at the prob = 1.0 the script passes (:367),
+        ops.dropout (x / prob * floor(prob + u), Philox) otherwise.
+    `trainable` is accepted like the reference's argument; whether parameter gradients are produced is decided by the ops.TrainContext
+    the call runs under (frozen=True: input gradients only, as the reference's optimisers only list the latents, :397-413).  The res
+    blocks' ReLU has no parameter: under a non-frozen context no gradient is asked for it.
     Widths are those of the loaded tensors."""
-    if float(prob) != 1.0:
-        raise L.RenderNetHipError("RenderNet_pretrained: prob = %g; the reference runs the frozen net at prob = 1.0 "
-                                  "(Reconstruct_RenderNet_Face.py:367)" % prob)
+    prob = float(prob)
+    if not 0.0 < prob <= 1.0:
+        raise L.RenderNetHipError("RenderNet_pretrained: prob = %g is not a keep probability in (0, 1]" % prob)
+    drop = (lambda t: t) if prob >= 1.0 else (lambda t: ops.dropout(t, prob))
     wd = weight_dict
     st = V.get_default_store()
     B = models_in.shape[0]
@@ -192,6 +197,7 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
                 net = LU.conv3d(net, nout(key + "_weights", 4), kernel_size=[k, k, k], stride=stride, pad="SAME", scope=name,
                                 trainable=trainable, weight_initializer=wd[key + "_weights"], bias_initializer=wd[key + "_biases"],
                                 activation_alpha=a)
+            net = drop(net)                                                                                           # :131, :138, :145
             tap("enc" + name[-1], net)
         shortcut = net
         c3 = int(net.shape[-1])
@@ -211,6 +217,7 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
             enc4 = LU.conv2d(enc3_2d, nout("e_conv4_e_conv4_weights", 3), kernel_size=[1, 1], scope='e_conv4', trainable=trainable,
                              weight_initializer=wd["e_conv4_e_conv4_weights"], bias_initializer=wd["e_conv4_e_conv4_biases"],
                              activation_alpha=a)
+        enc4 = drop(enc4)                                                                                             # :179
         tap("enc4", enc4)
 
         def res_stack(x, prefix):
@@ -227,6 +234,7 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
             enc5 = LU.conv2d(enc4_skip, nout("e_conv5_e_conv5_weights", 3), kernel_size=[4, 4], scope='e_conv5', trainable=trainable,
                              weight_initializer=wd["e_conv5_e_conv5_weights"], bias_initializer=wd["e_conv5_e_conv5_biases"],
                              activation_alpha=a)
+        enc5 = drop(enc5)                                                                                             # :208
         tap("enc5", enc5)
         enc5_skip = tap("enc5_skip", res_stack(enc5, "res3"))
 
@@ -239,6 +247,7 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
                 with st.variable_scope(name):
                     net = LU.conv2d(enc5_skip, nout(key + "_weights", 3), kernel_size=[4, 4], scope=name, trainable=trainable,
                                     weight_initializer=wd[key + "_weights"], bias_initializer=wd[key + "_biases"], activation_alpha=a)
+                net = drop(net)                                                                                       # :233, :271
                 for num in (7, 8, 9):
                     name = "e_conv%d_%s" % (num, h)
                     key = "%s_%s_%s" % (head, name, name)
@@ -247,6 +256,8 @@ def RenderNet_pretrained(models_in, weight_dict, prob=1.0, trainable=False, taps
                         net = LU.conv2d_transpose(net, nout(key + "_weights", 2), [4, 4], stride=[2, 2], scope=name, trainable=trainable,
                                                   weight_initializer=wd[key + "_weights"], bias_initializer=wd[key + "_biases"],
                                                   activation_alpha=a)
+                    if num < 9 or head == "Normal":
+                        net = drop(net)                                                           # :240, :247, :278, :285, :292 (e_conv9_1: none)
                 name = "e_conv11_" + h
                 key = "%s_%s_%s" % (head, name, name)
                 # the Normal head opens variable scope 'e_conv11' around conv scope 'e_conv11_2' (:295-296); the Image head

@@ -44,3 +44,17 @@ def fixtures_vox():
 
 def demo_pose(az=250.0, el=60.0, r=3.3):
     return np.array([az * np.pi / 180.0, (90 - el) * np.pi / 180.0, 3.3 / r], np.float32)
+
+
+GEMM_MODES = ("split", "f32", "split16")        # rendernet_amd.ops.GEMM_MODES, the product default first
+
+
+@pytest.fixture(params=GEMM_MODES)
+def gemm_mode(request, monkeypatch):
+    """Runs the test once per multiply-stage mode of the wide convs (rendernet_amd.ops.WINO_GEMM): "split" = the product default
+    (bf16x3 operands, fp32 accumulate), "f32" = exact-fp32 MFMA everywhere (the fallback, RN_WINO_GEMM=f32), "split16" = the opt-in
+    fp16x2 fast mode.  Whole modules opt in with `pytest.mark.usefixtures("gemm_mode")`: every net-level -m gpu test (configs 2, 3, 5,
+    inverse rendering, the CLIs) is green in all three, at the same bars."""
+    from rendernet_amd import ops
+    monkeypatch.setattr(ops, "WINO_GEMM", request.param)
+    return request.param

@@ -28,13 +28,27 @@ def test_render_line_has_the_contract_keys_roofline_parity_and_cpu_baseline():
         assert isinstance(d[k], t), (k, d.get(k))
     assert "vs_baseline" in d and d["vs_baseline"] is None              # BASELINE.md holds no published number for this metric
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    # the primary pass is the product default: fp32 values, multiply stages on bf16x3-split operands with fp32 accumulation
+    assert d["gemm_mode"] == "split" and d["dtype"].startswith("f32 (multiply stages: bf16x3-split operands")
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]      # frames/s of the whole job
-    r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-2 * r["achieved"]
-    assert "traffic" in r and "layer_ms" in r and r["layer_ms"] >= r["avg_launch_ms"]
+
+    def check_roofline(r, peak):
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - peak) < 0.01
+        assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-2 * r["achieved"]
+        assert "traffic" in r and "layer_ms" in r and r["layer_ms"] >= r["avg_launch_ms"]
+
+    check_roofline(d["roofline"], 2500.0 / 6)                  # six bf16 piece products per fp32 product
+    assert "bf16 MFMA dense peak / 6" in d["roofline"]["peak_name"]
+    # ... and the other two modes ride along as named blocks, each with its own roofline and parity
+    ex, a2 = d["exact"], d["alt2"]
+    assert ex["gemm_mode"] == "f32" and a2["gemm_mode"] == "split16" and "alt" not in d
+    check_roofline(ex["roofline"], 157.3)
+    check_roofline(a2["roofline"], 2500.0 / 3)
+    for blk in (ex, a2):
+        assert blk["parity"]["ok"] is True and blk["parity"]["max_abs_err"] <= 1e-3 and blk["parity_golden"]["ok"] is True
+        assert blk["value"] > 0 and abs(blk["speedup_vs_value"] - blk["value"] / d["value"]) < 1e-2
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str) and c["unit"] == "frames/s"
     p = d["parity"]
@@ -43,6 +57,14 @@ def test_render_line_has_the_contract_keys_roofline_parity_and_cpu_baseline():
     assert c["protocol"]["batched_pass_frames"] == 4 and c["protocol"]["single_frame_passes"] == 1
     _check_per_rank(d, 1, [4])
     assert d["roofline_resampler"]["bound"] == "hbm"
+
+
+def test_render_line_in_exact_mode_carries_the_split_blocks():
+    """`--gemm f32` (or RN_WINO_GEMM=f32): the exact-fp32 pass is the value, priced against the fp32 MFMA peak; the split modes are `alt` / `alt2`."""
+    d = _run(["--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"], {"RN_WINO_GEMM": "f32"})
+    assert d["gemm_mode"] == "f32" and d["dtype"] == "f32" and d["roofline"]["peak"] == 157.3
+    assert d["alt"]["gemm_mode"] == "split" and d["alt2"]["gemm_mode"] == "split16" and "exact" not in d
+    assert d["parity"]["ok"] is True and d["alt"]["parity"]["ok"] is True and d["alt2"]["parity"]["ok"] is True
 
 
 def test_self_spawned_two_rank_line_and_refusal_without_devices():

@@ -9,7 +9,7 @@ import shutil
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]      # every test once per multiply-stage mode (conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -161,9 +161,12 @@ def test_reconstruct_script_runs_and_writes_the_reference_outputs(tmp_path, caps
     assert np.load(os.path.join(cfg["sample_save"], "2_loss_.txt.npz"))["arr_0"].shape == (5,)
 
 
-def test_demo_rotate_renders_72_numbered_frames_equal_to_single_pose_runs(tmp_path):
+def test_demo_rotate_renders_72_numbered_frames_equal_to_single_pose_runs(tmp_path, gemm_mode):
     """`RenderNet_demo.py --rotate True` (RenderNet_demo.py:130-137): 72 files numbered 000..071, azimuth 0..355 in 5
-    degree steps, rendered in batches -- pixel-identical to 72 runs of the single-pose path -- plus the optional GIF."""
+    degree steps, rendered in batches -- pixel-identical to 72 runs of the single-pose path in the exact-fp32 mode -- plus the
+    optional GIF.  In the split modes a batch of 24 and a batch of 1 take different (equally accurate) routes through the 3-D
+    encoder (ops._conv3d_split: item-count gate), and split16 scales by the maximum of the whole batch tensor: frames agree to
+    fp32 rounding, i.e. at most one grey level on isolated pixels of the 8-bit PNG."""
     from PIL import Image
     import RenderNet_demo
     vox = os.path.join(ROOT, "binvox", "teapot.binvox")
@@ -183,4 +186,8 @@ def test_demo_rotate_renders_72_numbered_frames_equal_to_single_pose_runs(tmp_pa
                              "--radius", "3.0"])
         a = np.asarray(Image.open(rot / files[i]))
         b = np.asarray(Image.open(one / os.listdir(one)[0]))
-        assert np.array_equal(a, b), "frame %d of the rotation differs from the single-pose render" % i
+        if gemm_mode == "f32":
+            assert np.array_equal(a, b), "frame %d of the rotation differs from the single-pose render" % i
+        else:
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            assert d.max() <= 1 and (d > 0).mean() <= 1e-3, "frame %d: max diff %d, %.2g of the pixels differ" % (i, d.max(), (d > 0).mean())

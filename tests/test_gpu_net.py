@@ -16,7 +16,7 @@ from conftest import GOLDEN_DIR, demo_pose
 from oracle import rendernet as ON
 from oracle import resample as OR
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]      # every test once per multiply-stage mode (conftest.py)
 TAP_RTOL = 2e-4
 OUT_ATOL = 1e-3
 

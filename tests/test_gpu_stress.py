@@ -10,7 +10,7 @@ import torch
 
 from conftest import GOLDEN_DIR, demo_pose
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]      # every test once per multiply-stage mode (conftest.py)
 
 
 @pytest.fixture(scope="module")
@@ -38,12 +38,18 @@ def test_stress_frame_matches_golden(stress_renderer, fixtures_vox):
     assert np.abs(lg - g["logits_crop"]).max() <= 1e-3 * np.abs(g["logits_crop"]).max() + 1e-5
 
 
-def test_stress_batch_independence(stress_renderer, fixtures_vox):
+def test_stress_batch_independence(stress_renderer, fixtures_vox, gemm_mode):
+    """Frames of a batch are rendered independently: bit for bit in the exact and the bf16x3 modes (every launch plan sums a frame's
+    products in the same order whatever the batch); split16 scales every tensor by ITS maximum, which a batch-mate can raise -- there
+    the frame moves by fp32 rounding only."""
     vox = np.concatenate([_chair128(fixtures_vox), _chair128(fixtures_vox)[:, ::-1].copy()])
     poses = np.stack([demo_pose(), demo_pose(40, 35, 3.0)])
     both = stress_renderer.render(vox, poses)
     one = stress_renderer.render(vox[1:2], poses[1:2])
-    assert torch.equal(both[1:2], one)
+    if gemm_mode == "split16":
+        assert float((both[1:2] - one).abs().max()) <= 1e-5
+    else:
+        assert torch.equal(both[1:2], one)
     assert bool(torch.isfinite(both).all()) and float(both.std()) > 0
 
 

@@ -7,7 +7,7 @@ import torch
 from conftest import demo_pose
 from oracle import texture_net as OT
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]      # every test once per multiply-stage mode (conftest.py)
 TAP_RTOL = 2e-4
 
 
