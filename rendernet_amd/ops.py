@@ -913,7 +913,7 @@ def res_stack_2d(x, blocks, skip=None):
     B, H, W, C = x.shape
     lib = L.lib()
     fused = (RES_STACK_FUSED and len(blocks) > 0 and not (TRAIN is not None and torch.is_grad_enabled()) and not torch.is_grad_enabled()
-             and WINO63_CHECK_TOL is None
+             and WINO63_CHECK_TOL is None and WINO_GEMM == "f32"            # the chain runs the exact-fp32 GEMM stage
              and all(p.kind == L.RN_PACK_CONV and p.kdims == [3, 3] and p.cin == C and p.cout == C and _use_wino43(p, H, W) for p in pws))
     which = None
     if fused:

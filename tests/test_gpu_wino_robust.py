@@ -59,17 +59,19 @@ def test_21_stacked_convs():
         assert e <= BAR[scheme], (scheme, e)
 
 
-def test_wino63_self_check_demotes_and_passes(monkeypatch):
-    """ops.WINO63_CHECK_TOL: the first F(6x6,3x3) launch of a filter is repeated with F(4x4,3x3); an impossible tolerance
-    demotes the filter (the result IS the F(4x4,3x3) one, later launches take that route), a sane one keeps F(6x6,3x3) and
-    checks only once."""
+def test_wino63_self_check_demotes_and_passes(monkeypatch, gemm_mode):
+    """ops.WINO63_CHECK_TOL, in every multiply-stage mode (the default mode's check is what RenderNet_demo.py --weights runs): the first
+    F(6x6,3x3) launch of a filter -- in the ACTIVE mode -- is repeated with F(4x4,3x3) on the exact-fp32 stage; an impossible tolerance
+    demotes the filter (the result IS the exact F(4x4,3x3) one, later launches take that route), a sane one keeps the mode's F(6x6,3x3)
+    route and checks only once."""
     from rendernet_amd import ops
     rng = np.random.default_rng(3)
     x = torch.as_tensor((np.abs(rng.standard_normal((2, 64, 64, 256))) + 3.0).astype(np.float32)).cuda()
     w = torch.as_tensor(RU.xavier(rng, (3, 3, 256, 256))).cuda()
     b = torch.as_tensor((0.1 * rng.standard_normal(256)).astype(np.float32)).cuda()
-    y43 = RU.conv_with_scheme(x, w, b, "f43")
-    y63 = RU.conv_with_scheme(x, w, b, "f63")
+    y43 = RU.conv_with_scheme(x, w, b, "f43")                                   # exact fp32: what a demoted filter computes
+    y63 = RU.conv_with_scheme(x, w, b, "f63" + {"f32": "", "split": "s", "split16": "h"}[gemm_mode])
+    assert ops.WINO_GEMM == gemm_mode                                           # (conv_with_scheme restores the mode)
     assert not torch.equal(y43, y63)
     with torch.no_grad():
         # impossible tolerance -> demoted
@@ -79,7 +81,7 @@ def test_wino63_self_check_demotes_and_passes(monkeypatch):
         assert ops._wino_scheme(pw, 64, 64) == "f63"
         got = ops.conv2d(x, pw, b)
         assert torch.equal(got, y43)
-        assert len(ops.WINO63_DEMOTED) == n0 + 1 and ops.WINO63_DEMOTED[-1]["cin"] == 256
+        assert len(ops.WINO63_DEMOTED) == n0 + 1 and ops.WINO63_DEMOTED[-1]["cin"] == 256 and ops.WINO63_DEMOTED[-1]["mode"] == gemm_mode
         assert ops._wino_scheme(pw, 64, 64) == "f43" and torch.equal(ops.conv2d(x, pw, b), y43)
         # the documented bar -> kept, verdict cached
         monkeypatch.setattr(ops, "WINO63_CHECK_TOL", 2e-4)
