@@ -319,12 +319,14 @@ def test_numpy_phong_front_end_matches_reference_outputs():
         assert np.abs(got - ref[key]).max() <= 3e-5, key
 
 
-@pytest.mark.parametrize("mode", ["split", "split16"])
-def test_full_size_inverse_rendering_gradients_agree_across_multiply_stage_modes(mode, monkeypatch):
+def test_full_size_inverse_rendering_gradients_agree_across_multiply_stage_modes(monkeypatch):
     """Reconstruct_RenderNet_Face.py:334-413 at the reference sizes in the split multiply-stage modes: the per-hypothesis losses and the
     gradients of all four latent groups (through the split 3-D encoder, the split GEMM stages of the 512-wide trunk and their input-gradient
-    launches) against the SAME step in the exact-fp32 mode -- the mode the tiny-graph tests above pin to the oracle -- at the bars those tests
-    use against the oracle (loss 1e-4 relative, gradients 2e-3 * max, pose 5e-3)."""
+    launches) against the SAME step in the exact-fp32 mode -- the mode the tiny-graph tests above pin to the oracle.
+    The latent gradients of this graph are sums that cancel to ~1e-6 of their terms (max|d loss / d shape code| = 6e-7), so fp32 rounding
+    alone moves them by several 1e-3 of their maximum: the yardstick is measured, not assumed -- the exact mode run through its OTHER exact
+    route (F(4x4,3x3) instead of F(6x6,3x3): scripts/recon_mode_diff.py, 4.9e-3 / 2.6e-3 / 4.4e-3 / 5e-5 for shape / pose / texture / light).
+    A split mode must stay within 4x that difference (measured: 2.0x bf16x3, 2.7x fp16x2) and within 3e-2 of max|g| in any case; losses 1e-6."""
     from rendernet_amd import ops
     from rendernet_amd import reconstruct as RC
     rng = np.random.default_rng(1)
@@ -332,19 +334,28 @@ def test_full_size_inverse_rendering_gradients_agree_across_multiply_stage_modes
                texture=rng.standard_normal((5, 199)).astype(np.float32),
                light=(np.linspace(230, 320, num=5) * math.pi / 180.0)[:, None])
     target = torch.from_numpy(rng.uniform(0, 1, (5, 512, 512, 3)).astype(np.float32)).cuda()
-    res = {}
-    for m in ("f32", mode):
-        monkeypatch.setattr(ops, "WINO_GEMM", m)
+
+    def run(mode, gain=None):
+        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        if gain is not None:
+            monkeypatch.setattr(ops, "WINO63_MIN_GAIN", gain)
         rec = RC.Reconstructor(batch_size=5)
         rec.assign(**lat)
         rec.etas.update(vector=0.0, param=0.0, texture=0.0, light=0.0)         # gradients only: the latents stay where they are
         loss = rec.step(target).cpu().numpy()
-        res[m] = (loss, {k: v.grad.cpu().numpy().copy() for k, v in rec.latents.items()})
+        grads = {k: v.grad.cpu().numpy().astype(np.float64) for k, v in rec.latents.items()}
         del rec
         torch.cuda.empty_cache()
-    l0, g0 = res["f32"]
-    l1, g1 = res[mode]
-    assert np.abs(l1 - l0).max() <= 1e-4 * np.abs(l0).max()
-    for k in g0:
-        bar = 5e-3 if k == "param" else 2e-3
-        assert np.abs(g1[k] - g0[k]).max() <= bar * np.abs(g0[k]).max(), (k, np.abs(g1[k] - g0[k]).max(), np.abs(g0[k]).max())
+        return loss, grads
+
+    old_gain = ops.WINO63_MIN_GAIN
+    l0, g0 = run("f32")
+    _, gx = run("f32", 2.0)                                                    # no layer reaches a gain of 2: F(4x4,3x3) everywhere
+    monkeypatch.setattr(ops, "WINO63_MIN_GAIN", old_gain)
+    floor = {k: np.abs(gx[k] - g0[k]).max() / np.abs(g0[k]).max() for k in g0}
+    for mode in ("split", "split16"):
+        l1, g1 = run(mode)
+        assert np.abs(l1 - l0).max() <= 1e-6 * np.abs(l0).max(), mode
+        for k in g0:
+            d = np.abs(g1[k] - g0[k]).max() / np.abs(g0[k]).max()
+            assert d <= 4.0 * floor[k] + 1e-4 and d <= 3e-2, (mode, k, d, floor[k])
