@@ -18,7 +18,7 @@ RN_PACK_CONV_WINO43, RN_PACK_CONVT_S1_WINO43 = 7, 8
 RN_PACK_CONV_WINO44, RN_PACK_CONVT_S1_WINO44 = 9, 10
 RN_PACK_CONV_WINO63, RN_PACK_CONVT_S1_WINO63 = 11, 12
 RN_PACK_CONVT_S2_WINO = 13
-RN_WINO_F43, RN_WINO_F44, RN_WINO_F63 = 0, 1, 2
+RN_WINO_F43, RN_WINO_F44, RN_WINO_F63, RN_WINO_F11 = 0, 1, 2, 3
 RN_SPLIT_FMT_H2 = 0x100                  # operand format flag of the rn_winograd_split_* entries (OR-ed into the scheme)
 
 _c_int, _c_vp, _c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float

@@ -463,7 +463,7 @@ extern "C" size_t rn_winograd_split_packed_bytes(int scheme, int Cin, int Cout)
 }
 extern "C" size_t rn_winograd_split_v_bytes(int scheme, long long T, int Cin)
 {
-    return (rn_wino_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || T < 1 || Cin < 16) ? 0 : rn_wino_bf3_v_bytes(scheme, T, Cin);
+    return (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || T < 1 || Cin < 16) ? 0 : rn_wino_bf3_v_bytes(scheme, T, Cin);
 }
 extern "C" size_t rn_winograd_split_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)
 {
@@ -478,7 +478,7 @@ extern "C" int rn_winograd_split_pack(int scheme, const float* w_tf, void* w_spl
 extern "C" int rn_winograd_split_input_transform(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, void* stream)
 {
     if (!x || !Vs) return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform: null pointer");
-    if (rn_wino_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
+    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
         return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform: bad arguments");
     return rn_launch_wino_input_bf3(scheme, x, Vs, B, H, W, C, pad_lo, (hipStream_t)stream);
 }
@@ -494,7 +494,7 @@ extern "C" int rn_conv2d_winograd_split_fwd(int scheme, const float* x, const vo
     if (!x || !w_split || !y || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd: null pointer");
     if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd: PReLU needs alpha");
-    const int pad_lo = ((scheme & 0xff) == RN_WINO_F44 && transposed) ? 2 : 1;
+    const int pad_lo = (scheme & 0xff) == RN_WINO_F11 ? 0 : ((scheme & 0xff) == RN_WINO_F44 && transposed) ? 2 : 1;
     return rn_launch_conv_wino_bf3(scheme, x, w_split, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, pad_lo, act,
                                    (hipStream_t)stream);
 }
@@ -506,7 +506,7 @@ extern "C" int rn_conv2d_winograd_split_fwd_ex(int scheme, const float* x, const
     if (!x || !w_split || !y || !workspace) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: null pointer");
     if (B < 1 || H < 1 || W < 1) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: bad sizes");
     if ((act & RN_ACT_PRELU) && !alpha) return rn_set_error(RN_E_INVALID, "rn_conv2d_winograd_split_fwd_ex: PReLU needs alpha");
-    const int pad_lo = ((scheme & 0xff) == RN_WINO_F44 && transposed) ? 2 : 1;
+    const int pad_lo = (scheme & 0xff) == RN_WINO_F11 ? 0 : ((scheme & 0xff) == RN_WINO_F44 && transposed) ? 2 : 1;
     return rn_launch_conv_wino_bf3_ex(scheme, x, w_split, bias, alpha, residual, y, preact, workspace, B, H, W, Cin, Cout, pad_lo, act,
                                       static_cast<const unsigned*>(amax_x), static_cast<unsigned*>(amax_y), (hipStream_t)stream);
 }
@@ -514,7 +514,7 @@ extern "C" int rn_winograd_split_input_transform_ex(int scheme, const float* x, 
                                                     const void* amax_x, void* stream)
 {
     if (!x || !Vs) return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: null pointer");
-    if (rn_wino_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
+    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
         return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: bad arguments");
     return rn_launch_wino_input_bf3_ex(scheme, x, Vs, B, H, W, C, pad_lo, static_cast<const unsigned*>(amax_x), (hipStream_t)stream);
 }

@@ -729,14 +729,17 @@ int rn_launch_wino_output(int scheme, const float* M, const float* bias, const f
 int rn_launch_wino_output_amax(int scheme, const float* M, const float* bias, const float* alpha, const float* residual, float* y,
                                float* preact, int B, int H, int W, int C, int act, unsigned* amax, hipStream_t st)
 {
-    const int m = rn_wino_scheme_m(scheme);
+    const int m = scheme == RN_WINO_F11 ? 1 : rn_wino_scheme_m(scheme);
     if (m == 0) return rn_set_error(RN_E_INVALID, "wino_output: unknown scheme %d", scheme);
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
-    const int vw = scheme == RN_WINO_F43 ? 4 : 2;
+    const int vw = (scheme == RN_WINO_F43 || scheme == RN_WINO_F11) ? 4 : 2;
     const unsigned long long n = ((unsigned long long)T * (C / vw) + 255) / 256;
     const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-    if (scheme == RN_WINO_F43)
+    if (scheme == RN_WINO_F11)          // one plane, identity transform: the conv epilogue over M (split path of a 1x1 filter, conv_wino_bf3.hip)
+        hipLaunchKernelGGL((wino_output_kernel<WinoF11, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
+                           H, W, C, th, tw, T, act, nblk8, amax);
+    else if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_output_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
                            H, W, C, th, tw, T, act, nblk8, amax);
     else if (scheme == RN_WINO_F44)

@@ -535,7 +535,7 @@ struct Bf3GemmArgs {
 // WM = waves along the tile rows: 4 -> block 256 rows x 256 channels (waves 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA tiles, 128
 // accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64 = 2 x 2 tiles): the launcher runs ragged row blocks, the
 // items of a last partial round and small batches as half items.
-// TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower, 4: filter gradient)
+// TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower, 4: filter gradient, 5: 1x1 filter)
 template <class F, int WM, int TAG>
 __global__ __launch_bounds__(512, 2)
 void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
@@ -747,10 +747,10 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 namespace {
 inline int fmt_of(int scheme) { return (scheme >> 8) & 0xff; }
 inline int sch_of(int scheme) { return scheme & 0xff; }
-inline size_t h2_u_data(int sch, int Cin, int Cout) { return (size_t)rn_wino_scheme_nxi(sch) * Cin * Cout * 4; }
-inline size_t h2_v_data(int sch, long long T, int Cin) { return ((size_t)rn_wino_scheme_nxi(sch) * T * Cin * 4 + 255) / 256 * 256; }
-inline float h2_bound_v(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>::bt() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::bt() : H2Bound<WinoF63>::bt(); }
-inline float h2_bound_u(int sch) { return sch == RN_WINO_F43 ? H2Bound<WinoF43>::g() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::g() : H2Bound<WinoF63>::g(); }
+inline size_t h2_u_data(int sch, int Cin, int Cout) { return (size_t)rn_split_scheme_nxi(sch) * Cin * Cout * 4; }
+inline size_t h2_v_data(int sch, long long T, int Cin) { return ((size_t)rn_split_scheme_nxi(sch) * T * Cin * 4 + 255) / 256 * 256; }
+inline float h2_bound_v(int sch) { return sch == RN_WINO_F11 ? 1.f : sch == RN_WINO_F43 ? H2Bound<WinoF43>::bt() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::bt() : H2Bound<WinoF63>::bt(); }
+inline float h2_bound_u(int sch) { return sch == RN_WINO_F11 ? 1.f : sch == RN_WINO_F43 ? H2Bound<WinoF43>::g() : sch == RN_WINO_F44 ? H2Bound<WinoF44>::g() : H2Bound<WinoF63>::g(); }
 
 // *out = bit pattern of max |x| over n floats (n % 4 == 0)
 int launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st) { return rn_launch_absmax(x, n, out, st); }
@@ -773,32 +773,38 @@ int rn_launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t st)
 }
 
 
+int rn_split_scheme_nxi(int scheme) { return scheme == RN_WINO_F11 ? 1 : rn_wino_scheme_nxi(scheme); }
+int rn_split_scheme_m(int scheme) { return scheme == RN_WINO_F11 ? 1 : rn_wino_scheme_m(scheme); }
+
 bool rn_wino_bf3_supported(int scheme, int Cin, int Cout)
 {
     static const bool off = getenv("RN_NO_WINOGRAD_BF3") != nullptr;
-    return !off && fmt_of(scheme) <= 1 && rn_wino43_supported(sch_of(scheme), Cin, Cout);
+    static const bool off11 = getenv("RN_NO_SPLIT_1X1") != nullptr;
+    if (off || fmt_of(scheme) > 1) return false;
+    if (sch_of(scheme) == RN_WINO_F11) return !off11 && Cin >= 32 && Cin % 32 == 0 && Cout >= 256 && Cout % 256 == 0;
+    return rn_wino43_supported(sch_of(scheme), Cin, Cout);
 }
 
 // B3: 6 bytes per element.  H2: 4 bytes per element + a 256-byte tail whose first word is max|w| (bit pattern) of the filter.
 size_t rn_wino_bf3_packed_bytes(int scheme, int Cin, int Cout)
 {
     if (fmt_of(scheme) == 1) return h2_u_data(sch_of(scheme), Cin, Cout) + 256;
-    return (size_t)rn_wino_scheme_nxi(scheme) * Cin * Cout * 6;
+    return (size_t)rn_split_scheme_nxi(scheme) * Cin * Cout * 6;
 }
 
 // workspace: Vs (B3: nxi * T * Cin * 6 bytes, rounded up to 256; H2: ... * 4 + a 256-byte tail holding max|x|) followed by M (nxi * T * Cout floats)
 size_t rn_wino_bf3_v_bytes(int scheme, long long T, int Cin)
 {
     if (fmt_of(scheme) == 1) return h2_v_data(sch_of(scheme), T, Cin) + 256;
-    return ((size_t)rn_wino_scheme_nxi(scheme) * T * Cin * 6 + 255) / 256 * 256;
+    return ((size_t)rn_split_scheme_nxi(scheme) * T * Cin * 6 + 255) / 256 * 256;
 }
 
 size_t rn_wino_bf3_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)
 {
-    const int m = rn_wino_scheme_m(sch_of(scheme));
+    const int m = rn_split_scheme_m(sch_of(scheme));
     if (m == 0) return 0;
     const long long T = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
-    return rn_wino_bf3_v_bytes(scheme, T, Cin) + (size_t)rn_wino_scheme_nxi(sch_of(scheme)) * T * Cout * 4;
+    return rn_wino_bf3_v_bytes(scheme, T, Cin) + (size_t)rn_split_scheme_nxi(sch_of(scheme)) * T * Cout * 4;
 }
 
 int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, int Cout, int transposed, hipStream_t st)
@@ -810,15 +816,17 @@ int rn_launch_wino_pack_bf3(int scheme, const float* w_tf, void* us, int Cin, in
     char* u = static_cast<char*>(us);
     if (fmt == 1) {
         unsigned* amax = reinterpret_cast<unsigned*>(u + h2_u_data(scheme, Cin, Cout));
-        const int R = scheme == RN_WINO_F44 ? 4 : 3;
+        const int R = scheme == RN_WINO_F11 ? 1 : scheme == RN_WINO_F44 ? 4 : 3;
         const int rc = launch_absmax(w_tf, (size_t)R * R * Cin * Cout, amax, st);
         if (rc != RN_OK) return rc;
-        if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
+        if (scheme == RN_WINO_F11) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF11>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
+        else if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
         else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
         else hipLaunchKernelGGL(wino_pack_h2_kernel<WinoF63>, dim3(nbw), dim3(256), 0, st, w_tf, u, amax, Cin, Cout, transposed);
         return rn_check_launch("wino_pack_h2");
     }
-    if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    if (scheme == RN_WINO_F11) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF11>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
+    else if (scheme == RN_WINO_F43) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF43>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else if (scheme == RN_WINO_F44) hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF44>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     else hipLaunchKernelGGL(wino_pack_bf3_kernel<WinoF63>, dim3(nbw), dim3(256), 0, st, w_tf, u, Cin, Cout, transposed);
     return rn_check_launch("wino_pack_bf3");
@@ -835,7 +843,7 @@ int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int
 {
     const int fmt = fmt_of(scheme);
     scheme = sch_of(scheme);
-    const int m = rn_wino_scheme_m(scheme);
+    const int m = rn_split_scheme_m(scheme);
     if (m == 0 || C % 16 != 0) return rn_set_error(RN_E_INVALID, "wino_input_bf3: scheme %d, C %d", scheme, C);
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
@@ -853,7 +861,9 @@ int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int
             const int rc = launch_absmax(x, (size_t)B * H * W * C, amax, st);
             if (rc != RN_OK) return rc;
         }
-        if (scheme == RN_WINO_F43)
+        if (scheme == RN_WINO_F11)
+            hipLaunchKernelGGL((wino_input_h2_kernel<WinoF11>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+        else if (scheme == RN_WINO_F43)
             hipLaunchKernelGGL((wino_input_h2_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
         else if (scheme == RN_WINO_F44)
             hipLaunchKernelGGL((wino_input_h2_kernel<WinoF44>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
@@ -861,7 +871,9 @@ int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int
             hipLaunchKernelGGL((wino_input_h2_kernel<WinoF63>), dim3(nblk8), dim3(256), 0, st, x, v, amax, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
         return rn_check_launch("wino_input_h2");
     }
-    if (scheme == RN_WINO_F43)
+    if (scheme == RN_WINO_F11)
+        hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF11>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
+    else if (scheme == RN_WINO_F43)
         hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF43>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
     else if (scheme == RN_WINO_F44)
         hipLaunchKernelGGL((wino_input_bf3_kernel<WinoF44>), dim3(nblk8), dim3(256), 0, st, x, v, H, W, C, th, tw, T, ncb, nwg, nblk8, pad_lo);
@@ -891,6 +903,7 @@ static int wino_gemm_bf3_launch_w(int tag, const Bf3GemmArgs& a, int begin, int 
     case 1: return wino_gemm_bf3_launch_t<F, WM, 1>(a, begin, end, parts, st);
     case 2: return wino_gemm_bf3_launch_t<F, WM, 2>(a, begin, end, parts, st);
     case 4: return wino_gemm_bf3_launch_t<F, WM, 4>(a, begin, end, parts, st);
+    case 5: return wino_gemm_bf3_launch_t<F, WM, 5>(a, begin, end, parts, st);
     default: return wino_gemm_bf3_launch_t<F, WM, 3>(a, begin, end, parts, st);
     }
 }
@@ -983,13 +996,13 @@ int rn_launch_wino_gemm_bf3(int scheme, const void* Vs, const void* us, float* M
     if (!rn_wino_bf3_supported(scheme, Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: scheme=%d Cin=%d Cout=%d", scheme, Cin, Cout);
     const int fmt = fmt_of(scheme);
     scheme = sch_of(scheme);
-    const int tag = scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
+    const int tag = scheme == RN_WINO_F11 ? 5 : scheme == RN_WINO_F43 ? 0 : scheme == RN_WINO_F44 ? 1 : Cin >= 1024 ? 2 : 3;
     if (fmt == 1) {
         const unsigned* av = reinterpret_cast<const unsigned*>(static_cast<const char*>(Vs) + h2_v_data(scheme, T, Cin));
         const unsigned* au = reinterpret_cast<const unsigned*>(static_cast<const char*>(us) + h2_u_data(scheme, Cin, Cout));
-        return gemm_split_planes(1, rn_wino_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, av, au, h2_bound_v(scheme), h2_bound_u(scheme), st);
+        return gemm_split_planes(1, rn_split_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, av, au, h2_bound_v(scheme), h2_bound_u(scheme), st);
     }
-    return rn_launch_gemm_bf3_planes(rn_wino_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, st);
+    return rn_launch_gemm_bf3_planes(rn_split_scheme_nxi(scheme), tag, Vs, us, M, T, Cin, Cout, st);
 }
 
 // x [B,H,W,Cin] -> y [B,H,W,Cout]; us from rn_launch_wino_pack_bf3; ws >= rn_wino_bf3_workspace_bytes(...) bytes
@@ -1004,7 +1017,7 @@ static int conv_wino_bf3_rec(int scheme, const float* x, const void* us, const f
                              float* y, float* preact, void* ws, int B, int H, int W, int Cin, int Cout, int pad_lo, int act,
                              const unsigned* amax_x, unsigned* amax_y, hipStream_t st)
 {
-    const int m = rn_wino_scheme_m(sch_of(scheme));
+    const int m = rn_split_scheme_m(sch_of(scheme));
     const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
     const long long T = (long long)B * th * tw;
     const int cmax = Cin > Cout ? Cin : Cout;

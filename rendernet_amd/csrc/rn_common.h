@@ -46,6 +46,17 @@ int rn_launch_conv_wino(const float* x, const float* u, const float* bias, const
                         float* y, float* preact, int B, int H, int W, int D, int KD, int Cin, int Cout, int act,
                         int mode, int pad, hipStream_t st);
 
+// The "scheme" of a 1x1 filter on the split multiply stage (conv_wino_bf3.hip): one plane, identity transforms -- the three launches are then
+// split x into the GEMM's row format / one T x Cin x Cout GEMM on the 16-bit matrix pipe / the conv epilogue.  Exists only in the split path
+// (RN_WINO_F11 in include/rendernet_hip.h): the exact-fp32 helpers below do not know it (rn_wino_scheme_nxi(RN_WINO_F11) == 0).
+struct WinoF11 {
+    static constexpr int M = 1, TA = 1, R = 1, NXI = 1;
+    static constexpr float AT(int, int) { return 1.f; }
+    static constexpr double G(int, int) { return 1.0; }
+    static constexpr float BT(int, int) { return 1.f; }
+};
+int rn_split_scheme_nxi(int scheme);                  // conv_wino_bf3.hip: rn_wino_scheme_nxi / _m that also know RN_WINO_F11 (1 plane, 1 pixel)
+int rn_split_scheme_m(int scheme);
 bool rn_wino43_supported(int scheme, int Cin, int Cout);                                                  // conv_wino43.hip
 int rn_wino_scheme_nxi(int scheme);
 int rn_wino_scheme_r(int scheme);

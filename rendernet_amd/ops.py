@@ -52,7 +52,7 @@ class PackedWeight:
         # never materialises its direct pack (949 MB for the net), and a training step re-derives only the forms its
         # forward and input-gradient launches actually read.
         self._buf = {"data": None, "wino": None, "wino4": None, "wino43": None, "wino63": None, "wino43s": None, "wino63s": None, "wino43h": None, "wino63h": None, "wino3dh": None,
-                     "wino3ds": None}
+                     "wino3ds": None, "wino11s": None, "wino11h": None}
         self._dirty = {k: True for k in self._buf}
         self._packed_on = {}              # form -> (stream, event recorded behind its last pack kernel)
         # Winograd F(2x2,3x3) companion (csrc/conv_wino.hip): 3x3 / 3x3x3 filters whose channel counts the kernel takes;
@@ -77,6 +77,10 @@ class PackedWeight:
             self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO43, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO43}.get(kind)
         elif ndim == 2 and self.kdims == [4, 4] and lib.rn_conv2d_wino44_supported(self.cin, self.cout):
             self._wino43_kind = {L.RN_PACK_CONV: L.RN_PACK_CONV_WINO44, L.RN_PACK_CONVT_S1: L.RN_PACK_CONVT_S1_WINO44}.get(kind)
+        # 1x1 filters (the projection unit, tools/layer_util.py:8-22): on the split multiply stage a plain GEMM, scheme RN_WINO_F11 (one plane,
+        # identity transforms; csrc/conv_wino_bf3.hip).  The exact-fp32 mode keeps the implicit-GEMM kernel for them.
+        self._split11 = (ndim == 2 and self.kdims == [1, 1] and kind in (L.RN_PACK_CONV, L.RN_PACK_CONVT_S1)
+                         and bool(lib.rn_winograd_split_supported(L.RN_WINO_F11, self.cin, self.cout)))
         # ... and F(6x6,3x3) for the same 3x3 layers on maps where the 6-pixel tile grid pays (_wino_scheme picks per launch)
         self._wino63_kind = None
         if self._wino43_kind is not None and self.kdims == [3, 3] and lib.rn_conv2d_wino63_supported(self.cin, self.cout):
@@ -179,6 +183,8 @@ class PackedWeight:
         """The split form (uint8 buffer) of scheme `which` ("f43" | "f44" | "f63") for the split GEMM stage, or None.  fmt: 0 = three
         bf16 pieces, L.RN_SPLIT_FMT_H2 = two fp16 pieces of the scaled value."""
         sfx = "h" if fmt else "s"
+        if which == "f11":
+            return self._packed("wino11" + sfx, L.RN_WINO_F11 | fmt) if self._split11 else None
         if which == "f63":
             return None if self._wino63_kind is None else self._packed("wino63" + sfx, L.RN_WINO_F63 | fmt)
         if self._wino43_kind is None:
@@ -549,11 +555,13 @@ def _gemm_mode(pw, gemm=None):
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, gemm=None, amax_out=None):
     lib = L.lib()
     gmode = _gemm_mode(pw, gemm)
-    f44, f63 = which == "f44", which == "f63"
+    f44, f63, f11 = which == "f44", which == "f63", which == "f11"
     transposed = 1 if pw.kind == L.RN_PACK_CONVT_S1 else 0
-    m = 6 if f63 else 4
+    m = 6 if f63 else 1 if f11 else 4
     T = B * ((H + m - 1) // m) * ((W + m - 1) // m)
-    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F43, 36)
+    scheme, nxi = (L.RN_WINO_F44, 49) if f44 else (L.RN_WINO_F63, 64) if f63 else (L.RN_WINO_F11, 1) if f11 else (L.RN_WINO_F43, 36)
+    if f11 and gmode == "f32":
+        raise L.RenderNetHipError("the 1x1 GEMM route exists on the split multiply stage only")
     st = L.stream_ptr()
     if gmode in ("split", "split16") and lib.rn_winograd_split_supported(scheme, Cin, Cout):
         fmt = L.RN_SPLIT_FMT_H2 if gmode == "split16" else 0
@@ -575,7 +583,7 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, gemm=None, amax_out=No
         if ev is None:
             return lib.rn_conv2d_winograd_split_fwd_ex(scheme, L.ptr(x), us, *e, wsp, B, H, W, Cin, Cout, transposed, act, axp, ayp, st)
         M = ctypes.c_void_p(ws.data_ptr() + lib.rn_winograd_split_v_bytes(scheme, T, Cin))
-        rc = lib.rn_winograd_split_input_transform_ex(scheme, L.ptr(x), wsp, B, H, W, Cin, 2 if (f44 and transposed) else 1, axp, st)
+        rc = lib.rn_winograd_split_input_transform_ex(scheme, L.ptr(x), wsp, B, H, W, Cin, 0 if f11 else 2 if (f44 and transposed) else 1, axp, st)
         if rc != 0:
             return rc
         ev[0].record()
@@ -610,6 +618,15 @@ def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, gemm=None, amax_out=No
 
 def _use_wino43(pw, H, W):
     return pw._wino43_kind is not None and H * W >= WINO43_MIN_PIXELS
+
+
+def _use_split11(pw, pixels):
+    """A 1x1 filter takes the split GEMM stage (three launches: split, GEMM, epilogue) in the split modes when the launch has at least a
+    256-row block of pixels per CU pair; below that the one-launch implicit-GEMM kernel wins."""
+    return pw._split11 and _gemm_mode(pw) in ("split", "split16") and pixels >= SPLIT11_MIN_PIXELS
+
+
+SPLIT11_MIN_PIXELS = int(os.environ.get("RN_SPLIT11_MIN_PIXELS", "8192"))
 
 
 WINO43_MIN_PIXELS = int(os.environ.get("RN_WINO43_MIN_PIXELS", "64"))
@@ -678,6 +695,8 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act, a
         B, H, W, Cin = x.shape
         if unit and _use_wino43(pw, H, W):
             return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act, y, amax_out)
+        if unit and _use_split11(pw, B * H * W):
+            return _wino43_run(x, pw, e, B, H, W, Cin, pw.cout, act, "f11", amax_out=amax_out)
         if unit and pw.wino is not None:
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
         if unit and pw.wino4 is not None:
@@ -814,6 +833,9 @@ class _Conv(torch.autograd.Function):
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode in ("conv2d", "conv2d_transpose") and unit and _use_wino43(dp, H, W):
                 rc = _wino43_fwd(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
+            elif mode == "conv2d" and unit and _use_split11(dp, B * H * W):
+                # 1x1: the input gradient is the GEMM with the transposed filter (the same TF tensor packed the other way round)
+                rc = _wino43_run(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0, "f11")
             elif mode == "conv2d" and unit and dp.wino is not None:
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
                 rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
@@ -993,9 +1015,10 @@ def projection(x, pw, bias, alpha):
     x = x.contiguous().float()
     if x.shape[3] * x.shape[4] != pw.cin or pw.cin != pw.cout:
         raise L.RenderNetHipError("projection: D*C=%d but filter is %dx%d" % (x.shape[3] * x.shape[4], pw.cin, pw.cout))
-    if TRAIN is not None and torch.is_grad_enabled():
-        # training: the same GEMM through the differentiable 1x1 conv2d path (the reshape is a view)
-        B, H, W, D, C = x.shape
+    B, H, W, D, C = x.shape
+    if (TRAIN is not None and torch.is_grad_enabled()) or _use_split11(pw, B * H * W):
+        # training: the same GEMM through the differentiable 1x1 conv2d path (the reshape is a view); split modes: that path takes the 1x1
+        # filter through the split GEMM stage (exact fp32: the one-launch kernel below)
         return _conv_apply(x.view(B, H, W, D * C), pw, bias, alpha, None, (1, 1), (1, 1), False, "conv2d")
     return _Projection.apply(x, pw, bias, alpha)
 

@@ -322,6 +322,101 @@ class _TrainStub:
         pass
 
 
+CASES_1X1 = [   # (B, H, W, Cin, Cout): pixel counts below / across / above the 256-row block and the 8-pixel transform group, 2 .. 64 K steps
+    (1, 3, 5, 32, 256), (1, 16, 16, 64, 256), (2, 17, 15, 1024, 512), (3, 64, 64, 256, 256), (1, 64, 64, 1024, 1024), (5, 9, 7, 96, 768),
+]
+
+
+@pytest.mark.parametrize("smode", ["split", "split16"])
+@pytest.mark.parametrize("case", CASES_1X1)
+def test_conv2d_1x1_split_vs_oracle(case, smode, monkeypatch):
+    """A 1x1 filter on the split multiply stage (scheme RN_WINO_F11: split x into the GEMM's rows / ONE T x Cin x Cout GEMM / epilogue) -- the
+    projection unit's conv (tools/layer_util.py:8-22: slim.conv2d [1,1] + prelu) and its input gradient: the C entry with every epilogue
+    flavour and the pre-activation output, ops.conv2d's routing, the exact-fp32 kernel on the same filter, all at the 1e-4 * max|ref| bar of
+    every other conv flavour."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    B, H, W, Cin, Cout = case
+    fmt = L.RN_SPLIT_FMT_H2 if smode == "split16" else 0
+    sid = L.RN_WINO_F11
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = _xavier(rng, (1, 1, Cin, Cout))
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
+    y0 = OL.conv2d(x, w, b, (1, 1))
+    res = rng.standard_normal(y0.shape).astype(np.float32)
+    lib = L.lib()
+    assert lib.rn_winograd_split_supported(sid | fmt, Cin, Cout) == 1 and lib.rn_conv2d_wino43_supported(Cin, Cout) in (0, 1)
+    monkeypatch.setattr(ops, "SPLIT11_MIN_PIXELS", 1)
+    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    pw = ops.pack_conv(_dev(w))
+    assert pw._split11 and pw.split("f11", fmt) is not None
+    xd, bd, ad, rd = _dev(x), _dev(b), _dev(alpha), _dev(res)
+    ws = torch.empty(lib.rn_winograd_split_workspace_bytes(sid | fmt, B, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    yy, zz = torch.empty(y0.shape, device="cuda"), torch.empty(y0.shape, device="cuda")
+    us = ctypes.c_void_p(pw.split("f11", fmt).data_ptr())
+    L.check(lib.rn_conv2d_winograd_split_fwd(sid | fmt, L.ptr(xd), us, L.ptr(bd), L.ptr(ad), L.ptr(rd), L.ptr(yy), L.ptr(zz),
+                                             ctypes.c_void_p(ws.data_ptr()), B, H, W, Cin, Cout, 0, 1, L.stream_ptr()), "rn_conv2d_winograd_split_fwd (1x1)")
+    _close(zz, y0, "1x1 split preact")
+    _close(yy, OL.prelu(y0, alpha) + torch.from_numpy(res), "1x1 split prelu + residual")
+    with torch.no_grad():
+        got = ops.conv2d(xd, pw, bd, ad, rd)                                  # the dispatcher takes the same route ...
+        assert torch.equal(got, yy)
+        _close(ops.conv2d(xd, pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "1x1 split + sigmoid")
+        monkeypatch.setattr(ops, "WINO_GEMM", "f32")                          # ... and the exact mode the implicit-GEMM kernel
+        exact = ops.conv2d(xd, pw, bd, ad, rd)
+        monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    assert float((got - exact).abs().max()) <= 1e-4 * float(exact.abs().max()) and not torch.equal(got, exact)
+    # the input gradient: the same TF tensor packed the other way round (needs Cin % 256 == 0: the channel roles swap)
+    if Cin % 256 == 0:
+        dp = pw.dgrad_pack(True)
+        assert dp._split11
+        dz = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+        dx = torch.empty((B, H, W, Cin), device="cuda")
+        L.check(ops._wino43_run(_dev(dz), dp, (None, None, None, L.ptr(dx), None), B, H, W, Cout, Cin, 0, "f11"), "1x1 split dgrad")
+        _close(dx, OL.conv2d_transpose(dz, w, None, (1, 1)), "1x1 split dgrad vs oracle")
+    # the exact-fp32 stage entries do not know the scheme
+    assert lib.rn_winograd_input_transform(sid, L.ptr(xd), L.ptr(yy), B, H, W, Cin, 0, L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("smode", ["split", "split16"])
+def test_projection_unit_on_the_split_stage(smode, monkeypatch):
+    """ops.projection (depth-flatten + 1x1 conv + PReLU, tools/layer_util.py:8-22) at the benched width: in the split modes the GEMM runs on
+    the split stage (forward, and under a training context forward + input gradient), against the oracle's projection unit and against the
+    exact-fp32 kernel."""
+    from rendernet_amd import ops
+    rng = np.random.default_rng(17)
+    B, H, W, D, C = 2, 64, 64, 32, 32
+    x = rng.standard_normal((B, H, W, D, C)).astype(np.float32)
+    w = _xavier(rng, (1, 1, D * C, D * C))
+    b = (0.1 * rng.standard_normal(D * C)).astype(np.float32)
+    al = rng.uniform(0, 0.25, D * C).astype(np.float32)
+    want = OL.prelu(OL.conv2d(x.reshape(B, H, W, D * C), w, b, (1, 1)), al)
+    pw = ops.pack_conv(_dev(w))
+    out = {}
+    for mode in ("f32", smode):
+        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        with torch.no_grad():
+            out[mode] = ops.projection(_dev(x), pw, _dev(b), _dev(al))
+        _close(out[mode], want, "projection unit, %s" % mode)
+    assert not torch.equal(out["f32"], out[smode])                           # two routes, not one
+    # under autograd: forward + input gradient (the filter gradient stays on the shared exact kernel)
+    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    xd, wd, ad, bd = _dev(x).requires_grad_(True), pw.w_tf, _dev(al), _dev(b)
+    tc = _TrainStub(wd, ad, bd)
+    monkeypatch.setattr(ops, "TRAIN", tc)
+    g = rng.standard_normal((B, H, W, D * C)).astype(np.float32)
+    y = ops.projection(xd, pw, bd, ad)
+    y.backward(_dev(g))
+    xr, wr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
+    yr = OL.prelu(OL.conv2d(xr.reshape(B, H, W, D * C), wr, torch.from_numpy(b), (1, 1)), torch.from_numpy(al))
+    yr.backward(torch.from_numpy(g))
+    _close(y, yr, "projection under autograd")
+    _close(xd.grad, xr.grad, "projection input gradient", rtol=2e-4)
+    _close(tc.g[id(wd)], wr.grad, "projection filter gradient", rtol=2e-4)
+
+
 def test_conv3d_split_through_autograd_matches_the_fp32_kernel(monkeypatch):
     """ops.conv3d under autograd (forward with the saved pre-activation, input gradient through the split kernel, filter gradient
     through the shared wgrad kernel) with the opt-in on, against the same layer with it off."""
