@@ -367,7 +367,7 @@ def train_main(args, world, rank, local_rank):
     gemm_events, wgrad_events = [], []
 
     def stage_hook(stage, tkn):
-        if stage in ("gemm", "wgrad") and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+        if stage in ("gemm", "wgrad") and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2 and tkn[3] != "f11":
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             (gemm_events if stage == "gemm" else wgrad_events).append((ev, tkn))
             return ev
@@ -401,7 +401,7 @@ def train_main(args, world, rank, local_rank):
                 alt_events = {"gemm": [], "wgrad": []}
 
                 def alt_hook(stage, tkn):
-                    if stage in alt_events and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2:
+                    if stage in alt_events and tkn[1] == spec.w_res2 and tkn[2] == spec.w_res2 and tkn[3] != "f11":
                         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                         alt_events[stage].append((ev, tkn))
                         return ev
@@ -627,7 +627,7 @@ def render_main(args, world, rank, local_rank):
         ev = {"layer": [], "gemm": [], "resample": []}
 
         def stage_hook(stage, tkn):
-            if stage == "gemm" and tkn[1] == wtrunk and tkn[2] == wtrunk:
+            if stage == "gemm" and tkn[1] == wtrunk and tkn[2] == wtrunk and tkn[3] in ("f43", "f63"):      # (not the projection unit's 1x1 GEMM)
                 e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev["gemm"].append((e, tkn))
                 return e

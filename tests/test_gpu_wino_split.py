@@ -401,20 +401,23 @@ def test_projection_unit_on_the_split_stage(smode, monkeypatch):
             out[mode] = ops.projection(_dev(x), pw, _dev(b), _dev(al))
         _close(out[mode], want, "projection unit, %s" % mode)
     assert not torch.equal(out["f32"], out[smode])                           # two routes, not one
-    # under autograd: forward + input gradient (the filter gradient stays on the shared exact kernel)
+    # under autograd: forward + input gradient on the split stage (the filter gradient stays on the shared exact kernel).  The gradients are
+    # compared on the LINEAR unit (no PReLU): among 8 M pre-activations a few lie within rounding of zero and take the other PReLU branch on the
+    # two sides, which moves single entries of dx by a whole filter coefficient -- the epilogue backward has its own tests (test_gpu_train.py)
     monkeypatch.setattr(ops, "WINO_GEMM", smode)
     xd, wd, ad, bd = _dev(x).requires_grad_(True), pw.w_tf, _dev(al), _dev(b)
     tc = _TrainStub(wd, ad, bd)
     monkeypatch.setattr(ops, "TRAIN", tc)
     g = rng.standard_normal((B, H, W, D * C)).astype(np.float32)
-    y = ops.projection(xd, pw, bd, ad)
+    _close(ops.projection(xd, pw, bd, ad), want, "projection under autograd (forward, with the saved pre-activation)")
+    y = ops.conv2d(xd.view(B, H, W, D * C), pw, bd)
     y.backward(_dev(g))
     xr, wr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
-    yr = OL.prelu(OL.conv2d(xr.reshape(B, H, W, D * C), wr, torch.from_numpy(b), (1, 1)), torch.from_numpy(al))
+    yr = OL.conv2d(xr.reshape(B, H, W, D * C), wr, torch.from_numpy(b), (1, 1))
     yr.backward(torch.from_numpy(g))
-    _close(y, yr, "projection under autograd")
-    _close(xd.grad, xr.grad, "projection input gradient", rtol=2e-4)
-    _close(tc.g[id(wd)], wr.grad, "projection filter gradient", rtol=2e-4)
+    _close(y, yr, "1x1 conv under autograd")
+    _close(xd.grad, xr.grad, "1x1 conv input gradient (split stage)", rtol=2e-4)
+    _close(tc.g[id(wd)], wr.grad, "1x1 conv filter gradient", rtol=2e-4)
 
 
 def test_conv3d_split_through_autograd_matches_the_fp32_kernel(monkeypatch):
