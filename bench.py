@@ -504,7 +504,9 @@ def other_modes(primary):
 
 ALT_DTYPE = {"f32": "exact fp32 everywhere (fp32 MFMA multiply stages)",
              "split": "bf16x3-split operands (three bf16 pieces that sum exactly to the fp32 value: 24-bit operands), fp32 accumulate",
-             "split16": "fp16x2-split of value / power-of-two tensor scale (22-bit operands), fp32 accumulate"}
+             "split16": "fp16x2-split of value / power-of-two tensor scale (22-bit operands; ONE scale per tensor: a region 2^15 / 2^20 below the "
+                        "tensor's max|x| is computed with 2.8x / 88x the exact route's error relative to its OWN magnitude -- profiles/r05_regional_range.md; "
+                        "max-norm error below the exact route's on every case), fp32 accumulate"}
 LINE_DTYPE = {"f32": "f32", "split": "f32 (multiply stages: bf16x3-split operands, fp32 accumulate)",
               "split16": "f32 (multiply stages: fp16x2-split operands of value / tensor scale -- 22-bit, fp32 accumulate)"}
 ALT_WHAT = {

@@ -742,6 +742,194 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 2b.  The same GEMM items with FOUR waves per workgroup (one per SIMD): wave tile 128 x 128 = 4 x 4 MFMA tiles, 256 accumulators
+// (the whole accumulator half of a 512-register wave), 2 x 2 waves over the 256 x 256 block.  Why: per K step the
+// 8-wave kernel reads 18 fragment sets for 48 MFMAs per wave, this one 24 for 96 -- a third fewer LDS bytes per MFMA, which is the one lever
+// on the POWER the stage runs into (MFMA busy 0.74 at 1.75 GHz) rather than on a stall count -- and a step's barrier is met by four waves
+// instead of eight.  With one wave per SIMD nothing hides a wave's own latencies but its own instruction stream: the V fragments of a
+// step are all read one step ahead (double-buffered: 2 x 48 registers), the U fragments one channel tile ahead, the stage-after-next's DMA
+// pieces go out between the MFMA groups.  Whole 256-row items only (ragged blocks and partial rounds stay on the 8-wave kernel's half items).
+// Selected per launch by RN_WINO_BF3_W4 (default: see gemm_split_planes).
+template <class F, int TAG>
+__global__ __launch_bounds__(256, 1)
+void wino_gemm_bf3_w4_kernel(const Bf3GemmArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename F::frag frag;
+    constexpr int NP = F::NP, SB_ROW = F::ROW, SB_UB = SB_BN * SB_ROW;
+    constexpr int BM = 256, VB = BM * SB_ROW, STAGE = VB + SB_UB;     // B3: 24 + 24 KiB, H2: 16 + 16
+    constexpr int NPIECE = STAGE / 4096;                               // DMA pieces (1 KiB) per wave and stage: 12 | 8
+    constexpr int NVP = VB / 4096;                                     // ... of which V: 6 | 4
+    constexpr int NSTORE = 4 * 4 * 4;                                  // 16-byte stores of a wave's epilogue
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hb = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned vfrag[NP], ufrag[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        vfrag[p] = (unsigned)((wm * 128 + l32) * SB_ROW) + F::chunk(l32, p, hb);
+        ufrag[p] = (unsigned)(VB + (wn * 128 + l32) * SB_ROW) + F::chunk(l32, p, hb);
+    }
+    const unsigned dma_lane = (unsigned)(wave * 1024 + lane * 16);
+
+    struct Item { const char* vplane; const char* upanel; float* mplane; long long m0; int nb; };
+    const int rounds_total = (a.item_end - a.item_begin) * a.parts;
+    const int perm = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    auto decode = [&](int r, Item& it) -> bool {
+        const int id = r * (int)gridDim.x + perm;
+        if (id >= rounds_total) return false;
+        const int L = a.item_begin + id / a.parts, h = id % a.parts;
+        const int nb = L % a.nblocks;
+        const int mbx = L / a.nblocks;
+        const int mb = a.mb_begin + mbx % a.mblocks, xi = mbx / a.mblocks;
+        it.nb = nb;
+        it.m0 = (long long)mb * a.mrows + h * BM;
+        it.vplane = a.V + (size_t)xi * a.ksteps * a.v_step_bytes;
+        it.upanel = a.U + ((size_t)xi * a.nblocks + nb) * ((size_t)a.ksteps * SB_UB);
+        it.mplane = a.M + (size_t)xi * a.T * a.Cout;
+        return true;
+    };
+    // piece j of a stage's DMAs of this wave: j < NVP the V pieces (rows wave + 4 j of the 1-KiB grid), then the U pieces.  `oob` = 2^31
+    // turns the piece into a zero fill of its LDS slot (offset beyond the buffer window): the step issues its pieces UNCONDITIONALLY -- a
+    // branch around each of them cuts the step into basic blocks, and hipcc then drains the LDS counter at every join instead of where a
+    // fragment is first used; with one wave per SIMD that wait is on the critical path.  (The zero-filled stage is never read: there is no
+    // next item.)
+    auto issue_piece = [&](const Item& it, int s, int buf, int j, unsigned oob) {
+        char* sb = smem + buf * STAGE;
+        if (j < NVP) {
+            const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
+            const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 4 * j) * 1024), 16, (vo + j * 4096) | oob, 0, 0, 0);
+        } else {
+            const int i = j - NVP;
+            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 4 * i) * 1024), 16, (dma_lane + i * 4096) | oob, 0, 0, 0);
+        }
+    };
+    auto issue = [&](const Item& it, int s, int buf) {
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) issue_piece(it, s, buf, j, 0u);
+    };
+    // all but the newest stage's DMAs of this wave (always NPIECE: see above) have landed (behind an item's end its 64 stores sit in front of
+    // them: the counter holds 63 at most, so the first step of an item also waits for the oldest of those stores), then the barrier
+    auto wait_stage = [&](bool after_store) {
+        if (after_store) { BF3_WAIT_BARRIER(63); return; }
+        if constexpr (NPIECE == 12) BF3_WAIT_BARRIER(12); else BF3_WAIT_BARRIER(8);
+    };
+    static_assert(NPIECE == 12 || NPIECE == 8, "counted waits");
+
+    f32x16 acc[4][4];
+    auto ldv = [&](const char* sb, int mt, frag (&v)[NP]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const frag*>(sb + vfrag[p] + mt * (32 * SB_ROW));
+    };
+    auto ldu = [&](const char* sb, int nt, frag (&u)[NP]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) u[p] = *reinterpret_cast<const frag*>(sb + ufrag[p] + nt * (32 * SB_ROW));
+    };
+    auto grp = [&](const frag (&v)[NP], const frag (&u)[NP], f32x16& c) {
+#pragma unroll
+        for (int k = 0; k < F::NPROD; ++k) c = F::mfma(u[F::PU[k]], v[F::PV[k]], c);
+    };
+
+    Item cur, nxt;
+    if (!decode(0, cur)) return;
+    bool have_next = decode(1, nxt);
+    frag va[4][NP], vb[4][NP], ua[NP], ub[NP];
+    issue(cur, 0, 0);
+    issue(cur, 1, 1);
+    wait_stage(false);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ldv(smem, mt, va[mt]);
+    ldu(smem, 0, ua);
+    int buf = 0;
+    bool after_store = false;
+
+    // One K step: 16 (row tile, channel tile) groups, channel tile by channel tile; the V fragments v0 of all four row tiles were read during
+    // the previous step, the next channel tile's U fragments are read one tile ahead; before the last channel tile the next stage is waited
+    // for and the barrier taken (nobody reads this stage any more), and the next step's V fragments (v1) and first U fragments are read
+    // under the last 24 MFMAs.
+    auto step = [&](int s, frag (&v0)[4][NP], frag (&v1)[4][NP]) {
+        const char* sb = smem + buf * STAGE;
+        const int bn = buf == SB_NSTAGE - 1 ? 0 : buf + 1;
+        const int b2 = bn == SB_NSTAGE - 1 ? 0 : bn + 1;
+        const int s2 = s + 2;
+        const bool in_item = s2 < a.ksteps;
+        const unsigned oob = (!(a.probe & 1) && (in_item || have_next)) ? 0u : 0x80000000u;
+        const Item& src = in_item ? cur : nxt;
+        const int ss = in_item ? s2 : s2 - a.ksteps;
+        auto dma = [&](int j) { if (j < NPIECE) issue_piece(src, ss, b2, j, oob); };
+        ldu(sb, 1, ub);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { grp(v0[mt], ua, acc[mt][0]); dma(mt); }
+        __builtin_amdgcn_sched_barrier(0);
+        ldu(sb, 2, ua);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { grp(v0[mt], ub, acc[mt][1]); dma(4 + mt); }
+        __builtin_amdgcn_sched_barrier(0);
+        ldu(sb, 3, ub);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { grp(v0[mt], ua, acc[mt][2]); dma(8 + mt); }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_stage(after_store);
+        {   // (unconditional: behind the last step of the last item the fragments read here are never used)
+            const char* sn = smem + bn * STAGE;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) ldv(sn, mt, v1[mt]);
+            ldu(sn, 0, ua);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) grp(v0[mt], ub, acc[mt][3]);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = bn;
+        after_store = false;
+    };
+
+    for (int r = 0;; ++r) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        for (int s = 0; s < a.ksteps; s += 2) {
+            step(s, va, vb);
+            step(s + 1, vb, va);
+        }
+        if (!(a.probe & 2)) {
+            // H2: back to the scale of the fp32 operands (powers of two: exact) -- applied to the four values of a store, not to the 256
+            // accumulators at once (that would pull the whole accumulator file through the vector half)
+            float sc = 1.f;
+            if constexpr (F::ID == 1)
+                sc = h2_scale(__builtin_bit_cast(float, *a.amax_v), a.bound_v) * h2_scale(__builtin_bit_cast(float, *a.amax_u), a.bound_u);
+            const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
+            const unsigned mo = (unsigned)(((cur.m0 + wm * 128 + l32) * a.Cout + cur.nb * SB_BN + wn * 128 + hb * 4) * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 o = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                        if constexpr (F::ID == 1) o *= sc;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), mrsrc,
+                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, 0);
+                    }
+            static_assert(NSTORE == 64, "the counted waits assume this many stores per wave");
+            after_store = true;
+        }
+        if (!have_next) break;
+        cur = nxt;
+        have_next = decode(r + 2, nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the zero-fill pieces of the last steps must not outlive the workgroup's LDS
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // `scheme` of the entry points below = Winograd scheme | operand format << 8 (RN_SPLIT_FMT_H2 = 0x100: two fp16 pieces of the scaled
 // value, three products; 0: three bf16 pieces, six products).
 namespace {
@@ -908,8 +1096,38 @@ static int wino_gemm_bf3_launch_w(int tag, const Bf3GemmArgs& a, int begin, int 
     }
 }
 
+template <class F, int TAG>
+static int wino_gemm_bf3_w4_launch_t(Bf3GemmArgs a, int begin, int end, hipStream_t st)
+{
+    a.item_begin = begin; a.item_end = end; a.parts = 1;
+    const size_t lds = (size_t)SB_NSTAGE * (256 * F::ROW + SB_BN * F::ROW);
+    auto kern = wino_gemm_bf3_w4_kernel<F, TAG>;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
+    const int n = end - begin;
+    hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(256), lds, st, a);
+    return rn_check_launch("wino_gemm_bf3_w4");
+}
+
+template <class F>
+static int wino_gemm_bf3_w4_launch(int tag, const Bf3GemmArgs& a, int begin, int end, hipStream_t st)
+{
+    switch (tag) {
+    case 0: return wino_gemm_bf3_w4_launch_t<F, 0>(a, begin, end, st);
+    case 1: return wino_gemm_bf3_w4_launch_t<F, 1>(a, begin, end, st);
+    case 2: return wino_gemm_bf3_w4_launch_t<F, 2>(a, begin, end, st);
+    case 4: return wino_gemm_bf3_w4_launch_t<F, 4>(a, begin, end, st);
+    case 5: return wino_gemm_bf3_w4_launch_t<F, 5>(a, begin, end, st);
+    default: return wino_gemm_bf3_w4_launch_t<F, 3>(a, begin, end, st);
+    }
+}
+
+// RN_WINO_BF3_W4: 1 = whole 256-row items on the four-wave kernel (128 x 128 wave tiles), 0 = on the eight-wave kernel
+static int w4_mode() { static const int m = getenv("RN_WINO_BF3_W4") ? atoi(getenv("RN_WINO_BF3_W4")) : 0; return m; }
+
 static int wino_gemm_bf3_launch(int fmt, int wm, int tag, const Bf3GemmArgs& a, int begin, int end, int parts, hipStream_t st)
 {
+    // (format B3 only: the H2 instance of the four-wave kernel spills -- 256 + 11 vector registers -- and stays on the eight-wave kernel)
+    if (fmt == 0 && wm == 4 && parts == 0 && w4_mode() && a.ksteps % 2 == 0) return wino_gemm_bf3_w4_launch<FmtB3>(tag, a, begin, end, st);
     if (fmt == 1) return wm == 4 ? wino_gemm_bf3_launch_w<FmtH2, 4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<FmtH2, 2>(tag, a, begin, end, parts, st);
     return wm == 4 ? wino_gemm_bf3_launch_w<FmtB3, 4>(tag, a, begin, end, parts, st) : wino_gemm_bf3_launch_w<FmtB3, 2>(tag, a, begin, end, parts, st);
 }
