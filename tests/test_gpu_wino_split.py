@@ -322,6 +322,38 @@ class _TrainStub:
         pass
 
 
+def test_four_wave_gemm_variant_is_bit_identical(tmp_path):
+    """RN_WINO_BF3_W4=1: whole 256-row items of the bf16x3 GEMM stage on the four-wave kernel (128 x 128 wave tiles, one wave per SIMD;
+    csrc/conv_wino_bf3.hip: wino_gemm_bf3_w4_kernel).  Every output element sums the same piece products over the same K steps in the same
+    order as on the eight-wave kernel, so the two builds of the stage must agree BIT FOR BIT (the variant exists for the measurement that
+    showed the stage to be power-bound: same time on both kernels, profiles/r05_gemm_w4_ab.txt).  The switch is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rendernet_amd import ops\n"
+        "ops.WINO_GEMM = 'split'\n"
+        "rng = np.random.default_rng(3)\n"
+        "outs = []\n"
+        "for (B, hw, cin, cout, k) in ((5, 64, 64, 256, 3), (9, 64, 96, 512, 3), (4, 64, 64, 256, 4)):\n"      # T = 605 / 1089 / 1024: whole blocks + ragged rows
+        "    x = torch.as_tensor(rng.standard_normal((B, hw, hw, cin)).astype(np.float32)).cuda()\n"
+        "    w = torch.as_tensor((0.05 * rng.standard_normal((k, k, cin, cout))).astype(np.float32)).cuda()\n"
+        "    with torch.no_grad():\n"
+        "        outs.append(ops.conv2d(x, ops.pack_conv(w)).cpu().numpy())\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    got = {}
+    for w4 in ("0", "1"):
+        out = str(tmp_path / ("w4_%s.npz" % w4))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, RN_WINO_BF3_W4=w4), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[w4] = np.load(out)
+    for k in got["0"].files:
+        assert np.array_equal(got["0"][k], got["1"][k]), k
+        assert np.isfinite(got["1"][k]).all() and np.abs(got["1"][k]).max() > 0
+
+
 CASES_1X1 = [   # (B, H, W, Cin, Cout): pixel counts below / across / above the 256-row block and the 8-pixel transform group, 2 .. 64 K steps
     (1, 3, 5, 32, 256), (1, 16, 16, 64, 256), (2, 17, 15, 1024, 512), (3, 64, 64, 256, 256), (1, 64, 64, 1024, 1024), (5, 9, 7, 96, 768),
 ]
