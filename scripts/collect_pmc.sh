@@ -28,11 +28,15 @@ for tag in sq fetch write tcc; do
     case $tag in
         sq) C=$SQ ;; fetch) C="FETCH_SIZE" ;; write) C="WRITE_SIZE" ;; tcc) C=$TCC ;;
     esac
+    # PMC_SET=full: every kernel family of rounds 2-4; default (round 5): the kernels the bench lines quote `traffic` for (the res2 GEMM stage in
+    # all three modes: bf3_check.py runs the fp32 stages, then the split ones), the 3-D split kernel and the resampler
+    if [ "${PMC_SET:-}" = full ]; then
     run wino63 $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --only f63
     run wino43 $tag $C -- python "$R/scripts/wino_bench.py" --shapes 64x1024 --iters 3 --only f43
-    run bf3 $tag $C -- python "$R/scripts/bf3_check.py" --no-accuracy --iters 3 --shapes 0          # res2 shape, F(6x6,3x3): fp32 stages, then the split ones
     RN_NO_WINOGRAD3D=1 run res1 $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
-    run res1w $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    RN_WINO_GEMM=f32 run res1w $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3
+    fi
+    run bf3 $tag $C -- python "$R/scripts/bf3_check.py" --no-accuracy --iters 3 --shapes 0          # res2 shape, F(6x6,3x3): fp32 stages, then the split ones
     RN_CONV3D_SPLIT=1 run res1s $tag $C -- python "$R/scripts/layer_bench.py" --only res1 --iters 3        # the bf16x3 kernel on the same layer
     run resample $tag $C -- python "$R/scripts/layer_bench.py" --only resample --iters 5 --no-dense
 done

@@ -17,7 +17,8 @@ csv.field_size_limit(1 << 30)
 KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s), algorithmic bytes per launch at B=24)
     # the GEMM stage runs as two launches: full rounds with 256-row blocks (<4, .>) and the last partial round as 128-row blocks (<2, .>)
     # F(6x6,3x3): T = 24 * 11 * 11 = 2904 tiles, 64 planes; 11 whole rounds of 256-row blocks (<4, 3>) + the ragged last block as 128-row items (<2, 3>)
-    "wino63_gemm_res2": ("wino63", ["wino43_gemm_kernel<4, 3>", "wino43_gemm_kernel<2, 3>"], 64 * 2904 * (1024 + 1024) * 4 + 64 * 1024 * 1024 * 4),
+    # (round 5: from the `bf3` pass -- scripts/bf3_check.py times the exact-fp32 stages first, then the split ones, on the same shape)
+    "wino63_gemm_res2": ("bf3", ["wino43_gemm_kernel<4, 3>", "wino43_gemm_kernel<2, 3>"], 64 * 2904 * (1024 + 1024) * 4 + 64 * 1024 * 1024 * 4),
     "wino63_input_res2": ("wino63", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 4),
     "wino63_output_res2": ("wino63", ["wino_output_kernel"], 64 * 2904 * 1024 * 4 + 24 * 64 * 64 * 1024 * 4),
     # split (bf16x3) route, same shape: V and U are 6 bytes per element (three bf16 pieces), M stays fp32

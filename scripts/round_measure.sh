@@ -12,42 +12,34 @@ python bench.py --steps 20 --warmup 3 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_ben
 python bench.py --mode texture --steps 20 --warmup 3 > "$O/${TAG}_bench_texture.json" 2>> "$O/${TAG}_bench.err"
 python bench.py --mode stress --steps 5 --warmup 2 > "$O/${TAG}_bench_stress.json" 2>> "$O/${TAG}_bench.err"
 python bench.py --mode train --steps 10 --warmup 3 > "$O/${TAG}_bench_train.json" 2>> "$O/${TAG}_bench.err"
-RN_NO_WINOGRAD63=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$O/${TAG}_bench_f43only.json" 2>> "$O/${TAG}_bench.err"
 {
-  echo "# python bench.py --batch B --steps 10 --warmup 3 --no-cpu-baseline, one MI355X, git ${GIT_REV:-?}"
+  echo "# python bench.py --batch B --steps 10 --warmup 3 --no-cpu-baseline, one MI355X, git ${GIT_REV:-?}; value = the default mode (bf16x3 split multiply stages)"
   for b in 1 3 6 12 24 48; do
     python bench.py --batch $b --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-a = d.get('alt') or {}
+e = d.get('exact') or {}
 a2 = d.get('alt2') or {}
-print('batch %3d  fp32 GEMM stage %8.2f frames/s  %8.2f ms/step  frac %.3f   |   split (bf16x3) %8.2f frames/s  %8.2f ms/step  frac %.3f (of bf16 peak / 6)   |   split16 (fp16x2) %8.2f frames/s  %8.2f ms/step  frac %.3f (of fp16 peak / 3)'
-      % ($b, d['value'], d['ms_per_step'], d['roofline']['frac'], a.get('value', 0), a.get('ms_per_step', 0), (a.get('roofline') or {}).get('frac', 0),
+print('batch %3d  default (bf16x3) %8.2f frames/s  %8.2f ms/step  frac %.3f (of bf16 peak / 6)   |   exact fp32 %8.2f frames/s  %8.2f ms/step  frac %.3f (of the fp32 MFMA peak)   |   split16 (fp16x2) %8.2f frames/s  %8.2f ms/step  frac %.3f (of fp16 peak / 3)'
+      % ($b, d['value'], d['ms_per_step'], d['roofline']['frac'], e.get('value', 0), e.get('ms_per_step', 0), (e.get('roofline') or {}).get('frac', 0),
          a2.get('value', 0), a2.get('ms_per_step', 0), (a2.get('roofline') or {}).get('frac', 0)))"
   done
 } > "$O/${TAG}_batch_sweep.txt"
 {
-  echo "# scripts/wino_stage_bench.py / res1_bench.py / outin_bench.py, one MI355X, git ${GIT_REV:-?}"
-  python scripts/wino_stage_bench.py --shapes 64x1024,64x512 --batch 24 2>&1 | grep -v amdgpu.ids
-  python scripts/res1_bench.py 2>&1 | grep -v amdgpu.ids
-  echo "# scripts/bf3_check.py --no-accuracy: the three stages, exact-fp32 multiply stage vs bf16x3 split"
+  echo "# scripts/bf3_check.py --no-accuracy: the three stages, exact-fp32 multiply stage vs bf16x3 / fp16x2 split; one MI355X, git ${GIT_REV:-?}"
   python scripts/bf3_check.py --no-accuracy --batch 24 2>&1 | grep -v amdgpu.ids
   echo "# scripts/wgrad_split_bench.py: F(4x4,3x3) / F(4x4,4x4) filter gradient at crop 64, exact fp32 vs split (all four launches)"
   python scripts/wgrad_split_bench.py 2>&1 | grep -v amdgpu.ids
-  echo "# scripts/c3_check.py: fused 3x3x3 32 -> 32 kernel, fp32 vs bf16x3 split"
-  python scripts/c3_check.py 2>&1 | grep -v amdgpu.ids
-  for l in e_conv7 e_conv8 e_conv9; do
-    RN_NO_WINOGRAD_S2=1 python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (direct phase kernels)/'
-    python scripts/layer_bench.py --only $l --iters 20 2>&1 | grep "^e_conv" | grep -v "_1" | sed 's/$/   (F(2x2,2x2) per phase)/'
-  done
+  echo "# scripts/c3_check.py: fused 3x3x3 32 -> 32 kernel, fp32 vs bf16x3 / fp16x2 split"
+  python scripts/c3_check.py --no-accuracy 2>&1 | grep -v amdgpu.ids
+  echo "# scripts/latency_bench.py: single-frame latency, eager vs hipGraph replay, default mode"
+  python scripts/latency_bench.py 2>&1 | grep -v amdgpu.ids
 } > "$O/${TAG}_stage_ab.txt"
-bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_render --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1                       # the default mode (bf16x3)
+bash scripts/profile_bench.sh ${TAG}_render_exact --gemm f32 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
+bash scripts/profile_bench.sh ${TAG}_render_split16 --gemm split16 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_texture --mode texture --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_train --mode train --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_render_split --gemm split --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_render_split16 --gemm split16 --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_train_split --mode train --gemm split --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
-bash scripts/profile_bench.sh ${TAG}_train_split16 --mode train --gemm split16 --steps 3 --warmup 2 --no-cpu-baseline --no-alt > /dev/null 2>&1
 bash scripts/profile_bench.sh ${TAG}_b3 --batch 3 --steps 10 --warmup 3 --no-cpu-baseline --no-alt > /dev/null 2>&1
 tail -3 "$O/${TAG}_bench.err"
 cut -c1-250 "$O/${TAG}_bench.json"
