@@ -462,6 +462,12 @@ int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B, int H, in
                     int Cin, int Cout, const int* ksize, const int* stride, void* stream);
 int rn_conv2d_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
                     int Cin, int Cout, const int* ksize, const int* stride, void* stream);
+/* rn_conv3d_wgrad for the 3x3x3, stride-1, 32 -> 32 convs of the 3-D encoder (res_block_3d / res1_skip: tools/layer_util.py:60-73,
+ * RenderNet_Shader.py:51-64; tf.nn.conv3d_backprop_filter_v2 under AdamOptimizer.minimize, :165-167) with the reduction over the positions
+ * on the bf16 matrix pipe at fp32 accuracy: every fp32 value of x and dz as three bf16 pieces (exact sum, made on the fly), six piece
+ * products, fp32 accumulation -- the arithmetic of the split forward entries.  Same contract: dw [3,3,3,32,32] ACCUMULATED with fp32 atomics. */
+int rn_conv3d_wgrad_split_supported(int Cin, int Cout);
+int rn_conv3d_wgrad_split(const float* x, const float* dz, float* dw, int B, int H, int W, int D, int Cin, int Cout, void* stream);
 int rn_conv2d_transpose_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W,
                               int Cin, int Cout, int ksize, int stride, void* stream);
 /* rn_conv2d_wgrad for the 3x3, stride-1 convs (res_block_2d, *_skip: tools/layer_util.py:101-104) through the Winograd

@@ -68,6 +68,8 @@ SIGNATURES = {
     "rn_conv3d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_vp]),
     "rn_conv3d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
     "rn_conv2d_wgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
+    "rn_conv3d_wgrad_split_supported": (_c_int, [_c_int, _c_int]),
+    "rn_conv3d_wgrad_split": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_c_vp]),
     "rn_conv2d_wino43_supported": (_c_int, [_c_int, _c_int]),
     "rn_conv2d_wino43_workspace_floats": (ctypes.c_size_t, [_c_int] * 5),
     "rn_conv2d_wino43_fwd": (_c_int, [_c_vp] * 8 + [_c_int] * 6 + [_c_vp]),

@@ -385,6 +385,13 @@ extern "C" int rn_conv3d_wgrad(const float* x, const float* dz, float* dw, int B
     return conv_wgrad_nd(x, dz, dw, B, I, Cin, Cout, ksize, stride, (hipStream_t)stream, "rn_conv3d_wgrad");
 }
 
+extern "C" int rn_conv3d_wgrad_split_supported(int Cin, int Cout) { return rn_conv3d_wgrad_split_ok(Cin, Cout) ? 1 : 0; }
+extern "C" int rn_conv3d_wgrad_split(const float* x, const float* dz, float* dw, int B, int H, int W, int D, int Cin, int Cout, void* stream)
+{
+    if (!rn_conv3d_wgrad_split_ok(Cin, Cout)) return rn_set_error(RN_E_UNSUPPORTED, "rn_conv3d_wgrad_split: Cin=%d Cout=%d (3x3x3, stride 1, 32 -> 32 only)", Cin, Cout);
+    return rn_launch_conv3d_wgrad_split(x, dz, dw, B, H, W, D, (hipStream_t)stream);
+}
+
 extern "C" int rn_conv2d_wino43_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F43, Cin, Cout) ? 1 : 0; }
 extern "C" int rn_conv2d_wino44_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F44, Cin, Cout) ? 1 : 0; }
 extern "C" int rn_conv2d_wino63_supported(int Cin, int Cout) { return rn_wino43_supported(RN_WINO_F63, Cin, Cout) ? 1 : 0; }

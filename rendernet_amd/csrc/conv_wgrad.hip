@@ -434,6 +434,31 @@ struct Wgrad3Args {
     int H, W, D, ncols, ndch, nitems, ipw, nsplit;
 };
 
+// SPLIT (round 5; rn_conv3d_wgrad_split): the same reduction on the bf16 matrix pipe at fp32 accuracy -- every fp32 value of the two slabs
+// as three bf16 pieces (exact sum), the six piece products with i + j <= 2, fp32 accumulation (conv_wino_bf3.hip has the arithmetic).  The
+// pieces are made ON THE FLY from the fp32 slabs in LDS (the operands stay 4 bytes per element on their nine trips through L2): per 16
+// depth positions a lane reads the 10 slab rows its three depth taps touch and 8 rows of G for its channel, splits them pairwise (positions
+// e, e + 1 land in one register = one k pair of a v_mfma_f32_32x32x16_bf16 operand; the odd tap's operand is the even ones' registers
+// shifted by 16 bits), and issues 3 taps x 6 products -- about 95 vector instructions per 18 MFMAs of 32 cycles, against 24 exact-fp32
+// MFMAs of 64 cycles for the same positions.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> the three packed bf16 pairs of their pieces (round to nearest even; the remainders are exact in fp32)
+__device__ __forceinline__ void wg_split_pair(float a, float b, unsigned (&p)[3])
+{
+    wg_f32x2 v = {a, b};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const wg_bf16x2 h = __builtin_convertvector(v, wg_bf16x2);
+        p[q] = __builtin_bit_cast(unsigned, h);
+        if (q < 2) v -= __builtin_convertvector(h, wg_f32x2);
+    }
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
 {
@@ -534,6 +559,46 @@ void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
         if (item + 1 < iend) issue_dma((n + 1) & 1, item + 1, cur ^ 1);
         // the column table of item + 2 goes where item's was: item's DMA was issued one iteration ago, and the
         // table of item + 1 (read just above) sits in the other slot
+        if constexpr (SPLIT) {
+            // lane (li, lh): k group lh of a 16-position block = positions 16 kb + 8 lh + e, e = 0..7; slab row of tap t2 = position + t2
+            const float* Ab = As + cur * ASZ + (wave * ROWS + 8 * lh) * C + li;
+            const float* Gb = Gs + cur * GSZ + (wave * TD + 8 * lh) * C + li;
+#pragma unroll
+            for (int kb = 0; kb < TD / 16; ++kb) {
+                float xv[10], gv[8];
+#pragma unroll
+                for (int e = 0; e < 10; ++e) xv[e] = Ab[(16 * kb + e) * C];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] = Gb[(16 * kb + e) * C];
+                unsigned xp[5][3], gp[4][3];                      // [position pair][piece]
+#pragma unroll
+                for (int q = 0; q < 5; ++q) wg_split_pair(xv[2 * q], xv[2 * q + 1], xp[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wg_split_pair(gv[2 * q], gv[2 * q + 1], gp[q]);
+                wg_bf16x8 xa[3][3], gb[3];                        // [tap][piece], [piece]
+#pragma unroll
+                for (int p_ = 0; p_ < 3; ++p_) {
+                    const wg_u32x4 t0v = {xp[0][p_], xp[1][p_], xp[2][p_], xp[3][p_]};
+                    const wg_u32x4 t2v = {xp[1][p_], xp[2][p_], xp[3][p_], xp[4][p_]};
+                    wg_u32x4 t1v;                                 // positions 1..8: the pairs (1,2) (3,4) (5,6) (7,8)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t1v[q] = (xp[q][p_] >> 16) | (xp[q + 1][p_] << 16);
+                    xa[0][p_] = __builtin_bit_cast(wg_bf16x8, t0v);
+                    xa[1][p_] = __builtin_bit_cast(wg_bf16x8, t1v);
+                    xa[2][p_] = __builtin_bit_cast(wg_bf16x8, t2v);
+                    const wg_u32x4 gq = {gp[0][p_], gp[1][p_], gp[2][p_], gp[3][p_]};
+                    gb[p_] = __builtin_bit_cast(wg_bf16x8, gq);
+                }
+                // the six piece products with i + j <= 2, smallest terms first; the three taps interleaved (MFMAs on one accumulator three apart)
+                constexpr int PX[6] = {2, 1, 0, 1, 0, 0}, PG[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][PX[k]], gb[PG[k]], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][PX[k]], gb[PG[k]], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2][PX[k]], gb[PG[k]], acc2, 0, 0, 0);
+                }
+            }
+        } else {
         const float* Ab = As + cur * ASZ + (wave * ROWS + lh) * C + li;     // slab row (2kk + lh) + t2
         const float* Gb = Gs + cur * GSZ + (wave * TD + lh) * C + li;
         float g[2], x0[2], x1[2], x2[2];
@@ -549,6 +614,7 @@ void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[kk & 1], g[kk & 1], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x2[kk & 1], g[kk & 1], acc2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         setup_cols(n & 1, item + 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,7 +640,7 @@ void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
 }
 
 static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, int H, int W, int D,
-                              unsigned a_bytes, unsigned g_bytes, hipStream_t st)
+                              unsigned a_bytes, unsigned g_bytes, hipStream_t st, bool split = false)
 {
     Wgrad3Args a;
     a.a = A; a.g = G; a.dw = dw; a.a_bytes = a_bytes; a.g_bytes = g_bytes;
@@ -590,9 +656,33 @@ static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, 
     a.nsplit = (a.nitems + a.ipw - 1) / a.ipw;
     const long long nb = (long long)((a.nsplit + 7) / 8) * 72;
     const size_t lds = (size_t)2 * (136 * 32 + 128 * 32) * 4;
-    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_k3d32_kernel), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
-    hipLaunchKernelGGL(conv_wgrad_k3d32_kernel, dim3((unsigned)nb), dim3(256), lds, st, a);
-    return rn_check_launch("conv_wgrad_k3d32");
+    void (*kern)(const Wgrad3Args) = split ? conv_wgrad_k3d32_kernel<true> : conv_wgrad_k3d32_kernel<false>;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds)); if (rc_ != RN_OK) return rc_; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch(split ? "conv_wgrad_k3d32 (bf16x3)" : "conv_wgrad_k3d32");
+}
+
+// 3x3x3, stride 1, 32 -> 32 (x [B,H,W,D,32], dz likewise) on the bf16 pipe: dw [3,3,3,32,32] += ...; batch chunks keep the byte offsets below 2^31
+bool rn_conv3d_wgrad_split_ok(int Cin, int Cout)
+{
+    static const bool off = getenv("RN_NO_WGRAD3D_SPLIT") != nullptr;
+    return !off && Cin == 32 && Cout == 32;
+}
+
+int rn_launch_conv3d_wgrad_split(const float* x, const float* dz, float* dw, int B, int H, int W, int D, hipStream_t st)
+{
+    if (!x || !dz || !dw) return rn_set_error(RN_E_INVALID, "conv3d_wgrad_split: null pointer");
+    if (B < 1 || H < 1 || W < 1 || D < 1) return rn_set_error(RN_E_INVALID, "conv3d_wgrad_split: bad sizes");
+    const long long item = (long long)H * W * D * 32 * 4;
+    if (item >= 0x80000000LL) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wgrad_split: one batch item exceeds the 2 GiB buffer window");
+    const int chunk = (int)(0x7fffffffLL / item);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = B - b0 < chunk ? B - b0 : chunk;
+        const size_t off = (size_t)b0 * (item / 4);
+        const int rc = launch_wgrad_k3d32(x + off, dz + off, dw, nb, H, W, D, (unsigned)(item * nb), (unsigned)(item * nb), st, true);
+        if (rc != RN_OK) return rc;
+    }
+    return RN_OK;
 }
 
 // A [B,I0,I1,I2,Ca], G [B,O0,O1,O2,Cg] -> dw [K0,K1,K2,Ca,Cg] (accumulated)

@@ -109,6 +109,8 @@ int rn_launch_conv_wino43_wgrad(int scheme, const float* x, const float* dz, flo
 bool rn_wino_wgrad_supported(int Cin, int Cout);                                                          // conv_wino_wgrad.hip
 int rn_launch_conv_wino_wgrad(const float* x, const float* dz, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t st);
 
+bool rn_conv3d_wgrad_split_ok(int Cin, int Cout);
+int rn_launch_conv3d_wgrad_split(const float* x, const float* dz, float* dw, int B, int H, int W, int D, hipStream_t st);
 int rn_launch_conv_wgrad(const float* A, const float* G, float* dw, int B, const int* I, int Ca,
                          const int* O, int Cg, const int* K, const int* S, const int* P, hipStream_t st);   // conv_wgrad.hip
 int rn_launch_conv_dgrad_direct(const float* dz, const float* w_fwd_packed, float* dx, int B, const int* I, int Cin,

@@ -782,6 +782,10 @@ class _Conv(torch.autograd.Function):
             B, H, W, Cin = x.shape
         if dw is None:
             rc = 0
+        elif (mode == "conv3d" and unit and tuple(ksize) == (3, 3, 3) and WINO_GEMM in ("split", "split16") and WGRAD_SPLIT
+              and lib.rn_conv3d_wgrad_split_supported(Cin, pw.cout)):
+            # the 3-D encoder's 32 -> 32 filter gradients: the reduction over the positions on the bf16 pipe (bf16x3 in both split modes)
+            rc = lib.rn_conv3d_wgrad_split(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, st)
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
         elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and WINO_GEMM in ("split", "split16") and WGRAD_SPLIT

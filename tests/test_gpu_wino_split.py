@@ -452,6 +452,37 @@ def test_projection_unit_on_the_split_stage(smode, monkeypatch):
     _close(tc.g[id(wd)], wr.grad, "1x1 conv filter gradient", rtol=2e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 40, 6), (1, 8, 8, 33), (3, 16, 16, 16), (1, 5, 7, 1), (24, 32, 32, 16)])
+def test_conv3d_wgrad_split(shape):
+    """rn_conv3d_wgrad_split: the filter gradient of the 3-D encoder's 3x3x3 32 -> 32 convs (tf.nn.conv3d_backprop_filter_v2 of slim.conv3d,
+    tools/layer_util.py:60-73) with the reduction over the positions on the bf16 pipe -- against torch-CPU autograd over the oracle conv
+    (1e-4 * max|ref|, the bar of the exact kernel), against the exact-fp32 kernel (3e-5 * max: two fp32-class sums of the same terms), and
+    ACCUMULATING into dw (two calls = twice the gradient).  Depths that are not multiples of the 16-position block / 32-position stage, one
+    position, the benched shape (crop 64: B = 24, 32 x 32 x 16)."""
+    from rendernet_amd import _lib as L
+    B, H, W, D = shape
+    rng = np.random.default_rng(B * 131 + D)
+    x = rng.standard_normal((B, H, W, D, 32)).astype(np.float32)
+    dz = rng.standard_normal((B, H, W, D, 32)).astype(np.float32)
+    lib = L.lib()
+    assert lib.rn_conv3d_wgrad_split_supported(32, 32) == 1 and lib.rn_conv3d_wgrad_split_supported(16, 16) == 0
+    xd, dzd = _dev(x), _dev(dz)
+    dws = torch.zeros((3, 3, 3, 32, 32), device="cuda")
+    dwe = torch.zeros_like(dws)
+    L.check(lib.rn_conv3d_wgrad_split(L.ptr(xd), L.ptr(dzd), L.ptr(dws), B, H, W, D, 32, 32, L.stream_ptr()), "rn_conv3d_wgrad_split")
+    L.check(lib.rn_conv3d_wgrad(L.ptr(xd), L.ptr(dzd), L.ptr(dwe), B, H, W, D, 32, 32, L.ivec((3, 3, 3)), L.ivec((1, 1, 1)), L.stream_ptr()), "rn_conv3d_wgrad")
+    ref = float(dwe.abs().max())
+    assert float((dws - dwe).abs().max()) <= 3e-5 * ref, (float((dws - dwe).abs().max()), ref)
+    if B * H * W * D <= 20000:                                      # oracle autograd where the CPU conv is quick
+        w = torch.zeros((3, 3, 3, 32, 32), requires_grad=True)
+        OL.conv3d(torch.from_numpy(x), w, None, (1, 1, 1)).backward(torch.from_numpy(dz))
+        _close(dws, w.grad, "split 3-D filter gradient vs oracle autograd")
+    once = dws.clone()
+    L.check(lib.rn_conv3d_wgrad_split(L.ptr(xd), L.ptr(dzd), L.ptr(dws), B, H, W, D, 32, 32, L.stream_ptr()), "rn_conv3d_wgrad_split")
+    assert float((dws - 2 * once).abs().max()) <= 2e-6 * ref       # (fp32 atomics: the order of the partial sums varies)
+    assert lib.rn_conv3d_wgrad_split(L.ptr(xd), L.ptr(dzd), L.ptr(dws), B, H, W, D, 16, 32, L.stream_ptr()) != 0
+
+
 def test_conv3d_split_through_autograd_matches_the_fp32_kernel(monkeypatch):
     """ops.conv3d under autograd (forward with the saved pre-activation, input gradient through the split kernel, filter gradient
     through the shared wgrad kernel) with the opt-in on, against the same layer with it off."""
