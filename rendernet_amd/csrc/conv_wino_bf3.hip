@@ -1079,7 +1079,10 @@ static int wino_gemm_bf3_launch_t(Bf3GemmArgs a, int begin, int end, int parts, 
     auto kern = wino_gemm_bf3_kernel<F, WM, TAG>;
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
     const int n = (end - begin) * a.parts;
-    hipLaunchKernelGGL(kern, dim3(n < 256 ? (unsigned)((n + 7) / 8 * 8) : 256u), dim3(512), lds, st, a);
+    // RN_WINO_BF3_GRID (a multiple of 8, <= 256; measurement): workgroups = CUs the persistent kernel occupies (one workgroup per CU)
+    static const unsigned gmax = getenv("RN_WINO_BF3_GRID") ? (unsigned)atoi(getenv("RN_WINO_BF3_GRID")) / 8 * 8 : 256u;
+    const unsigned cap = gmax >= 8 && gmax <= 256 ? gmax : 256u;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n < cap ? (unsigned)((n + 7) / 8 * 8) : cap), dim3(512), lds, st, a);
     return rn_check_launch("wino_gemm_bf3");
 }
 
