@@ -639,6 +639,208 @@ void conv_wgrad_k3d32_kernel(const Wgrad3Args a)
     }
 }
 
+// ... and with the three taps of one filter ROW (t0 fixed, t1 = 0..2) per workgroup (W % 4 == 0): the stage's four columns (b, h, w0 .. w0 + 3) of G
+// serve all nine (t1, t2) taps of the row, and the A slab needs only the SIX columns w0 - 1 .. w0 + 4 of input row h + t0 - 1 instead of 3 x 4:
+// 21.5 KiB staged per 54 MFMAs per wave instead of 33 KiB per 36 -- the nine-pair form above moves 1.8 GB through L2 for the crop-64 layer
+// (6 TB/s at 0.29 ms: THAT bounds it), this one 0.8 GB.  Stage = 16 depth positions (one k block); wave w = column w0 + w; nine 32 x 32
+// accumulators (144 registers); the four waves' partials are summed through LDS three taps at a time.
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_k3d32_row_kernel(const Wgrad3Args a)
+{
+    constexpr int C = 32, COLS = 4, ACOLS = COLS + 2, TD = 16, ROWS = TD + 2, NAROWS = ACOLS * ROWS;     // 108 slab rows of A
+    constexpr int ASZ = 112 * C;                        // 14 DMA instructions of 8 rows (the last four rows are never read)
+    constexpr int GSZ = COLS * TD * C;                  // 2048 floats: 8 DMA instructions
+    constexpr int NAI = 14, NGI = 8;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);         // [2][112][32]
+    float* Gs = As + 2 * ASZ;                           // [2][64][32]
+    __shared__ unsigned colA[2][ACOLS], colG[2][COLS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    int id = blockIdx.x;
+    const int xs = id & 7; id >>= 3;
+    const int t0 = id % 3, split = (id / 3) * 8 + xs;
+    if (split >= a.nsplit) return;
+    const int ibeg = split * a.ipw, iend = min(a.nitems, ibeg + a.ipw);
+    if (ibeg >= iend) return;
+
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.g_bytes, 0x00020000);
+
+    // DMA assignment.  A: wave w issues instructions q = w, w + 4, ... (< 14); lane -> slab row 8 q + lane / 8 of the flat [6 columns][18 rows]
+    // list, 16-byte chunk lane % 8.  G: wave w issues q = 2 w, 2 w + 1; lane -> row 8 q + lane / 8 of [4 columns][16 rows].
+    int acol[4], arow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = wave + 4 * p;
+        const int rr = q * 8 + (lane >> 3);
+        const bool ok = q < NAI && rr < NAROWS;
+        acol[p] = ok ? rr / ROWS : 0;
+        arow[p] = ok ? rr % ROWS : -0x40000000;
+    }
+    const unsigned cbytes = (unsigned)((lane & 7) * 16);
+    int gcol[2], grow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = (wave * 2 + j) * 8 + (lane >> 3);
+        gcol[j] = rr / TD; grow[j] = rr % TD;
+    }
+
+    // item = (group of four columns, depth chunk of 16): columns (b, h, w0 .. w0 + 3) -- W % 4 == 0, so a group never straddles two rows
+    auto setup_cols = [&](int buf, int item) {
+        if (tid < ACOLS) {
+            const int col0 = (item / a.ndch) * COLS;
+            unsigned ao = OOB, go = OOB;
+            if (item < iend && col0 < a.ncols) {
+                const int w0 = col0 % a.W, h = (col0 / a.W) % a.H, b = col0 / (a.W * a.H);
+                const int hh = h + t0 - 1, ww = w0 - 1 + tid;
+                if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W)
+                    ao = (unsigned)((b * a.H + hh) * a.W + ww) * (unsigned)(a.D * C * 4);
+                if (tid < COLS) go = (unsigned)(col0 + tid) * (unsigned)(a.D * C * 4);
+            }
+            colA[buf][tid] = ao;
+            if (tid < COLS) colG[buf][tid] = go;
+        }
+    };
+    auto issue_dma = [&](int buf, int item, int stage) {
+        const int d0 = (item % a.ndch) * TD;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (wave + 4 * p < NAI) {
+                const unsigned cb = colA[buf][acol[p]];
+                const int dd = d0 - 1 + arow[p];
+                const unsigned off = ((cb & OOB) || (unsigned)dd >= (unsigned)a.D) ? OOB : cb + (unsigned)dd * (C * 4) + cbytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(As + stage * ASZ + (wave + 4 * p) * 256), 16, off, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned cb = colG[buf][gcol[j]];
+            const int dd = d0 + grow[j];
+            const unsigned off = ((cb & OOB) || dd >= a.D) ? OOB : cb + (unsigned)dd * (C * 4) + cbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void*)(Gs + stage * GSZ + (wave * 2 + j) * 256), 16, off, 0, 0, 0);
+        }
+    };
+    static_assert(NGI == 8, "two G instructions per wave");
+
+    f32x16 acc[3][3];                                   // [t1][t2]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    setup_cols(0, ibeg);
+    setup_cols(1, ibeg + 1);
+    __syncthreads();
+    issue_dma(0, ibeg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int item = ibeg; item < iend; ++item) {
+        const int n = item - ibeg;
+        if (item + 1 < iend) issue_dma((n + 1) & 1, item + 1, cur ^ 1);
+        // lane (li, lh): k group lh of the 16-position block = depth positions 8 lh + e, e = 0..7; slab row of tap t2 = position + t2;
+        // tap t1 of column w0 + wave reads A column wave + t1 of the six staged ones
+        const float* Gb = Gs + cur * GSZ + (wave * TD + 8 * lh) * C + li;
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = Gb[e * C];
+        unsigned gp[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wg_split_pair(gv[2 * q], gv[2 * q + 1], gp[q]);
+        wg_bf16x8 gb[3];
+#pragma unroll
+        for (int p_ = 0; p_ < 3; ++p_) {
+            const wg_u32x4 gq = {gp[0][p_], gp[1][p_], gp[2][p_], gp[3][p_]};
+            gb[p_] = __builtin_bit_cast(wg_bf16x8, gq);
+        }
+#pragma unroll
+        for (int t1 = 0; t1 < 3; ++t1) {
+            const float* Ab = As + cur * ASZ + ((wave + t1) * ROWS + 8 * lh) * C + li;
+            float xv[10];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) xv[e] = Ab[e * C];
+            unsigned xp[5][3];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) wg_split_pair(xv[2 * q], xv[2 * q + 1], xp[q]);
+            wg_bf16x8 xa[3][3];                               // [t2][piece]
+#pragma unroll
+            for (int p_ = 0; p_ < 3; ++p_) {
+                const wg_u32x4 e0 = {xp[0][p_], xp[1][p_], xp[2][p_], xp[3][p_]};
+                const wg_u32x4 e2 = {xp[1][p_], xp[2][p_], xp[3][p_], xp[4][p_]};
+                wg_u32x4 e1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e1[q] = (xp[q][p_] >> 16) | (xp[q + 1][p_] << 16);
+                xa[0][p_] = __builtin_bit_cast(wg_bf16x8, e0);
+                xa[1][p_] = __builtin_bit_cast(wg_bf16x8, e1);
+                xa[2][p_] = __builtin_bit_cast(wg_bf16x8, e2);
+            }
+            constexpr int PX[6] = {2, 1, 0, 1, 0, 0}, PG[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                acc[t1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][PX[k]], gb[PG[k]], acc[t1][0], 0, 0, 0);
+                acc[t1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][PX[k]], gb[PG[k]], acc[t1][1], 0, 0, 0);
+                acc[t1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2][PX[k]], gb[PG[k]], acc[t1][2], 0, 0, 0);
+            }
+        }
+        setup_cols(n & 1, item + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // sum the four waves' partial tiles through LDS three taps (one t1) at a time (48 KiB: the stage buffers are dead), one atomic per output
+    float* red = reinterpret_cast<float*>(smem);        // [4 waves][3 taps][32 ca][32 cg]
+#pragma unroll
+    for (int t1 = 0; t1 < 3; ++t1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ca = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            red[((wave * 3 + 0) * C + ca) * C + li] = acc[t1][0][r];
+            red[((wave * 3 + 1) * C + ca) * C + li] = acc[t1][1][r];
+            red[((wave * 3 + 2) * C + ca) * C + li] = acc[t1][2][r];
+        }
+        __syncthreads();
+        float* dwp = a.dw + (size_t)(t0 * 3 + t1) * 3 * C * C;       // taps (t0, t1, 0..2) are adjacent in [3,3,3,Ca,Cg]
+        for (int e = tid; e < 3 * C * C; e += 256) {
+            const float v = (red[e] + red[3 * C * C + e]) + (red[2 * 3 * C * C + e] + red[3 * 3 * C * C + e]);
+            unsafeAtomicAdd(dwp + e, v);
+        }
+        __syncthreads();
+    }
+}
+
+static int launch_wgrad_k3d32_row(const float* A, const float* G, float* dw, int B, int H, int W, int D,
+                                  unsigned a_bytes, unsigned g_bytes, hipStream_t st)
+{
+    Wgrad3Args a;
+    a.a = A; a.g = G; a.dw = dw; a.a_bytes = a_bytes; a.g_bytes = g_bytes;
+    a.H = H; a.W = W; a.D = D;
+    a.ncols = B * H * W;
+    a.ndch = (D + 15) / 16;
+    a.nitems = (a.ncols / 4) * a.ndch;                  // W % 4 == 0: whole groups of four columns
+    static const int target_wgs = getenv("RN_WGRAD_WGS") ? atoi(getenv("RN_WGRAD_WGS")) : 3072;
+    int ns = (target_wgs + 2) / 3;
+    if (ns > (a.nitems + 15) / 16) ns = (a.nitems + 15) / 16;      // at least 16 stages per workgroup (every workgroup ends with 9216 atomics)
+    if (ns < 1) ns = 1;
+    a.ipw = (a.nitems + ns - 1) / ns;
+    a.nsplit = (a.nitems + a.ipw - 1) / a.ipw;
+    const long long nb = (long long)((a.nsplit + 7) / 8) * 24;
+    const size_t stage = (size_t)2 * (112 * 32 + 64 * 32) * 4, redb = (size_t)4 * 3 * 32 * 32 * 4;
+    const size_t lds = stage > redb ? stage : redb;
+    { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_k3d32_row_kernel), lds); if (rc_ != RN_OK) return rc_; }
+    hipLaunchKernelGGL(conv_wgrad_k3d32_row_kernel, dim3((unsigned)nb), dim3(256), lds, st, a);
+    return rn_check_launch("conv_wgrad_k3d32_row (bf16x3)");
+}
+
 static int launch_wgrad_k3d32(const float* A, const float* G, float* dw, int B, int H, int W, int D,
                               unsigned a_bytes, unsigned g_bytes, hipStream_t st, bool split = false)
 {
@@ -679,7 +881,11 @@ int rn_launch_conv3d_wgrad_split(const float* x, const float* dz, float* dw, int
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = B - b0 < chunk ? B - b0 : chunk;
         const size_t off = (size_t)b0 * (item / 4);
-        const int rc = launch_wgrad_k3d32(x + off, dz + off, dw, nb, H, W, D, (unsigned)(item * nb), (unsigned)(item * nb), st, true);
+        // W % 4 == 0 (every map of the path): the row form -- three taps of a filter row per workgroup; RN_WGRAD3D_ROW=0: the nine-pair form
+        static const bool row_off = getenv("RN_WGRAD3D_ROW") != nullptr && atoi(getenv("RN_WGRAD3D_ROW")) == 0;
+        const int rc = (W % 4 == 0 && !row_off)
+            ? launch_wgrad_k3d32_row(x + off, dz + off, dw, nb, H, W, D, (unsigned)(item * nb), (unsigned)(item * nb), st)
+            : launch_wgrad_k3d32(x + off, dz + off, dw, nb, H, W, D, (unsigned)(item * nb), (unsigned)(item * nb), st, true);
         if (rc != RN_OK) return rc;
     }
     return RN_OK;
