@@ -3,6 +3,7 @@
 // the input gradient of the channel-starved strided stem conv (e_conv2) that has no MFMA shape.
 #include "rn_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // Backward of  y = sigmoid?( prelu?(z) + residual ),  z = conv + bias   (tools/layer_util.py:27-45,
@@ -21,14 +22,17 @@ struct EpiBwdArgs {
 
 // fast path: C % 4 == 0 and (256 % (C/4) == 0 or (C/4) % 256 == 0): a thread owns one float4 channel
 // group for its whole life, so its partial sums stay in registers
-__global__ __launch_bounds__(256)
+// NT threads per workgroup (256 | 1024): the row-block count is capped (see the launcher), so on large tensors the bytes in flight come from
+// wider workgroups -- 1024 threads = four row lanes per channel group at C = 1024
+template <int NT>
+__global__ __launch_bounds__(NT)
 void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
 {
-    __shared__ float red[2][256 * 4];
+    __shared__ float red[2][NT * 4];
     const int G = a.C >> 2;                         // float4 groups per row
     const int gper = G < 256 ? G : 256;             // groups handled by one block column
     const int g = blockIdx.y * 256 + (threadIdx.x % gper);
-    const int rsub = threadIdx.x / gper, rstep = 256 / gper;
+    const int rsub = threadIdx.x / gper, rstep = NT / gper;
     const long long r0 = (long long)blockIdx.x * a.rows_per_block;
     const long long r1 = r0 + a.rows_per_block < a.M ? r0 + a.rows_per_block : a.M;
     float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -150,7 +154,12 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
     const int G = C / 4;
     if (C % 4 == 0 && ((G <= 256 && 256 % G == 0) || G % 256 == 0)) {
         const int gy = G <= 256 ? 1 : G / 256;
-        const int rstep = G < 256 ? 256 / G : 1;
+        // large tensors (>= 8 MiB per operand): 1024-thread workgroups -- with the row-block count capped at ~512 a 256-thread block keeps
+        // only 8 waves per CU in flight (1.8 TB/s on the res2 layers); RN_EPI_NT=256 | 1024 forces either (measurement)
+        static const int nt_env = getenv("RN_EPI_NT") ? atoi(getenv("RN_EPI_NT")) : 0;
+        const int NT = nt_env == 256 || nt_env == 1024 ? nt_env : ((long long)M * C >= (2ll << 20) ? 1024 : 256);
+        const int gper = G < 256 ? G : 256;
+        const int rstep = NT / gper;
         // ~512 row blocks: every block ends with 2*C same-address atomics, which the L2 serialises per
         // cache line (~40 ns each) -- thousands of blocks made THAT the critical path (0.31 ms for a
         // 300 MB stream); 2 blocks per CU with 4 rows in flight per thread still cover the HBM latency
@@ -159,7 +168,8 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
         if (rpb < 4 * rstep) rpb = 4 * rstep;
         a.rows_per_block = (int)rpb;
         const long long nb = ((long long)M + rpb - 1) / rpb;
-        hipLaunchKernelGGL(epilogue_bwd_vec_kernel, dim3((unsigned)nb, gy), dim3(256), 0, st, a);
+        if (NT == 1024) hipLaunchKernelGGL(epilogue_bwd_vec_kernel<1024>, dim3((unsigned)nb, gy), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL(epilogue_bwd_vec_kernel<256>, dim3((unsigned)nb, gy), dim3(256), 0, st, a);
     } else {
         if (C > 1024) return rn_set_error(RN_E_UNSUPPORTED, "rn_epilogue_bwd: C=%d", C);
         long long rpb = ((long long)M + 4095) / 4096;
