@@ -483,3 +483,37 @@ def test_split_filter_gradient_planner_is_a_host_function():
     assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F44, 1, 1, 1, 256, 256) == 49 * 32 * 512 * 6 + 49 * 256 * 256 * 4 + 256
     assert lib.rn_winograd_split_wgrad_workspace_bytes(L.RN_WINO_F43, 24, 32, 32, 128, 256) == 0           # unsupported widths
     assert lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F63, 1024, 1024) == 0                            # 4x4-output schemes only
+
+
+def test_default_multiply_stage_mode_and_bench_blocks():
+    """Round 5: the product default is the bf16x3 split multiply stage (rendernet_amd.ops.WINO_GEMM = "split"), RN_WINO_GEMM overrides it
+    and is validated at import; bench.py times the default as `value` and the two other modes as the named blocks `exact` / `alt` / `alt2`;
+    the header's 1x1 scheme constant and the Python mirror agree."""
+    import subprocess
+    import sys
+    import bench
+    from rendernet_amd import _lib
+    code = "import sys; sys.path.insert(0, %r); from rendernet_amd import ops; print(ops.WINO_GEMM)" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "RN_WINO_GEMM"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "split"
+    assert subprocess.run([sys.executable, "-c", code], env=dict(env, RN_WINO_GEMM="f32"), capture_output=True, text=True).stdout.strip() == "f32"
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, RN_WINO_GEMM="bf16"), capture_output=True, text=True)
+    assert bad.returncode != 0 and "RN_WINO_GEMM" in bad.stderr
+    assert bench.other_modes("split") == (("exact", "f32"), ("alt2", "split16"))
+    assert bench.other_modes("f32") == (("alt", "split"), ("alt2", "split16"))
+    assert bench.other_modes("split16") == (("exact", "f32"), ("alt", "split"))
+    assert set(bench.LINE_DTYPE) == set(bench.ALT_DTYPE) == set(bench.ALT_WHAT) == set(bench.TRAIN_DTYPE) == {"f32", "split", "split16"}
+    assert bench.LINE_DTYPE["split"].startswith("f32 (multiply stages: bf16x3-split operands") and bench.LINE_DTYPE["f32"] == "f32"
+    hdr = open(os.path.join(ROOT, "include", "rendernet_hip.h")).read()
+    assert re.search(r"#define\s+RN_WINO_F11\s+3\b", hdr) and _lib.RN_WINO_F11 == 3
+    # the training roofline of a mode is priced against that mode's peak
+    class _Ev:
+        def __init__(self, ms): self.ms = ms
+        def elapsed_time(self, other): return other.ms - self.ms
+    ev = [((_Ev(0.0), _Ev(0.5)), (1536, 1024, 1024, "f43"))]
+    r32, rs, rh = (bench.train_stage_roofline(ev, "gemm", m, 1024) for m in ("f32", "split", "split16"))
+    fl = 2.0 * 36 * 1536 * 1024 * 1024
+    assert r32["peak"] == 157.3 and abs(rs["peak"] - 2500 / 6) < 0.01 and abs(rh["peak"] - 2500 / 3) < 0.01
+    for r in (r32, rs, rh):
+        assert abs(r["achieved"] - fl / 0.5e-3 / 1e12) < 0.01 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "peak_name" in rs and "peak_name" not in r32
