@@ -354,6 +354,37 @@ def test_four_wave_gemm_variant_is_bit_identical(tmp_path):
         assert np.isfinite(got["1"][k]).all() and np.abs(got["1"][k]).max() > 0
 
 
+@pytest.mark.parametrize("cin,cout,transposed", [(64, 256, 0), (1024, 512, 0), (256, 256, 1)])
+def test_1x1_split_pack_and_row_format_are_the_fp32_values_in_three_pieces(cin, cout, transposed):
+    """RN_WINO_F11 layouts stated in NumPy: the pack Us [1][Cout/256][Cin/16][256][3][16] holds w[c][n] (transposed: w[n][c] of the TF
+    conv_transpose layout) and the input "transform" Vs [1][C/16][T][3][16] holds x itself, each element as three bf16 pieces whose sum is
+    EXACTLY the fp32 value (the identity scheme adds no arithmetic)."""
+    from rendernet_amd import ops
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(cin + cout)
+    w = _xavier(rng, (1, 1, cout, cin) if transposed else (1, 1, cin, cout))
+    pw = ops.pack_conv_transpose(_dev(w), 1) if transposed else ops.pack_conv(_dev(w))
+    us = pw.split("f11").cpu().numpy().view(np.uint16).reshape(1, cout // 256, cin // 16, 256, 48)
+    p = _bf16_to_f64(_rows_to_planes(us, (np.arange(256) >> 3) & 1))                      # [1, nb, s, 256, 3, 16]
+    got = (p[..., 0, :] + p[..., 1, :] + p[..., 2, :])[0]                                  # [nb, s, 256 (n), 16 (c)]
+    wm = (w[0, 0].T if transposed else w[0, 0]).astype(np.float64)                         # [cin, cout]
+    want = wm.reshape(cin // 16, 16, cout // 256, 256).transpose(2, 0, 3, 1)
+    assert np.array_equal(got, want)
+    assert lib.rn_winograd_split_packed_bytes(L.RN_WINO_F11, cin, cout) == us.size * 2
+    B, H, W = 2, 5, 7                                                                       # T = 70: below the 8-pixel group boundary at the end
+    x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
+    T = B * H * W
+    nb = lib.rn_winograd_split_v_bytes(L.RN_WINO_F11, T, cin)
+    assert nb >= T * cin * 6
+    Vs = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    L.check(lib.rn_winograd_split_input_transform(L.RN_WINO_F11, L.ptr(_dev(x)), ctypes.c_void_p(Vs.data_ptr()), B, H, W, cin, 0, L.stream_ptr()), "split input (1x1)")
+    rows = Vs.cpu().numpy()[:T * cin * 6].view(np.uint16).reshape(1, cin // 16, T, 48)
+    pv = _bf16_to_f64(_rows_to_planes(rows, (np.arange(T) >> 3) & 1))
+    gotx = (pv[..., 0, :] + pv[..., 1, :] + pv[..., 2, :])[0].transpose(1, 0, 2).reshape(T, cin)
+    assert np.array_equal(gotx, x.reshape(T, cin).astype(np.float64))
+
+
 CASES_1X1 = [   # (B, H, W, Cin, Cout): pixel counts below / across / above the 256-row block and the 8-pixel transform group, 2 .. 64 K steps
     (1, 3, 5, 32, 256), (1, 16, 16, 64, 256), (2, 17, 15, 1024, 512), (3, 64, 64, 256, 256), (1, 64, 64, 1024, 1024), (5, 9, 7, 96, 768),
 ]
