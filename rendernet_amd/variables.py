@@ -11,6 +11,7 @@ names load unchanged, and the initialisers are the reference ones:
 """
 import contextlib
 import math
+import threading
 
 import numpy as np
 import torch
@@ -49,7 +50,14 @@ class VariableStore:
         self.rng = np.random.default_rng(seed)
         self.vars = {}
         self._packed = {}
-        self._scope = []
+        self._tls = threading.local()         # the scope stack is per thread: two streams / threads may build the same net from one store
+
+    @property
+    def _scope(self):
+        sc = getattr(self._tls, "scope", None)
+        if sc is None:
+            sc = self._tls.scope = []
+        return sc
 
     # -- scopes -----------------------------------------------------------------------------
     @contextlib.contextmanager
