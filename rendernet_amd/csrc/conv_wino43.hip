@@ -109,7 +109,9 @@ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 3. output transform Y = A^T m A + the conv epilogue.  thread = (tile, VW channels).
-template <class S, int VW>
+// RES (compile time): the launch has a residual -- its values are fetched a whole output row ahead (12 more registers, which the
+// residual-free instance must not pay for: 84 registers = six waves per SIMD).
+template <class S, int VW, bool RES = false>
 __global__ __launch_bounds__(256)
 void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ alpha,
                         const float* __restrict__ res, float* __restrict__ y, float* __restrict__ z,
@@ -156,6 +158,16 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
     for (int p_ = 0; p_ < MO; ++p_) {
         const int oy = MO * ty + p_;
         if (oy >= H) continue;
+        // RES: the residual values of the whole output row are fetched BEFORE the row's arithmetic, as one batch of independent loads --
+        // issued one by one at their use they sat behind the bounds branch of every pixel (res2 layer, B = 24: 0.326 -> 0.294 ms)
+        vec rv[RES ? MO : 1];
+        if constexpr (RES) {
+#pragma unroll
+            for (int q = 0; q < MO; ++q) {
+                const int ox = MO * tx + q;
+                rv[q] = ox < W ? __builtin_nontemporal_load(reinterpret_cast<const vec*>(res + (((size_t)b * H + oy) * W + ox) * C + cv * VW)) : vec(0.f);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < MO; ++q) {
             const int ox = MO * tx + q;
@@ -176,7 +188,7 @@ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ b
 #pragma unroll
                 for (int e = 0; e < VW; ++e) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
             }
-            if (res) v += *reinterpret_cast<const vec*>(res + off);
+            if constexpr (RES) v += rv[q];
             if (act & RN_ACT_SIGMOID) {
 #pragma unroll
                 for (int e = 0; e < VW; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
@@ -736,18 +748,18 @@ int rn_launch_wino_output_amax(int scheme, const float* M, const float* bias, co
     const int vw = (scheme == RN_WINO_F43 || scheme == RN_WINO_F11) ? 4 : 2;
     const unsigned long long n = ((unsigned long long)T * (C / vw) + 255) / 256;
     const unsigned nblk8 = (unsigned)((n + 7) / 8 * 8);
-    if (scheme == RN_WINO_F11)          // one plane, identity transform: the conv epilogue over M (split path of a 1x1 filter, conv_wino_bf3.hip)
-        hipLaunchKernelGGL((wino_output_kernel<WinoF11, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8, amax);
-    else if (scheme == RN_WINO_F43)
-        hipLaunchKernelGGL((wino_output_kernel<WinoF43, 4>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8, amax);
-    else if (scheme == RN_WINO_F44)
-        hipLaunchKernelGGL((wino_output_kernel<WinoF44, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8, amax);
-    else
-        hipLaunchKernelGGL((wino_output_kernel<WinoF63, 2>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,
-                           H, W, C, th, tw, T, act, nblk8, amax);
+#define RN_OUT_LAUNCH(S_, VW_)                                                                                                              \
+    do {                                                                                                                                    \
+        if (residual) hipLaunchKernelGGL((wino_output_kernel<S_, VW_, true>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y,  \
+                                         preact, H, W, C, th, tw, T, act, nblk8, amax);                                                     \
+        else hipLaunchKernelGGL((wino_output_kernel<S_, VW_, false>), dim3(nblk8), dim3(256), 0, st, M, bias, alpha, residual, y, preact,  \
+                                H, W, C, th, tw, T, act, nblk8, amax);                                                                      \
+    } while (0)
+    if (scheme == RN_WINO_F11) RN_OUT_LAUNCH(WinoF11, 4);          // one plane, identity transform: the conv epilogue over M (split path of a 1x1 filter, conv_wino_bf3.hip)
+    else if (scheme == RN_WINO_F43) RN_OUT_LAUNCH(WinoF43, 4);
+    else if (scheme == RN_WINO_F44) RN_OUT_LAUNCH(WinoF44, 2);
+    else RN_OUT_LAUNCH(WinoF63, 2);
+#undef RN_OUT_LAUNCH
     return rn_check_launch("wino_output");
 }
 
