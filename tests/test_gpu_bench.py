@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(args, env=None):
-    e = dict(os.environ)
+    # (these tests state the mode they are about: an RN_WINO_GEMM inherited from the caller's environment -- the suite is also run with
+    #  RN_WINO_GEMM=f32 / split16 exported -- must not change what "the default line" means)
+    e = {k: v for k, v in os.environ.items() if k != "RN_WINO_GEMM"}
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
