@@ -34,6 +34,10 @@
 //   * no compiler hazard padding exists around inline-asm MFMAs: every MFMA carries an s_nop 1 in front (vector write ->
 //     MFMA operand read) and the accumulators are read by vector code only behind an explicit wait.
 //   * persistent grid, XCD-contiguous item order.
+//   * DEPTH SEGMENTS (round 5): with few images the rows of tiles do not fill the 256 workgroups (batch 6 at 64^3: 384 rows = one full
+//     round and a half-empty one); the launcher then cuts every row into 2 .. 8 depth segments, each an item of its own that walks one
+//     halo slice more per end (c3_depth_segments).  Same bits for any count (every output slice sums the same taps in the same order);
+//     res1 layer at batch 6: 0.196 -> 0.160 ms, batch 1: 0.097 -> 0.047 ms, batch >= 12 at 64^3: one segment, as before.
 #include "rn_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -62,7 +66,8 @@ struct C3Args {
     unsigned x_bytes;
     int B, H, W, D;
     int bh, bw;                 // blocks per image along H (2 output rows each) and W (32 output columns each)
-    int nitems;                 // B * bh * bw: an item is a row of 16 tiles through ALL depth slices
+    int nitems;                 // nseg * B * bh * bw: an item is a row of 16 tiles through the depth slices of one SEGMENT
+    int nseg, seglen;           // depth segments per row of tiles (1 = the whole depth run) and output slices per segment; see c3_depth_segments
     int act;
     int probe;                  // RN_C3_PROBE (timing experiments, wrong results): 1 no DMA in the loop, 2 no compute, 4 no epilogue, 8 no barriers
     const unsigned* amax_x; const unsigned* amax_u;   // format H2: bit patterns of max|x| of the input tensor and of the filter (device words)
@@ -287,8 +292,13 @@ void conv3d_wino_bf3_kernel(const C3Args a)
     f32x4 acc[3][2][2];                                               // [output slice % 3][jj][channel tile]
     const int perm = (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);       // XCD-contiguous slot in a round (G % 8 == 0)
     for (int id = perm; id < a.nitems; id += G) {
-        // ---- item: block column bx, block row by, image b
-        const int bx = id % a.bw, by = (id / a.bw) % a.bh, bi = id / (a.bw * a.bh);
+        // ---- item: block column bx, block row by, image bi, depth segment seg = output slices o0 .. o1 - 1.  It walks the INPUT slices
+        // ds = max(o0 - 1, 0) .. dl = min(o1, D - 1); the ring indices (stage, accumulator set) count from ds.  With o0 > 0 the first
+        // step also feeds the sets of output slices o0 - 2 and o0 - 1 -- never flushed, like the sets that slice o1 restarts.
+        const int bx = id % a.bw, by = (id / a.bw) % a.bh, bi = (id / (a.bw * a.bh)) % a.B, seg = id / (a.bw * a.bh * a.B);
+        const int o0 = seg * a.seglen, o1 = o0 + a.seglen < a.D ? o0 + a.seglen : a.D;
+        if (o0 >= o1) continue;                                                       // (D not a multiple of the segment count: uniform for the workgroup)
+        const int ds = o0 > 0 ? o0 - 1 : 0, dl = o1 < a.D ? o1 : a.D - 1;
         const int y0 = by * 2 - 1, x0 = bx * 32 - 1;                                  // patch origin (may be -1: SAME padding)
         // byte offset of depth slice 0 of the patch origin; wraps below zero for the first row / column: all sums are modulo
         // 2^32 and only used where the pixel is inside
@@ -323,26 +333,26 @@ void conv3d_wino_bf3_kernel(const C3Args a)
             else if (three) C3_WAIT_BARRIER(3);
             else C3_WAIT_BARRIER(2);
         };
-        issue(0, 0);
-        if (a.D > 1) issue(1, 1);
+        issue(ds, 0);
+        if (ds + 1 <= dl) issue(ds + 1, 1);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[0][jj][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // output slice 0 has no tap-0 step
-        wait_newest(a.D > 1);                                         // slice 0 has landed (slice 1 may still be in flight)
+            for (int nt = 0; nt < 2; ++nt) acc[0][jj][nt] = f32x4{0.f, 0.f, 0.f, 0.f};       // output slice 0 has no tap-0 step (o0 > 0: the set of slice o0 - 1, unused)
+        wait_newest(ds + 1 <= dl);                                    // slice ds has landed (slice ds + 1 may still be in flight)
 
         // step d (S = d % 3 at compile time): see the file comment.  `fl` = output slice d - 1 exists and is flushed.
         auto step = [&](auto sc, int d) {
-            constexpr int S = decltype(sc)::value;                    // stage of slice d; accumulator set of OUTPUT slice d
+            constexpr int S = decltype(sc)::value;                    // (d - ds) % 3: stage of slice d; accumulator set of OUTPUT slice d
             constexpr int SP = (S + 2) % 3, SN = (S + 1) % 3;         // ... of output slices d - 1 and d + 1
-            const bool fl = d >= 1 && !(PROBE & 4);
-            const bool arith = d < a.D && !(PROBE & 2);               // d == D: the pass that only flushes output slice D - 1
+            const bool fl = d > o0 && !(PROBE & 4);                   // output slice d - 1 belongs to this segment
+            const bool arith = d <= dl && !(PROBE & 2);               // d == D: the pass that only flushes output slice D - 1
             // the flush's own load (residual of slice d - 1) goes out FIRST, then the fetch of slice d + 2: the flush can then wait
             // for everything but that fetch
             f32x4 rv = {0.f, 0.f, 0.f, 0.f};
             if (fl && a.res) rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ooff, (d - 1) * (C3 * 4), 0));
             asm volatile("" ::: "memory");
-            const bool issued = d + 2 < a.D;
+            const bool issued = d + 2 <= dl;
             if (issued) issue(d + 2, SP);                             // stage (d + 2) % 3 = (d - 1) % 3: read during step d - 1, free since its barrier
             if (arith) {
                 const char* sb = smem + S * C3STAGE;
@@ -427,14 +437,14 @@ void conv3d_wino_bf3_kernel(const C3Args a)
                 if (AMAX && ooff != C3OOB) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             }
         };
-        // input slices 0 .. D-1, then one more pass (d = D) that only flushes output slice D - 1
-        for (int d = 0; d <= a.D; d += 3) {
+        // input slices ds .. o1 (the last one flushes output slice o1 - 1; with o1 = D it is the pass that only flushes)
+        for (int d = ds; d <= o1; d += 3) {
             step(std::integral_constant<int, 0>{}, d);
-            if (d + 1 <= a.D) step(std::integral_constant<int, 1>{}, d + 1);
-            if (d + 2 <= a.D) step(std::integral_constant<int, 2>{}, d + 2);
+            if (d + 1 <= o1) step(std::integral_constant<int, 1>{}, d + 1);
+            if (d + 2 <= o1) step(std::integral_constant<int, 2>{}, d + 2);
         }
         // the next item's first fetch overwrites stage 0, which the last arithmetic step may still be read from by a slower
-        // wave: every wave has passed the barrier of the flush-only pass, which comes after all arithmetic -- safe.
+        // wave: every wave has passed the barrier of the last step, which comes after that step's arithmetic -- safe.
     }
     if (AMAX) {                                                       // max |y| for a consumer in format H2: one atomic per wave
 #pragma unroll
@@ -481,6 +491,26 @@ int rn_launch_conv3d_wino_bf3(const float* x, const void* us, const float* bias,
     return rn_launch_conv3d_wino_split(0, x, us, bias, alpha, residual, y, preact, B, H, W, D, act, nullptr, nullptr, nullptr, st);
 }
 
+// Depth segments per row of tiles.  A row of 16 tiles walked through all D slices is one item; with few images the rows do not fill the
+// 256 persistent workgroups (batch 3 at 64^3: 192 rows = 192 busy CUs for the whole launch, batch 6: 384 = a full round and a half-empty
+// one).  A segment of L output slices costs L + 1 steps (one halo slice more than it flushes, both ends) + about 3 steps of item start-up
+// (addresses, the first fetch's latency); the count that minimises rounds x steps wins: 1 from batch 12 on, 2 at batch 6, 4 at batch 1..3.
+// RN_C3_DEPTH_SEGMENTS = n forces n (tests, timing).
+static int c3_depth_segments(long long rows, int D)
+{
+    static const int forced = getenv("RN_C3_DEPTH_SEGMENTS") ? atoi(getenv("RN_C3_DEPTH_SEGMENTS")) : 0;
+    if (forced >= 1) return forced < D ? forced : D;
+    int best = 1;
+    long long best_cost = 0;
+    for (int n = 1; n <= 8 && n <= D; n *= 2) {
+        const int len = (D + n - 1) / n;
+        const long long rounds = (rows * n + 255) / 256;
+        const long long cost = rounds * (len + (n > 1 ? 2 : 1) + 3);
+        if (n == 1 || cost < best_cost) { best = n; best_cost = cost; }
+    }
+    return best;
+}
+
 // fmt 1 (H2): amax_x = device word with the bit pattern of max|x| (or of a bound), or null -> a pass over x into `scratch_amax` (a device
 // word the caller provides; required when amax_x is null).  amax_y (either format, may be null): receives max|y|.
 int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const float* bias, const float* alpha, const float* residual,
@@ -525,8 +555,11 @@ int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const f
         a.x_bytes = (unsigned)(nb * per_image);
         a.B = nb; a.H = H; a.W = W; a.D = D;
         a.bh = (H + 1) / 2; a.bw = (W + 31) / 32;
-        const long long nitems = (long long)nb * a.bh * a.bw;
-        if (nitems > 0x7fffffff) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: too many blocks");
+        const long long rows = (long long)nb * a.bh * a.bw;
+        if (rows * 8 > 0x7fffffff) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: too many blocks");
+        a.nseg = c3_depth_segments(rows, D);
+        a.seglen = (D + a.nseg - 1) / a.nseg;
+        const long long nitems = rows * a.nseg;
         a.nitems = (int)nitems; a.act = act;
         a.probe = probe;
         a.amax_x = amax_x; a.amax_y = amax_y;

@@ -64,6 +64,23 @@ using rnf::FmtH2;
 
 namespace {
 
+// two values at once: one v_cvt_pk_bf16_f32 per piece pair gives the packed word that is stored, its two halves widened again (a shift, a
+// mask) feed one packed subtraction -- 9 instructions per pair where split3<2> compiles to 15 (a conversion per value AND the packed one)
+__device__ __forceinline__ void split3_pair(f32x2 x, unsigned (&w)[3])
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        w[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        if (q < 2) {
+            f32x2 h;
+            h[0] = __builtin_bit_cast(float, w[q] << 16);
+            h[1] = __builtin_bit_cast(float, w[q] & 0xffff0000u);
+            x -= h;
+        }
+    }
+}
+
 // the power-of-two scale of a tensor in format H2 from the largest magnitude of its UNtransformed values (0 -> 1)
 __host__ __device__ inline float h2_scale(float amax, float bound)
 {
@@ -102,11 +119,43 @@ __device__ __forceinline__ void split3(const float (&x)[VW], unsigned short (&p)
     }
 }
 
+// B^T applied to one 8-vector, F(6x6,3x3): rows 1..6 come in +/- pairs over the even and the odd inputs, rows 0 and 7 are a
+// difference pair each -- 26 operations where the dense row-by-row form (44 non-zeros) takes 44.  The input transform is
+// issue-bound (4.7 TB/s of a 7.0 TB/s pure-write stream), so the count matters; the sums are the same to rounding order.
+template <class S, class V>
+__device__ __forceinline__ void bt_apply(const V (&d)[S::TA], V (&o)[S::TA])
+{
+    if constexpr (S::TA == 8 && S::R == 3) {
+        o[0] = (d[6] - d[0]) + 5.25f * (d[2] - d[4]);
+        o[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+        const V e1 = (d[2] + d[6]) - 4.25f * d[4], f1 = (d[1] + d[5]) - 4.25f * d[3];
+        o[1] = e1 + f1;
+        o[2] = e1 - f1;
+        const V e2 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], f2 = (0.5f * d[1] - 2.5f * d[3]) + 2.f * d[5];
+        o[3] = e2 + f2;
+        o[4] = e2 - f2;
+        const V e3 = (d[6] + 4.f * d[2]) - 5.f * d[4], f3 = (2.f * d[1] - 2.5f * d[3]) + 0.5f * d[5];
+        o[5] = e3 + f3;
+        o[6] = e3 - f3;
+    } else {
+#pragma unroll
+        for (int i = 0; i < S::TA; ++i) {
+            V acc = V(0.f);
+#pragma unroll
+            for (int k = 0; k < S::TA; ++k) {
+                const float cf = S::BT(i, k);
+                if (cf != 0.f) acc += cf * d[k];
+            }
+            o[i] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 1. input transform V = B^T d B, written as three bf16 planes in the GEMM's row layout.  The arithmetic is that of
-// wino_input_kernel (conv_wino43.hip) per element -- V itself is bit-identical, only its representation changes.
+// 1. input transform V = B^T d B, written as three bf16 planes in the GEMM's row layout: the fp32 V of wino_input_kernel
+// (conv_wino43.hip) to rounding order (F(6x6,3x3) applies B^T in its factored form, bt_apply), only its representation changes.
 // thread = (tile, 2 channels); workgroup = 8 consecutive tiles x 64 channels (4 K-step groups), 32 lanes per tile: a load
 // instruction reads two 256-byte runs.  What the workgroup produces for one (xi, K-step group) is 8 rows x 96 bytes =
 // 768 CONTIGUOUS bytes of Vs, but a thread holds only 4 bytes per plane of it -- measured on the res2 shape (B = 24): three
@@ -123,7 +172,7 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
 {
     typedef float vec __attribute__((ext_vector_type(2)));
     constexpr int A = S::TA;
-    constexpr int NSEG = A * 4, BUF = NSEG * IB_SEG, NCHUNK = NSEG * (IB_TILES * SB_ROW / 16);   // 16-byte chunks per row batch
+    constexpr int NSEG = A * 4, BUF = NSEG * IB_SEG;
     __shared__ __attribute__((aligned(16))) char xch[2 * BUF];
     const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
     if (blk >= nwg) return;                                    // (whole workgroups only: no barrier is skipped)
@@ -139,27 +188,26 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
         const int tx = (int)(tc % tw), ty = (int)((tc / tw) % th);
         const long long b = tc / ((long long)tw * th);
         const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
-        const float* xb = x + ((size_t)b * H * W) * C + (live ? c : 0);
+        // one 64-bit multiply per thread: the A x A addresses are the tile's corner (possibly outside the plane -- then never
+        // dereferenced) plus offsets r W C + col C that are the same for every lane, i.e. scalar arithmetic
+        const float* p0 = x + (((long long)b * H + y0) * W + x0) * (long long)C + (live ? c : 0);
+        const long long rs = (long long)W * C;
+        const float* prow[A];                                  // (A row pointers: the column step col C is then one scalar-offset add per load)
+#pragma unroll
+        for (int r = 0; r < A; ++r) prow[r] = r == 0 ? p0 : prow[r - 1] + rs;
 #pragma unroll
         for (int col = 0; col < A; ++col) {
             vec d[A];
-            const int ix = x0 + col;
+            const bool cok = live && (unsigned)(x0 + col) < (unsigned)W;
 #pragma unroll
             for (int r = 0; r < A; ++r) {
-                const int iy = y0 + r;
-                const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
+                const bool ok = cok && (unsigned)(y0 + r) < (unsigned)H;
+                d[r] = ok ? *reinterpret_cast<const vec*>(prow[r] + col * C) : vec(0.f);
             }
+            vec o[A];
+            bt_apply<S>(d, o);
 #pragma unroll
-            for (int i = 0; i < A; ++i) {
-                vec acc = vec(0.f);
-#pragma unroll
-                for (int k = 0; k < A; ++k) {
-                    const float cf = S::BT(i, k);
-                    if (cf != 0.f) acc += cf * d[k];
-                }
-                tt[i][col] = acc;
-            }
+            for (int i = 0; i < A; ++i) tt[i][col] = o[i];
         }
     }
     // LDS position of this thread's word of plane 0 in segment (j = 0, its K-step group): row tl, chunk (l32 % 8) / 4 swapped
@@ -170,32 +218,42 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
     const size_t step_stride = (size_t)T * SB_ROW;
     char* vbase = Vs + ((size_t)cb * 4 * T + t0) * SB_ROW;     // segment (xi = 0, K-step group 4 cb) of this tile group
     const int tiles_here = (int)((T - t0) < IB_TILES ? (T - t0) : IB_TILES);
+    // the way out: the four K-step-group segments of one xi are 4 x 48 = 192 16-byte chunks = three store instructions of a whole wave;
+    // wave w takes xi columns j = w, w + 4.  What depends on the lane (segment, chunk, the ragged-edge predicate) is fixed for the kernel.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned loff[3];
+    size_t goff[3];
+    bool cok[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = (tid & 63) + 64 * k, sg = q / 48, r = q - sg * 48;
+        loff[k] = (unsigned)(sg * IB_SEG + r * 16);
+        goff[k] = sg * step_stride + (size_t)(r * 16);
+        cok[k] = r < tiles_here * 6 && (int)cb * 4 + sg < (C >> 4);
+    }
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         char* buf = xch + (i & 1) * BUF;
+        vec vrow[A];
+        bt_apply<S>(tt[i], vrow);
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            vec acc = vec(0.f);
-#pragma unroll
-            for (int k = 0; k < A; ++k) {
-                const float cf = S::BT(j, k);
-                if (cf != 0.f) acc += cf * tt[i][k];
-            }
-            const float a2[2] = {acc[0], acc[1]};
-            unsigned short p[3][2];
-            split3<2>(a2, p);
+            unsigned pw[3];
+            split3_pair(vrow[j], pw);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                *reinterpret_cast<unsigned*>(buf + j * (4 * IB_SEG) + wofs + q * 32) = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
+                *reinterpret_cast<unsigned*>(buf + j * (4 * IB_SEG) + wofs + q * 32) = pw[q];
         }
         __syncthreads();
-        for (int q = tid; q < NCHUNK; q += 256) {
-            const int seg = q / 48, r = q - seg * 48;          // segment (j, K-step group), 16-byte chunk of its 768 bytes
-            if (r >= tiles_here * 6) continue;
-            const int j = seg >> 2, sg = seg & 3;
-            if ((int)cb * 4 + sg >= (C >> 4)) continue;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + seg * IB_SEG + r * 16);
-            *reinterpret_cast<u32x4*>(vbase + (size_t)(i * A + j) * xi_stride + sg * step_stride + r * 16) = v;
+#pragma unroll
+        for (int jj = 0; jj < (A + 3) / 4; ++jj) {
+            const int j = wv + 4 * jj;                         // wave-uniform: the xi's address is scalar arithmetic
+            if (j >= A) break;
+            char* gb = vbase + (size_t)(i * A + j) * xi_stride;
+            const char* lb = buf + j * (4 * IB_SEG);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (cok[k]) *reinterpret_cast<u32x4*>(gb + goff[k]) = *reinterpret_cast<const u32x4*>(lb + loff[k]);
         }
     }
 }
@@ -354,7 +412,7 @@ void wino_input_h2_kernel(const float* __restrict__ x, char* __restrict__ Vs, co
 {
     typedef float vec __attribute__((ext_vector_type(2)));
     constexpr int A = S::TA;
-    constexpr int NSEG = A * 4, BUF = NSEG * IH_SEG, NCHUNK = NSEG * (IB_TILES * IH_ROW / 16);
+    constexpr int NSEG = A * 4, BUF = NSEG * IH_SEG;
     __shared__ __attribute__((aligned(16))) char xch[2 * BUF];
     const unsigned blk = xcd_contiguous(blockIdx.x, nblk8);
     if (blk >= nwg) return;
@@ -371,27 +429,24 @@ void wino_input_h2_kernel(const float* __restrict__ x, char* __restrict__ Vs, co
         const int tx = (int)(tc % tw), ty = (int)((tc / tw) % th);
         const long long b = tc / ((long long)tw * th);
         const int y0 = S::M * ty - pad_lo, x0 = S::M * tx - pad_lo;
-        const float* xb = x + ((size_t)b * H * W) * C + (live ? c : 0);
+        const float* p0 = x + (((long long)b * H + y0) * W + x0) * (long long)C + (live ? c : 0);   // (addresses as in wino_input_bf3_kernel)
+        const long long rs = (long long)W * C;
+        const float* prow[A];
+#pragma unroll
+        for (int r = 0; r < A; ++r) prow[r] = r == 0 ? p0 : prow[r - 1] + rs;
 #pragma unroll
         for (int col = 0; col < A; ++col) {
             vec d[A];
-            const int ix = x0 + col;
+            const bool cok = live && (unsigned)(x0 + col) < (unsigned)W;
 #pragma unroll
             for (int r = 0; r < A; ++r) {
-                const int iy = y0 + r;
-                const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                d[r] = ok ? *reinterpret_cast<const vec*>(xb + ((size_t)iy * W + ix) * C) : vec(0.f);
+                const bool ok = cok && (unsigned)(y0 + r) < (unsigned)H;
+                d[r] = ok ? *reinterpret_cast<const vec*>(prow[r] + col * C) : vec(0.f);
             }
+            vec o[A];
+            bt_apply<S>(d, o);
 #pragma unroll
-            for (int i = 0; i < A; ++i) {
-                vec acc = vec(0.f);
-#pragma unroll
-                for (int k = 0; k < A; ++k) {
-                    const float cf = S::BT(i, k);
-                    if (cf != 0.f) acc += cf * d[k];
-                }
-                tt[i][col] = acc;
-            }
+            for (int i = 0; i < A; ++i) tt[i][col] = o[i];
         }
     }
     // LDS position of this thread's word of plane q in segment (j = 0, its K-step group): row tl, logical chunk 2 q + (l32 % 8) / 4
@@ -403,30 +458,40 @@ void wino_input_h2_kernel(const float* __restrict__ x, char* __restrict__ Vs, co
     const size_t step_stride = (size_t)T * IH_ROW;
     char* vbase = Vs + ((size_t)cb * 4 * T + t0) * IH_ROW;
     const int tiles_here = (int)((T - t0) < IB_TILES ? (T - t0) : IB_TILES);
+    // the way out as in wino_input_bf3_kernel: the four segments of one xi are 4 x 32 chunks = two store instructions of a whole wave
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned loff[2];
+    size_t goff[2];
+    bool cok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = (tid & 63) + 64 * k, sg = q >> 5, r = q & 31;
+        loff[k] = (unsigned)(sg * IH_SEG + r * 16);
+        goff[k] = sg * step_stride + (size_t)(r * 16);
+        cok[k] = r < tiles_here * 4 && (int)cb * 4 + sg < (C >> 4);
+    }
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         char* buf = xch + (i & 1) * BUF;
+        vec vrow[A];
+        bt_apply<S>(tt[i], vrow);
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            vec acc = vec(0.f);
-#pragma unroll
-            for (int k = 0; k < A; ++k) {
-                const float cf = S::BT(j, k);
-                if (cf != 0.f) acc += cf * tt[i][k];
-            }
             unsigned lo;
-            const unsigned hi = h2_word(acc[0] * inv, acc[1] * inv, lo);
+            const unsigned hi = h2_word(vrow[j][0] * inv, vrow[j][1] * inv, lo);
             *reinterpret_cast<unsigned*>(buf + j * (4 * IH_SEG) + wbase + (((0u + hbit) ^ swz) << 4)) = hi;
             *reinterpret_cast<unsigned*>(buf + j * (4 * IH_SEG) + wbase + (((2u + hbit) ^ swz) << 4)) = lo;
         }
         __syncthreads();
-        for (int q = tid; q < NCHUNK; q += 256) {
-            const int seg = q / 32, r = q - seg * 32;          // segment (j, K-step group), 16-byte chunk of its 512 bytes
-            if (r >= tiles_here * 4) continue;
-            const int j = seg >> 2, sg = seg & 3;
-            if ((int)cb * 4 + sg >= (C >> 4)) continue;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + seg * IH_SEG + r * 16);
-            *reinterpret_cast<u32x4*>(vbase + (size_t)(i * A + j) * xi_stride + sg * step_stride + r * 16) = v;
+#pragma unroll
+        for (int jj = 0; jj < (A + 3) / 4; ++jj) {
+            const int j = wv + 4 * jj;
+            if (j >= A) break;
+            char* gb = vbase + (size_t)(i * A + j) * xi_stride;
+            const char* lb = buf + j * (4 * IH_SEG);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (cok[k]) *reinterpret_cast<u32x4*>(gb + goff[k]) = *reinterpret_cast<const u32x4*>(lb + loff[k]);
         }
     }
 }

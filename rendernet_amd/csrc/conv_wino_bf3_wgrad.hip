@@ -36,12 +36,18 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned blk, unsigned nblk8)
 // two fp32 values (the same channel of two neighbouring tiles) -> three words of two bf16 pieces each
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned (&w)[3])
 {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t v = {a, b};
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const __bf16 ha = (__bf16)a, hb = (__bf16)b;
-        a -= (float)ha;
-        b -= (float)hb;
-        w[q] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+    for (int q = 0; q < 3; ++q) {                          // one packed conversion per piece pair; its halves widened again feed a packed subtraction
+        w[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        if (q < 2) {
+            f32x2_t h;
+            h[0] = __builtin_bit_cast(float, w[q] << 16);
+            h[1] = __builtin_bit_cast(float, w[q] & 0xffff0000u);
+            v -= h;
+        }
     }
 }
 
@@ -54,7 +60,17 @@ __device__ __forceinline__ void emit_rows(char* xch, char* gbase, size_t xi_stri
     const int c = tid & 31, tp = tid >> 5;                                   // channel row of the workgroup, tile pair (tiles 2 tp, 2 tp + 1)
     const unsigned sw = (unsigned)((c >> 3) & 1);
     const unsigned wofs = (unsigned)(c * TB_PITCH) + ((((unsigned)tp >> 2) ^ sw) << 4) + (unsigned)(tp & 3) * 4;
-    constexpr int BUF = A * TB_SEG, NCHUNK = A * TB_CH * 6;
+    constexpr int BUF = A * TB_SEG;
+    // the way out: one xi = 32 rows x 6 chunks = 192 16-byte chunks = three store instructions of a whole wave; wave w takes the
+    // columns j = w, w + 4 (its xi address is scalar arithmetic), the lane's row / chunk are fixed for the kernel
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned loff[3], goff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int rr = (tid & 63) + 64 * k, row = rr / 6, ch = rr - row * 6;
+        loff[k] = (unsigned)(row * TB_PITCH + ch * 16);
+        goff[k] = (unsigned)(rr * 16);
+    }
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         char* buf = xch + (i & 1) * BUF;
@@ -66,11 +82,14 @@ __device__ __forceinline__ void emit_rows(char* xch, char* gbase, size_t xi_stri
             for (int q = 0; q < 3; ++q) *reinterpret_cast<unsigned*>(buf + j * TB_SEG + wofs + q * 32) = w[q];
         }
         __syncthreads();
-        for (int q = tid; q < NCHUNK; q += 256) {
-            const int j = q / (TB_CH * 6), rr = q - j * (TB_CH * 6);
-            const int row = rr / 6, ch = rr - row * 6;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(buf + j * TB_SEG + row * TB_PITCH + ch * 16);
-            *reinterpret_cast<u32x4*>(gbase + (size_t)(i * A + j) * xi_stride + rr * 16) = v;
+#pragma unroll
+        for (int jj = 0; jj < (A + 3) / 4; ++jj) {
+            const int j = wv + 4 * jj;
+            if (j >= A) break;
+            char* gb = gbase + (size_t)(i * A + j) * xi_stride;
+            const char* lb = buf + j * TB_SEG;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(gb + goff[k]) = *reinterpret_cast<const u32x4*>(lb + loff[k]);
         }
         // (two buffers: the next row's writes go to the other one; its read-out is separated from this row's by that row's barrier)
     }

@@ -537,8 +537,9 @@ WGRAD_SPLIT = os.environ.get("RN_WGRAD_SPLIT", "1") not in ("", "0")
 
 
 def _conv3d_split(B=None, H=None, W=None):
-    """An item of the split kernel is a row of 16 tiles through ALL depth slices (B * ceil(H/2) * ceil(W/32) items): below about
-    three quarters of a round of 256 workgroups the fp32 kernel's finer items win (B = 1: 6.07 against 6.86 ms per frame)."""
+    """An item of the split kernel is a row of 16 tiles through the depth slices (B * ceil(H/2) * ceil(W/32) rows, cut into depth
+    segments when they do not fill the 256 workgroups): below about three quarters of a round the fp32 kernel's finer items still
+    win (res1 layer, B = 1: 0.040 ms against 0.047 ms with four segments and 0.097 ms without; B = 2: no gain either way)."""
     if CONV3D_SPLIT is not None:
         return bool(CONV3D_SPLIT)
     return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)

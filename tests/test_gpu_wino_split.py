@@ -305,6 +305,54 @@ def test_conv3d_split(case, smode, monkeypatch):
     _close(dx, OL.conv3d_transpose(dz.cpu().numpy(), w, None, (1, 1, 1)), "split 3-D dgrad", rtol=2e-6)
 
 
+def test_conv3d_split_depth_segments_are_bit_identical(tmp_path):
+    """csrc/conv3d_wino_bf3.hip: c3_depth_segments -- with few images a row of tiles is cut into depth segments so that the 256 persistent
+    workgroups all have work (batch 1..3: 4 segments, batch 6: 2).  A segment re-walks one halo slice per end; every OUTPUT slice still
+    sums the same taps in the same order, so any segment count gives the bits of the whole depth run -- forward with residual and PReLU
+    and the pre-activation tap, depths that the count does not divide, a single slice.  RN_C3_DEPTH_SEGMENTS is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rendernet_amd import ops, _lib as L\n"
+        "ops.WINO_GEMM = sys.argv[2]\n"
+        "fmt = 1 if sys.argv[2] == 'split16' else 0\n"
+        "rng = np.random.default_rng(11)\n"
+        "outs = []\n"
+        "for (B, H, W, D) in ((1, 8, 40, 13), (2, 5, 33, 7), (1, 4, 4, 1), (3, 16, 16, 64), (1, 64, 64, 64)):\n"
+        "    x = torch.as_tensor(rng.standard_normal((B, H, W, D, 32)).astype(np.float32)).cuda()\n"
+        "    w = torch.as_tensor((0.06 * rng.standard_normal((3, 3, 3, 32, 32))).astype(np.float32)).cuda()\n"
+        "    b = torch.as_tensor((0.1 * rng.standard_normal(32)).astype(np.float32)).cuda()\n"
+        "    a = torch.as_tensor(rng.uniform(0, 0.25, 32).astype(np.float32)).cuda()\n"
+        "    r = torch.as_tensor(rng.standard_normal((B, H, W, D, 32)).astype(np.float32)).cuda()\n"
+        "    pw = ops.pack_conv(w)\n"
+        "    y, z = torch.empty_like(x), torch.empty_like(x)\n"
+        "    words = torch.zeros(2, dtype=torch.int32, device='cuda')\n"
+        "    L.check(L.lib().rn_conv3d_winograd_split_fwd_ex(fmt, L.ptr(x), ctypes.c_void_p(pw.split3d(fmt).data_ptr()), L.ptr(b), L.ptr(a), L.ptr(r), L.ptr(y), L.ptr(z),\n"
+        "            B, H, W, D, 32, 32, L.RN_ACT_PRELU, None, ctypes.c_void_p(words.data_ptr() + 4), ctypes.c_void_p(words.data_ptr()), L.stream_ptr()), 'fwd')\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert words[:1].view(torch.float32).item() == float(y.abs().max())\n"
+        "    outs += [y.cpu().numpy(), z.cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    for smode in ("split", "split16"):
+        got = {}
+        for nseg in ("1", "2", "3", "4", "8", ""):                      # "": the launcher's own choice
+            out = str(tmp_path / ("seg_%s_%s.npz" % (smode, nseg or "auto")))
+            env = dict(os.environ)
+            env.pop("RN_C3_DEPTH_SEGMENTS", None)
+            if nseg:
+                env["RN_C3_DEPTH_SEGMENTS"] = nseg
+            r = subprocess.run([sys.executable, "-c", code, out, smode], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got[nseg] = np.load(out)
+        for nseg in got:
+            for k in got["1"].files:
+                assert np.array_equal(got["1"][k], got[nseg][k]), (smode, nseg, k)
+        assert all(np.isfinite(got["1"][k]).all() and np.abs(got["1"][k]).max() > 0 for k in got["1"].files)
+
+
 class _TrainStub:
     """What ops._Conv needs of a training context (rendernet_amd/train.py: Trainer): an autograd anchor, gradient views, `ready`."""
     frozen = False
