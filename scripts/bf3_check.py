@@ -130,7 +130,7 @@ def main():
             accuracy(1, 64, 1024, 512, 4)
     if not args.no_timing:
         B = args.batch
-        shapes = ((64, 1024, 1024, 3, None), (64, 512, 512, 3, None), (64, 1024, 512, 4, None), (64, 512, 256, 4, None), (64, 1024, 1024, 3, "f43"))
+        shapes = ((64, 1024, 1024, 3, None), (64, 512, 512, 3, None), (64, 1024, 512, 4, None), (64, 512, 256, 4, None), (64, 1024, 1024, 3, "f43"), (64, 512, 512, 3, "f43"))
         if args.shapes:
             shapes = tuple(shapes[int(i)] for i in args.shapes.split(","))
         for (hw, cin, cout, k, forced) in shapes:
