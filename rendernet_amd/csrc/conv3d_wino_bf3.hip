@@ -34,10 +34,10 @@
 //   * no compiler hazard padding exists around inline-asm MFMAs: every MFMA carries an s_nop 1 in front (vector write ->
 //     MFMA operand read) and the accumulators are read by vector code only behind an explicit wait.
 //   * persistent grid, XCD-contiguous item order.
-//   * DEPTH SEGMENTS (round 5): with few images the rows of tiles do not fill the 256 workgroups (batch 6 at 64^3: 384 rows = one full
-//     round and a half-empty one); the launcher then cuts every row into 2 .. 8 depth segments, each an item of its own that walks one
-//     halo slice more per end (c3_depth_segments).  Same bits for any count (every output slice sums the same taps in the same order);
-//     res1 layer at batch 6: 0.196 -> 0.160 ms, batch 1: 0.097 -> 0.047 ms, batch >= 12 at 64^3: one segment, as before.
+//   * DEPTH SEGMENTS (round 5): with few images the rows of tiles do not fill the 256 workgroups (the res1 layers, 64 x 64 x 32 deep, at
+//     batch 6: 384 rows = one full round and a half-empty one); the launcher then cuts every row into 2 .. 8 depth segments, each an item
+//     of its own that walks one halo slice more per end (c3_depth_segments).  Same bits for any count (every output slice sums the same
+//     taps in the same order); res1 layer at batch 6: 0.196 -> 0.160 ms, batch 1: 0.097 -> 0.047 ms, batch >= 8: one segment, as before.
 #include "rn_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -492,10 +492,11 @@ int rn_launch_conv3d_wino_bf3(const float* x, const void* us, const float* bias,
 }
 
 // Depth segments per row of tiles.  A row of 16 tiles walked through all D slices is one item; with few images the rows do not fill the
-// 256 persistent workgroups (batch 3 at 64^3: 192 rows = 192 busy CUs for the whole launch, batch 6: 384 = a full round and a half-empty
-// one).  A segment of L output slices costs L + 1 steps (one halo slice more than it flushes, both ends) + about 3 steps of item start-up
-// (addresses, the first fetch's latency); the count that minimises rounds x steps wins: 1 from batch 12 on, 2 at batch 6, 4 at batch 1..3.
-// RN_C3_DEPTH_SEGMENTS = n forces n (tests, timing).
+// 256 persistent workgroups (res1 layers, 64 x 64 maps 32 deep: batch 3 = 192 rows = 192 busy CUs for the whole launch, batch 6 = 384 = a
+// full round and a half-empty one).  A segment of L output slices costs L + 2 steps (a halo slice per end; L + 1 for the whole run) + about
+// one step of item start-up -- fitted to the res1 layer at batch 1 .. 12 x 1 / 2 / 4 / 8 segments (profiles/r05o_depth_segments_layer.txt:
+// batch 3: 0.104 / 0.113 / 0.098 / 0.112 ms, batch 6: 0.196 / 0.162 / 0.174 / 0.203); the count that minimises rounds x steps wins:
+// 1 from batch 8 on, 2 at batch 6, 4 at batch 3.  RN_C3_DEPTH_SEGMENTS = n forces n (tests, timing).
 static int c3_depth_segments(long long rows, int D)
 {
     static const int forced = getenv("RN_C3_DEPTH_SEGMENTS") ? atoi(getenv("RN_C3_DEPTH_SEGMENTS")) : 0;
@@ -505,7 +506,7 @@ static int c3_depth_segments(long long rows, int D)
     for (int n = 1; n <= 8 && n <= D; n *= 2) {
         const int len = (D + n - 1) / n;
         const long long rounds = (rows * n + 255) / 256;
-        const long long cost = rounds * (len + (n > 1 ? 2 : 1) + 3);
+        const long long cost = rounds * (len + (n > 1 ? 2 : 1) + 1);
         if (n == 1 || cost < best_cost) { best = n; best_cost = cost; }
     }
     return best;
