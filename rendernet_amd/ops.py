@@ -537,12 +537,14 @@ WGRAD_SPLIT = os.environ.get("RN_WGRAD_SPLIT", "1") not in ("", "0")
 
 
 def _conv3d_split(B=None, H=None, W=None):
-    """An item of the split kernel is a row of 16 tiles through the depth slices (B * ceil(H/2) * ceil(W/32) rows, cut into depth
-    segments when they do not fill the 256 workgroups): below about three quarters of a round the fp32 kernel's finer items still
-    win (res1 layer, B = 1: 0.040 ms against 0.047 ms with four segments and 0.097 ms without; B = 2: no gain either way)."""
+    """An item of the split kernel is a row of 16 tiles through the depth slices (B * ceil(H/2) * ceil(W/32) rows), cut into depth
+    segments when the rows do not fill the 256 workgroups (csrc/conv3d_wino_bf3.hip: c3_depth_segments).  Before the segments the
+    fp32 kernel's finer items won below three quarters of a round (192 rows); with them the split kernel wins from one 64 x 64 image
+    on (res1 layer 0.048 against 0.057 ms at B = 1, 0.068 against 0.093 at B = 2; frame 5.91 -> 5.74 ms, two frames 8.73 -> 8.19 ms).
+    Below 64 rows (maps of a few tiles) the fp32 kernel stays."""
     if CONV3D_SPLIT is not None:
         return bool(CONV3D_SPLIT)
-    return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 192)
+    return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 64)
 
 
 def _gemm_mode(pw, gemm=None):
