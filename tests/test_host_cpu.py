@@ -517,3 +517,56 @@ def test_default_multiply_stage_mode_and_bench_blocks():
     for r in (r32, rs, rh):
         assert abs(r["achieved"] - fl / 0.5e-3 / 1e12) < 0.01 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "peak_name" in rs and "peak_name" not in r32
+
+
+def test_conv3d_split_rule_and_factored_input_transform(monkeypatch):
+    """Two host-side facts of round 5's late changes.  (1) ops._conv3d_split: the split 3-D kernel takes every launch of at least 64 rows of
+    tiles (one 64 x 64 image) in the split modes -- its depth segments keep 256 workgroups busy from there on -- never in exact mode, and
+    RN_CONV3D_SPLIT forces it either way.  (2) the factored form of F(6x6,3x3)'s B^T that the split input transforms apply
+    (csrc/conv_wino_bf3.hip: bt_apply -- rows 1..6 as +/- pairs over the even and the odd inputs, 26 operations instead of 44) is the matrix
+    of csrc/wino_mats.h (WinoF63::BT), exactly in float64, and its nesting A^T [(G g G^T) . (B^T d B)] A is the 3x3 correlation."""
+    from rendernet_amd import ops
+    monkeypatch.setattr(ops, "CONV3D_SPLIT", None)
+    for mode, want in (("split", True), ("split16", True), ("f32", False)):
+        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        assert ops._conv3d_split(1, 64, 64) is want and ops._conv3d_split(24, 64, 64) is want and ops._conv3d_split() is want
+        assert ops._conv3d_split(1, 32, 32) is False and ops._conv3d_split(3, 32, 32) is False          # 16 / 48 rows: the fp32 kernel's finer items
+        assert ops._conv3d_split(4, 32, 32) is want                                                        # 64 rows
+    monkeypatch.setattr(ops, "WINO_GEMM", "f32")
+    monkeypatch.setattr(ops, "CONV3D_SPLIT", True)
+    assert ops._conv3d_split(1, 8, 8) is True
+    monkeypatch.setattr(ops, "CONV3D_SPLIT", False)
+    monkeypatch.setattr(ops, "WINO_GEMM", "split")
+    assert ops._conv3d_split(24, 64, 64) is False
+
+    BT = np.array([[-1, 0, 21 / 4, 0, -21 / 4, 0, 1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0], [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0],
+                   [0, .5, .25, -2.5, -1.25, 2, 1, 0], [0, -.5, .25, 2.5, -1.25, -2, 1, 0], [0, 2, 4, -2.5, -5, .5, 1, 0],
+                   [0, -2, 4, 2.5, -5, -.5, 1, 0], [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1]])
+    src = open(os.path.join(ROOT, "rendernet_amd", "csrc", "wino_mats.h")).read()
+    assert "{0.f, 1.f / 2.f, 1.f / 4.f, -5.f / 2.f, -5.f / 4.f, 2.f, 1.f, 0.f}" in src                   # the table above is WinoF63::BT's
+
+    def bt_apply(d):
+        o = [None] * 8
+        o[0] = (d[6] - d[0]) + 5.25 * (d[2] - d[4])
+        o[7] = (d[7] - d[1]) + 5.25 * (d[3] - d[5])
+        e1, f1 = (d[2] + d[6]) - 4.25 * d[4], (d[1] + d[5]) - 4.25 * d[3]
+        o[1], o[2] = e1 + f1, e1 - f1
+        e2, f2 = (d[6] + 0.25 * d[2]) - 1.25 * d[4], (0.5 * d[1] - 2.5 * d[3]) + 2.0 * d[5]
+        o[3], o[4] = e2 + f2, e2 - f2
+        e3, f3 = (d[6] + 4.0 * d[2]) - 5.0 * d[4], (2.0 * d[1] - 2.5 * d[3]) + 0.5 * d[5]
+        o[5], o[6] = e3 + f3, e3 - f3
+        return np.stack(o)
+
+    assert np.array_equal(bt_apply(np.eye(8)), BT)                                                         # column by column: the same matrix
+    rng = np.random.default_rng(63)
+    d = rng.standard_normal((8, 8))
+    V = bt_apply(bt_apply(d).T).T                                                                          # B^T d B: columns, then rows
+    assert np.abs(V - BT @ d @ BT.T).max() < 1e-12
+    G = np.array([[-1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45], [1 / 90, -1 / 45, 2 / 45],
+                  [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1]])
+    AT = np.array([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, .5, -.5, 0], [0, 1, 1, 4, 4, .25, .25, 0], [0, 1, -1, 8, -8, .125, -.125, 0],
+                   [0, 1, 1, 16, 16, 1 / 16, 1 / 16, 0], [0, 1, -1, 32, -32, 1 / 32, -1 / 32, 1]])
+    g = rng.standard_normal((3, 3))
+    y = AT @ ((G @ g @ G.T) * V) @ AT.T
+    want = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(6)] for i in range(6)])
+    assert np.abs(y - want).max() < 1e-9 * max(1.0, np.abs(want).max())                              # float64: the transforms' growth (~1e3) x 1e-16
