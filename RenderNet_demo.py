@@ -109,10 +109,7 @@ def main(argv=None):
     else:
         print("no --weights given: using seeded random weights (the reference ships no trained model)")
         weights = init_shader_weights(spec, seed=1234)
-    renderer = Renderer(spec, weights)
-    from rendernet_amd import ops
-    if args.gemm is not None:
-        ops.WINO_GEMM = args.gemm
+    renderer = Renderer(spec, weights, gemm=args.gemm)      # None: the library default (env RN_WINO_GEMM, "split")
 
     if not os.path.exists(args.render_dir):
         os.makedirs(args.render_dir)

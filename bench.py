@@ -341,9 +341,7 @@ def train_main(args, world, rank, local_rank):
     spec = ShaderSpec().check()
     weights = init_shader_weights(spec, seed=1234, perturb=True)
     from rendernet_amd import ops
-    LIB_DEFAULT_MODE = ops.WINO_GEMM
-    ops.WINO_GEMM = args.gemm                      # the primary mode (default: the library default, "split")
-    tr = Trainer(spec, weights, device="cuda:%d" % local_rank)
+    tr = Trainer(spec, weights, device="cuda:%d" % local_rank, gemm=args.gemm)   # the primary mode (default: the library default, "split")
     B, p = args.batch, args.patch
     vox_np, poses_np = synthetic_batch(B)
     poses_np[:, 0] = (poses_np[:, 0] + rank * 0.1) % (2 * np.pi)
@@ -392,9 +390,8 @@ def train_main(args, world, rank, local_rank):
         del tr
         for akey, gm in other_modes(args.gemm):
             torch.cuda.empty_cache()
-            ops.WINO_GEMM = gm
             try:
-                tr2 = Trainer(spec, weights, device="cuda:%d" % local_rank)
+                tr2 = Trainer(spec, weights, device="cuda:%d" % local_rank, gemm=gm)
                 parity2 = train_parity(tr2, spec, world)
                 for i in range(max(1, args.warmup)):
                     tr2.step(vox, poses, targets, patch_size=p, start_point=starts[i])
@@ -416,7 +413,6 @@ def train_main(args, world, rank, local_rank):
                 el2 = max(gather_per_rank(time.perf_counter() - t0, world, rank))
                 loss2 = float(loss2.item())
             finally:
-                ops.WINO_GEMM = LIB_DEFAULT_MODE
                 ops.STAGE_HOOK = None
             del tr2
             alt = {"dtype": TRAIN_DTYPE[gm], "gemm_mode": gm,
@@ -592,7 +588,6 @@ def render_main(args, world, rank, local_rank):
     from rendernet_amd.parallel import shard_range
 
     mode = args.mode
-    LIB_DEFAULT_MODE = ops.WINO_GEMM
     wl = build_workload(mode, "cuda:%d" % local_rank)
     B = args.batch
     hw, wtrunk = wl["trunk"]
@@ -625,7 +620,6 @@ def render_main(args, world, rank, local_rank):
         """warmup untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; the dominant layer,
         its GEMM stage and the resampler bracketed by HIP events on the launch stream.  -> (out, max-over-ranks seconds,
         per-rank seconds, events)."""
-        ops.WINO_GEMM = gemm_mode
         ev = {"layer": [], "gemm": [], "resample": []}
 
         def stage_hook(stage, tkn):
@@ -646,7 +640,8 @@ def render_main(args, world, rank, local_rank):
                 return e
             return None
 
-        with torch.no_grad():
+        # the renderer names no mode of its own (gemm=None): it runs in the mode of this context -- no module state is written
+        with torch.no_grad(), ops.gemm_mode(gemm_mode):
             for _ in range(warmup):
                 out = wl["render"](vox, aux, poses)
             ops.LAUNCH_HOOK, ops.STAGE_HOOK = hook, stage_hook
@@ -657,7 +652,6 @@ def render_main(args, world, rank, local_rank):
             barrier()
             elapsed = time.perf_counter() - t0
             ops.LAUNCH_HOOK = ops.STAGE_HOOK = None
-        ops.WINO_GEMM = LIB_DEFAULT_MODE
         if isinstance(out, (tuple, list)):
             out = torch.cat(list(out), dim=3)          # after the timed region: the checks below index one [n,H,W,6] tensor
         assert out.shape == (vox.shape[0], wl["out_hw"], wl["out_hw"], wl["out_ch"])

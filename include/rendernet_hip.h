@@ -233,7 +233,8 @@ int rn_conv2d_wino44_fwd(const float* x, const float* w_wino44, const float* bia
 #define RN_WINO_F11 3   /* split entries only (rn_winograd_split_* / rn_conv2d_winograd_split_fwd*): a 1x1 filter as ONE plane with identity
                          * transforms, i.e. a plain T x Cin x Cout GEMM on the split multiply stage, T = B*H*W pixels -- the projection unit's
                          * 1x1 conv (tools/layer_util.py:8-22) and its input gradient; w_tf [1,1,Cin,Cout] (transposed: [1,1,Cout,Cin]);
-                         * Cin % 16 == 0, Cout % 256 == 0.  The exact-fp32 stage entries reject it. */
+                         * Cin % 32 == 0 (Cin >= 32), Cout % 256 == 0 -- the contract of every split scheme (rn_winograd_split_supported);
+                         * rn_winograd_split_v_bytes / _input_transform check the same Cin.  The exact-fp32 stage entries reject it. */
 int rn_winograd_input_transform(int scheme, const float* x, float* V, int B, int H, int W, int C, int pad_lo, void* stream);
 int rn_winograd_gemm(int scheme, const float* V, const float* w_packed, float* M, long long T, int Cin, int Cout, void* stream);
 int rn_winograd_output_transform(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,

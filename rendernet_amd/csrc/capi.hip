@@ -470,7 +470,8 @@ extern "C" size_t rn_winograd_split_packed_bytes(int scheme, int Cin, int Cout)
 }
 extern "C" size_t rn_winograd_split_v_bytes(int scheme, long long T, int Cin)
 {
-    return (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || T < 1 || Cin < 16) ? 0 : rn_wino_bf3_v_bytes(scheme, T, Cin);
+    // the channel contract of the GEMM stage these planes feed (rn_winograd_split_supported): Cin >= 32, Cin % 32 == 0
+    return (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || T < 1 || Cin < 32 || Cin % 32 != 0) ? 0 : rn_wino_bf3_v_bytes(scheme, T, Cin);
 }
 extern "C" size_t rn_winograd_split_workspace_bytes(int scheme, int B, int H, int W, int Cin, int Cout)
 {
@@ -485,8 +486,8 @@ extern "C" int rn_winograd_split_pack(int scheme, const float* w_tf, void* w_spl
 extern "C" int rn_winograd_split_input_transform(int scheme, const float* x, void* Vs, int B, int H, int W, int C, int pad_lo, void* stream)
 {
     if (!x || !Vs) return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform: null pointer");
-    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
-        return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform: bad arguments");
+    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 32 || C % 32 != 0 || pad_lo < 0 || pad_lo > 3)
+        return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform: bad arguments (C must be a multiple of 32: the GEMM stage's K contract)");
     return rn_launch_wino_input_bf3(scheme, x, Vs, B, H, W, C, pad_lo, (hipStream_t)stream);
 }
 extern "C" int rn_winograd_split_gemm(int scheme, const void* Vs, const void* w_split, float* M, long long T, int Cin, int Cout, void* stream)
@@ -521,8 +522,8 @@ extern "C" int rn_winograd_split_input_transform_ex(int scheme, const float* x, 
                                                     const void* amax_x, void* stream)
 {
     if (!x || !Vs) return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: null pointer");
-    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 16 || C % 16 != 0 || pad_lo < 0 || pad_lo > 3)
-        return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: bad arguments");
+    if (rn_split_scheme_nxi(scheme & 0xff) == 0 || (scheme >> 8) > 1 || B < 1 || H < 1 || W < 1 || C < 32 || C % 32 != 0 || pad_lo < 0 || pad_lo > 3)
+        return rn_set_error(RN_E_INVALID, "rn_winograd_split_input_transform_ex: bad arguments (C must be a multiple of 32: the GEMM stage's K contract)");
     return rn_launch_wino_input_bf3_ex(scheme, x, Vs, B, H, W, C, pad_lo, static_cast<const unsigned*>(amax_x), (hipStream_t)stream);
 }
 extern "C" int rn_winograd_output_transform_ex(int scheme, const float* M, const float* bias, const float* alpha, const float* residual,

@@ -557,10 +557,10 @@ int rn_launch_conv3d_wino_split(int fmt, const float* x, const void* us, const f
         a.B = nb; a.H = H; a.W = W; a.D = D;
         a.bh = (H + 1) / 2; a.bw = (W + 31) / 32;
         const long long rows = (long long)nb * a.bh * a.bw;
-        if (rows * 8 > 0x7fffffff) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: too many blocks");
-        a.nseg = c3_depth_segments(rows, D);
+        a.nseg = c3_depth_segments(rows, D);               // <= 8, or what RN_C3_DEPTH_SEGMENTS forces (<= D)
         a.seglen = (D + a.nseg - 1) / a.nseg;
         const long long nitems = rows * a.nseg;
+        if (nitems > 0x7fffffffLL) return rn_set_error(RN_E_UNSUPPORTED, "conv3d_wino_bf3: too many items (%lld rows x %d depth segments)", rows, a.nseg);
         a.nitems = (int)nitems; a.act = act;
         a.probe = probe;
         a.amax_x = amax_x; a.amax_y = amax_y;

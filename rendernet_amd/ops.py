@@ -10,6 +10,7 @@ parameter tensors to (one flat buffer, see rendernet_amd/train.py) and reports c
 gradient buckets can be all-reduced while the rest of the backward is still running.
 """
 import contextlib
+import threading
 import os
 import ctypes
 
@@ -416,17 +417,37 @@ class TrainContext:
         return g
 
     def grad_if_param(self, t):
-        """The gradient view of t, or None when t is not a registered parameter -- a CONSTANT that rides in a parameter slot (the all-zero
-        PReLU slope that makes the pretrained res blocks' ReLU, tools/layer_util.py:_relu_slope): no gradient is produced for it."""
+        """The gradient view of t, or None for a tensor MARKED as a constant that rides in a parameter slot (ops.mark_constant: the
+        all-zero PReLU slope that makes the pretrained res blocks' ReLU, tools/layer_util.py:_relu_slope) -- no gradient is produced
+        for it.  Any other tensor must be registered: a PReLU slope that was never registered is a bug that would otherwise show up
+        as a parameter that silently never trains."""
         if self.frozen or t is None:
             return None
-        return self.grad_of.get(t.data_ptr())
+        g = self.grad_of.get(t.data_ptr())
+        if g is None and not is_constant(t):
+            raise L.RenderNetHipError("no gradient buffer registered for a parameter of shape %s (a constant in a parameter slot "
+                                      "must be marked with ops.mark_constant)" % (tuple(t.shape),))
+        return g
 
     def ready(self, *ts):
         if self.on_ready is not None:
             for t in ts:
-                if t is not None and t.data_ptr() in self.grad_of:
-                    self.on_ready(t.data_ptr())
+                if t is None or is_constant(t):
+                    continue
+                if t.data_ptr() not in self.grad_of:
+                    raise L.RenderNetHipError("ready(): a tensor of shape %s is neither a registered parameter nor a marked constant"
+                                              % (tuple(t.shape),))
+                self.on_ready(t.data_ptr())
+
+
+def mark_constant(t):
+    """Marks a tensor that sits in a parameter slot of an operator (bias / alpha) as a constant: no gradient, no on_ready call."""
+    t._rn_constant = True
+    return t
+
+
+def is_constant(t):
+    return bool(getattr(t, "_rn_constant", False))
 
 
 TRAIN = None
@@ -502,7 +523,7 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None, amax_out=None):
         diff, ref = float((y63 - y43).abs().max()), float(y43.abs().max())
         pw._wino63_verdict = diff <= WINO63_CHECK_TOL * ref
         if not pw._wino63_verdict:
-            WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30), "mode": WINO_GEMM})
+            WINO63_DEMOTED.append({"cin": Cin, "cout": Cout, "map": (H, W), "rel_diff": diff / max(ref, 1e-30), "mode": gemm_mode_now()})
             pw.wino63 = None                                  # this filter takes F(4x4,3x3) on the exact-fp32 stage from now on ...
             pw._gemm_f32 = True
             if pw._dgrad is not None:
@@ -515,7 +536,7 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None, amax_out=None):
 
 # Multiply stage of the three-launch path: "f32" = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = the same products on
 # the 16x faster bf16 pipe with every fp32 operand as three bf16 pieces and six piece products, fp32 accumulation
-# (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM, or set ops.WINO_GEMM.
+# (csrc/conv_wino_bf3.hip; fp32-class error, not bit-identical to "f32").  env RN_WINO_GEMM = the process default; per call: ops.gemm_mode(...).
 # "split16": the same stage with every operand as TWO fp16 pieces of value / (power-of-two scale of its tensor) and three products --
 # half the matrix work of "split"; 22-bit operands, fp32 accumulation (the accumulation error, which all three modes share, dominates).
 # DEFAULT since round 5: "split" -- the bf16x3 form carries the full 24-bit significand of every fp32 operand (the three pieces sum
@@ -523,9 +544,36 @@ def _wino43_fwd(x, pw, e, B, H, W, Cin, Cout, act, y_t=None, amax_out=None):
 # statistics suite, and it is 1.3x faster end to end.  RN_WINO_GEMM=f32 restores the exact-fp32 MFMA stage everywhere (it is also what a
 # filter is demoted to when the F(6x6,3x3) self-check below rejects it); "split16" is the opt-in fast mode.
 GEMM_MODES = ("f32", "split", "split16")
-WINO_GEMM = os.environ.get("RN_WINO_GEMM", "split")
+WINO_GEMM = os.environ.get("RN_WINO_GEMM", "split")         # the PROCESS DEFAULT only: what a caller that names no mode gets
 if WINO_GEMM not in GEMM_MODES:
     raise ValueError("RN_WINO_GEMM=%r: expected one of %s" % (WINO_GEMM, ", ".join(GEMM_MODES)))
+# The mode of a call is the innermost `with ops.gemm_mode(m)` of the calling thread, else the process default above.  Renderer /
+# TextureRenderer / Trainer / Reconstructor carry it as an attribute (`gemm=`) and enter the context around everything they launch, so
+# two renderers of one process can run different modes; a conv's backward runs under the mode its forward captured (autograd calls it
+# from its own thread).  Nothing in this module WRITES WINO_GEMM.
+_MODE = threading.local()
+
+
+def gemm_mode_now():
+    """The multiply-stage mode of a launch made now by this thread."""
+    return getattr(_MODE, "mode", None) or WINO_GEMM
+
+
+@contextlib.contextmanager
+def gemm_mode(mode):
+    """`with ops.gemm_mode("f32" | "split" | "split16")`: every launch of this thread inside the block uses that multiply stage;
+    None = leave whatever is in force."""
+    if mode is None:
+        yield
+        return
+    if mode not in GEMM_MODES:
+        raise ValueError("gemm mode %r: expected one of %s" % (mode, ", ".join(GEMM_MODES)))
+    prev = getattr(_MODE, "mode", None)
+    _MODE.mode = mode
+    try:
+        yield
+    finally:
+        _MODE.mode = prev
 # The fused 3x3x3 32 -> 32 kernel of the 3-D encoder has a bf16x3 variant too (csrc/conv3d_wino_bf3.hip: 0.50 ms against 0.82 ms on
 # the B = 24 64x64x32 layer, error 2.4e-7 .. 3.8e-7 of max|y| against the fp32 kernel's 3.2e-7 .. 4.9e-7).  None: it follows
 # WINO_GEMM ("split" turns both on); True / False (env RN_CONV3D_SPLIT=1 / 0) force it independently.
@@ -537,14 +585,18 @@ WGRAD_SPLIT = os.environ.get("RN_WGRAD_SPLIT", "1") not in ("", "0")
 
 
 def _conv3d_split(B=None, H=None, W=None):
-    """An item of the split kernel is a row of 16 tiles through the depth slices (B * ceil(H/2) * ceil(W/32) rows), cut into depth
-    segments when the rows do not fill the 256 workgroups (csrc/conv3d_wino_bf3.hip: c3_depth_segments).  Before the segments the
-    fp32 kernel's finer items won below three quarters of a round (192 rows); with them the split kernel wins from one 64 x 64 image
-    on (res1 layer 0.048 against 0.057 ms at B = 1, 0.068 against 0.093 at B = 2; frame 5.91 -> 5.74 ms, two frames 8.73 -> 8.19 ms).
-    Below 64 rows (maps of a few tiles) the fp32 kernel stays."""
+    """An item of the split kernel is a row of 16 tiles through the depth slices (ceil(H/2) * ceil(W/32) rows per image), cut into depth
+    segments when the rows do not fill the 256 workgroups (csrc/conv3d_wino_bf3.hip: c3_depth_segments; res1 layer 0.048 against 0.057 ms
+    at B = 1, 0.068 against 0.093 at B = 2).  The gate is a PER-IMAGE quantity (round 6, advisor finding on round 5's B * rows >= 64):
+    a frame takes the same kernels, and gets the same bits, alone and inside a batch -- the split kernel's results do not depend on the
+    item count (any segment count sums the same taps in the same order).  Maps of fewer than 8 rows of tiles per image (16 x 16 at crop
+    32 is the smallest the nets produce: 8 rows) stay on the fp32 kernel.  B is accepted and ignored."""
     if CONV3D_SPLIT is not None:
         return bool(CONV3D_SPLIT)
-    return WINO_GEMM in ("split", "split16") and (B is None or B * ((H + 1) // 2) * ((W + 31) // 32) >= 64)
+    return gemm_mode_now() in ("split", "split16") and (H is None or ((H + 1) // 2) * ((W + 31) // 32) >= CONV3D_SPLIT_MIN_ROWS)
+
+
+CONV3D_SPLIT_MIN_ROWS = int(os.environ.get("RN_CONV3D_SPLIT_MIN_ROWS", "8"))
 
 
 def _gemm_mode(pw, gemm=None):
@@ -552,7 +604,7 @@ def _gemm_mode(pw, gemm=None):
     else the module-wide mode."""
     if gemm is not None:
         return gemm
-    return "f32" if getattr(pw, "_gemm_f32", False) else WINO_GEMM
+    return "f32" if getattr(pw, "_gemm_f32", False) else gemm_mode_now()
 
 
 def _wino43_run(x, pw, e, B, H, W, Cin, Cout, act, which, gemm=None, amax_out=None):
@@ -624,12 +676,13 @@ def _use_wino43(pw, H, W):
 
 
 def _use_split11(pw, pixels):
-    """A 1x1 filter takes the split GEMM stage (three launches: split, GEMM, epilogue) in the split modes when the launch has at least a
-    256-row block of pixels per CU pair; below that the one-launch implicit-GEMM kernel wins."""
+    """A 1x1 filter takes the split GEMM stage (three launches: split, GEMM, epilogue) in the split modes when ONE IMAGE has at least
+    `SPLIT11_MIN_PIXELS` pixels (pixels = H * W: a per-image gate, so that a frame is routed alike alone and in a batch); below that the
+    one-launch implicit-GEMM kernel wins.  32 x 32 (the projection unit at crop 64) is the smallest map measured faster on the stage."""
     return pw._split11 and _gemm_mode(pw) in ("split", "split16") and pixels >= SPLIT11_MIN_PIXELS
 
 
-SPLIT11_MIN_PIXELS = int(os.environ.get("RN_SPLIT11_MIN_PIXELS", "8192"))
+SPLIT11_MIN_PIXELS = int(os.environ.get("RN_SPLIT11_MIN_PIXELS", "1024"))
 
 
 WINO43_MIN_PIXELS = int(os.environ.get("RN_WINO43_MIN_PIXELS", "64"))
@@ -661,7 +714,7 @@ def _tag_amax(y, word):
 
 
 def _conv3d_split_fmt():
-    return 1 if WINO_GEMM == "split16" else 0
+    return 1 if gemm_mode_now() == "split16" else 0
 
 
 def _conv3d_split_launch(x, pw, e, B, H, W, D, Cin, Cout, act, st, amax_out=None):
@@ -698,7 +751,7 @@ def _launch_conv(mode, x, pw, bias, alpha, residual, y, z, ksize, stride, act, a
         B, H, W, Cin = x.shape
         if unit and _use_wino43(pw, H, W):
             return _wino43_fwd(x, pw, e, B, H, W, Cin, pw.cout, act, y, amax_out)
-        if unit and _use_split11(pw, B * H * W):
+        if unit and _use_split11(pw, H * W):
             return _wino43_run(x, pw, e, B, H, W, Cin, pw.cout, act, "f11", amax_out=amax_out)
         if unit and pw.wino is not None:
             return lib.rn_conv2d_wino_fwd(L.ptr(x), L.ptr(pw.wino), *e, B, H, W, Cin, pw.cout, act, st)
@@ -754,10 +807,16 @@ class _Conv(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, z, y if (sigmoid or elu) else None)
             ctx.cfg = (pw, bias, alpha, residual is not None, tuple(ksize), tuple(stride), act, mode, TRAIN)
+            ctx.gemm = gemm_mode_now()                # the backward runs on autograd's thread: it takes the forward's mode along
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        with gemm_mode(ctx.gemm):
+            return _Conv._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, z, y = ctx.saved_tensors
         pw, bias, alpha, has_res, ksize, stride, act, mode, tc = ctx.cfg
         lib, st = L.lib(), L.stream_ptr()
@@ -785,13 +844,14 @@ class _Conv(torch.autograd.Function):
             B, H, W, Cin = x.shape
         if dw is None:
             rc = 0
-        elif (mode == "conv3d" and unit and tuple(ksize) == (3, 3, 3) and WINO_GEMM in ("split", "split16") and WGRAD_SPLIT
-              and lib.rn_conv3d_wgrad_split_supported(Cin, pw.cout)):
+        elif (mode == "conv3d" and unit and tuple(ksize) == (3, 3, 3) and _gemm_mode(pw) in ("split", "split16") and WGRAD_SPLIT
+              and lib.rn_conv3d_wgrad_split_supported(Cin, pw.cout)
+              and H * W * D * Cin * 4 < 0x80000000):      # one image inside the 2 GiB buffer window (else the exact kernel's launcher reports the limit)
             # the 3-D encoder's 32 -> 32 filter gradients: the reduction over the positions on the bf16 pipe (bf16x3 in both split modes)
             rc = lib.rn_conv3d_wgrad_split(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, st)
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
-        elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and WINO_GEMM in ("split", "split16") and WGRAD_SPLIT
+        elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and _gemm_mode(pw) in ("split", "split16") and WGRAD_SPLIT
               and max(Cin, pw.cout) >= 1024              # measured at crop 64: 1024 -> 1024 1.10 -> 0.79 ms, 1024 -> 512 (4x4) 0.92 -> 0.65; 512 -> 512: no gain
               and lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44, Cin, pw.cout)):
             # the reduction over the tiles on the bf16 pipe (csrc/conv_wino_bf3_wgrad.hip)
@@ -840,7 +900,7 @@ class _Conv(torch.autograd.Function):
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode in ("conv2d", "conv2d_transpose") and unit and _use_wino43(dp, H, W):
                 rc = _wino43_fwd(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
-            elif mode == "conv2d" and unit and _use_split11(dp, B * H * W):
+            elif mode == "conv2d" and unit and _use_split11(dp, H * W):
                 # 1x1: the input gradient is the GEMM with the transposed filter (the same TF tensor packed the other way round)
                 rc = _wino43_run(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0, "f11")
             elif mode == "conv2d" and unit and dp.wino is not None:
@@ -942,7 +1002,7 @@ def res_stack_2d(x, blocks, skip=None):
     B, H, W, C = x.shape
     lib = L.lib()
     fused = (RES_STACK_FUSED and len(blocks) > 0 and not (TRAIN is not None and torch.is_grad_enabled()) and not torch.is_grad_enabled()
-             and WINO63_CHECK_TOL is None and WINO_GEMM == "f32"            # the chain runs the exact-fp32 GEMM stage
+             and WINO63_CHECK_TOL is None and gemm_mode_now() == "f32"            # the chain runs the exact-fp32 GEMM stage
              and all(p.kind == L.RN_PACK_CONV and p.kdims == [3, 3] and p.cin == C and p.cout == C and _use_wino43(p, H, W) for p in pws))
     which = None
     if fused:
@@ -1023,7 +1083,7 @@ def projection(x, pw, bias, alpha):
     if x.shape[3] * x.shape[4] != pw.cin or pw.cin != pw.cout:
         raise L.RenderNetHipError("projection: D*C=%d but filter is %dx%d" % (x.shape[3] * x.shape[4], pw.cin, pw.cout))
     B, H, W, D, C = x.shape
-    if (TRAIN is not None and torch.is_grad_enabled()) or _use_split11(pw, B * H * W):
+    if (TRAIN is not None and torch.is_grad_enabled()) or _use_split11(pw, H * W):
         # training: the same GEMM through the differentiable 1x1 conv2d path (the reshape is a view); split modes: that path takes the 1x1
         # filter through the split GEMM stage (exact fp32: the one-launch kernel below)
         return _conv_apply(x.view(B, H, W, D * C), pw, bias, alpha, None, (1, 1), (1, 1), False, "conv2d")

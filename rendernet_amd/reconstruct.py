@@ -436,9 +436,13 @@ class Reconstructor:
 
     def __init__(self, tex_spec=None, dec_spec=None, weight_dict_rendernet=None, weight_dict_decoder=None, batch_size=5,
                  device="cuda", seed=1234, light_elevation_deg=105.0, light_col=(1.0, 1.0, 1.0), ambient=0.0, k_diffuse=1.0,
-                 shape_eta=0.8, pose_eta=0.01, tex_eta=0.8, light_eta=0.4):
-        """weight_dict_rendernet / weight_dict_decoder: what `load_weights(weight_dir)` / `load_weights(weight_dir_decoder)`
+                 shape_eta=0.8, pose_eta=0.01, tex_eta=0.8, light_eta=0.4, gemm=None):
+        """gemm: this graph's multiply-stage mode (rendernet_amd.ops.gemm_mode); None = the process default.
+        weight_dict_rendernet / weight_dict_decoder: what `load_weights(weight_dir)` / `load_weights(weight_dir_decoder)`
         return (:337-339; the texture decoder reads the RenderNet folder, :339); None: seeded random stand-ins."""
+        if gemm is not None and gemm not in ops.GEMM_MODES:
+            raise ValueError("gemm=%r: expected one of %s" % (gemm, ", ".join(ops.GEMM_MODES)))
+        self.gemm = gemm
         self.tex_spec = (tex_spec or TextureSpec()).check()
         self.dec_spec = dec_spec or ShapeDecoderSpec()
         if self.dec_spec.size != self.tex_spec.size:
@@ -484,7 +488,7 @@ class Reconstructor:
         old = V._default
         V.set_default_store(self.store)
         try:
-            with ops.training(self.ctx):
+            with ops.gemm_mode(self.gemm), ops.training(self.ctx):
                 shape = decoder_3d_pretrained(lat["vector"], self.weight_dict_decoder, taps=taps)                  # :356
                 tex = texture_decoder_pretrained(lat["texture"], self.weight_dict_texture, taps=taps)              # :357
                 # :360-361 + :363-364 + :366 -- both resamplers and the concat in one pass

@@ -243,7 +243,13 @@ class Renderer:
     RenderNet_Shader.py:135-156).  Holds the weights on one GPU and executes
     resample -> (crop) -> RenderNet for a batch."""
 
-    def __init__(self, spec=None, weights=None, device="cuda", seed=1234):
+    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, gemm=None):
+        """gemm: the multiply-stage mode of THIS renderer ("f32" exact fp32 | "split" bf16x3 | "split16" fp16x2; rendernet_amd.ops);
+        None = the process default (env RN_WINO_GEMM, "split").  Two renderers of one process may differ."""
+        from . import ops
+        if gemm is not None and gemm not in ops.GEMM_MODES:
+            raise ValueError("gemm=%r: expected one of %s" % (gemm, ", ".join(ops.GEMM_MODES)))
+        self.gemm = gemm
         self.spec = (spec or ShaderSpec()).check()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -267,10 +273,11 @@ class Renderer:
             if start_point is None:
                 start_point = torch.randint(0, s.new_size - patch_size + 1, (2,)).tolist()
             window = (int(start_point[0]), int(start_point[1]), int(patch_size), int(patch_size))
+        from . import ops
         old = V._default
         V.set_default_store(self.store)
         try:
-            with torch.no_grad():        # the Renderer is the inference runner (the trainers own the differentiable graph)
+            with torch.no_grad(), ops.gemm_mode(self.gemm):   # the Renderer is the inference runner (the trainers own the differentiable graph)
                 net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
                 if taps is not None:
                     taps["net_in"] = net_in

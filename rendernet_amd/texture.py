@@ -249,7 +249,12 @@ def RenderNetTexture(models_in, prob=0.75, reuse=False, spec=None, taps=None, is
 class TextureRenderer:
     """Graph of RenderNet_Texture_Face_Normal.py:152-179 on one GPU."""
 
-    def __init__(self, spec=None, weights=None, device="cuda", seed=1234):
+    def __init__(self, spec=None, weights=None, device="cuda", seed=1234, gemm=None):
+        """gemm: this renderer's multiply-stage mode (see shader.Renderer); None = the process default."""
+        from . import ops
+        if gemm is not None and gemm not in ops.GEMM_MODES:
+            raise ValueError("gemm=%r: expected one of %s" % (gemm, ", ".join(ops.GEMM_MODES)))
+        self.gemm = gemm
         self.spec = (spec or TextureSpec()).check()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -264,14 +269,16 @@ class TextureRenderer:
         tex = torch.as_tensor(textures, dtype=torch.float32).to(self.device)
         pose = torch.as_tensor(np.asarray(poses, np.float32) if not isinstance(poses, torch.Tensor) else poses,
                                dtype=torch.float32).to(self.device)
+        from . import ops
         old = V._default
         V.set_default_store(self.store)
         try:
-            tex_vol = decoder_texture(tex, s, taps)                                                     # :169
-            # :165-166 + :171-172 + :178 -- both resamplers and the concat in one pass
-            net_in = rotation_resampling_concat_to_image(vox, tex_vol, pose, size=s.size, new_size=s.new_size)
-            if taps is not None:
-                taps["net_in"] = net_in
-            return RenderNetTexture(net_in, spec=s, taps=taps)
+            with ops.gemm_mode(self.gemm):
+                tex_vol = decoder_texture(tex, s, taps)                                                 # :169
+                # :165-166 + :171-172 + :178 -- both resamplers and the concat in one pass
+                net_in = rotation_resampling_concat_to_image(vox, tex_vol, pose, size=s.size, new_size=s.new_size)
+                if taps is not None:
+                    taps["net_in"] = net_in
+                return RenderNetTexture(net_in, spec=s, taps=taps)
         finally:
             V._default = old

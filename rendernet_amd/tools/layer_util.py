@@ -132,7 +132,7 @@ def _relu_slope(channels, device):
     key = (str(device), int(channels))
     t = _RELU_SLOPE.get(key)
     if t is None:
-        t = _RELU_SLOPE[key] = torch.zeros(int(channels), dtype=torch.float32, device=device)
+        t = _RELU_SLOPE[key] = ops.mark_constant(torch.zeros(int(channels), dtype=torch.float32, device=device))
     return t
 
 

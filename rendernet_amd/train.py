@@ -109,7 +109,10 @@ class _TrainerBase:
     optimiser step.  With torch.distributed initialised every rank holds a full replica and a shard of the batch."""
 
     def __init__(self, spec, weights, device="cuda", seed=1234, e_eta=1e-5, decay_steps=100000,
-                 beta1=0.5, beta2=0.999, epsilon=1e-8, keep_prob=1.0, bucket_mb=100.0, group=None):
+                 beta1=0.5, beta2=0.999, epsilon=1e-8, keep_prob=1.0, bucket_mb=100.0, group=None, gemm=None):
+        if gemm is not None and gemm not in ops.GEMM_MODES:
+            raise ValueError("gemm=%r: expected one of %s" % (gemm, ", ".join(ops.GEMM_MODES)))
+        self.gemm = gemm                  # this trainer's multiply-stage mode (ops.gemm_mode); None = the process default
         self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -292,7 +295,7 @@ class Trainer(_TrainerBase):
         V.set_default_store(self.store)
         self._seed_dropout()
         try:
-            with ops.training(self.ctx):
+            with ops.gemm_mode(self.gemm), ops.training(self.ctx):
                 if net_in is None:
                     net_in = rotation_resampling_to_image(vox, pose, size=s.size, new_size=s.new_size, window=window)
                 if taps is not None:
@@ -346,7 +349,7 @@ class TextureTrainer(_TrainerBase):
         V.set_default_store(self.store)
         self._seed_dropout()
         try:
-            with ops.training(self.ctx):
+            with ops.gemm_mode(self.gemm), ops.training(self.ctx):
                 tex_vol = decoder_texture(tex, s, taps)
                 net_in = rotation_resampling_concat_to_image(vox, tex_vol, pose, size=s.size, new_size=s.new_size, window=window)
                 if taps is not None:

@@ -57,13 +57,8 @@ def conv_with_scheme(x, w, b, scheme, alpha=None, residual=None):
         pw.force_scheme = "f63"
     else:
         raise ValueError(scheme)
-    old = ops.WINO_GEMM
-    ops.WINO_GEMM = split or "f32"
-    try:
-        with torch.no_grad():
-            return ops.conv2d(x, pw, b, alpha, residual)
-    finally:
-        ops.WINO_GEMM = old
+    with torch.no_grad(), ops.gemm_mode(split or "f32"):
+        return ops.conv2d(x, pw, b, alpha, residual)
 
 
 def res_stack_weights(rng, C, n_blocks=10):

@@ -51,10 +51,10 @@ GEMM_MODES = ("split", "f32", "split16")        # rendernet_amd.ops.GEMM_MODES, 
 
 @pytest.fixture(params=GEMM_MODES)
 def gemm_mode(request, monkeypatch):
-    """Runs the test once per multiply-stage mode of the wide convs (rendernet_amd.ops.WINO_GEMM): "split" = the product default
+    """Runs the test once per multiply-stage mode of the wide convs (rendernet_amd.ops.gemm_mode): "split" = the product default
     (bf16x3 operands, fp32 accumulate), "f32" = exact-fp32 MFMA everywhere (the fallback, RN_WINO_GEMM=f32), "split16" = the opt-in
     fp16x2 fast mode.  Whole modules opt in with `pytest.mark.usefixtures("gemm_mode")`: every net-level -m gpu test (configs 2, 3, 5,
     inverse rendering, the CLIs) is green in all three, at the same bars."""
     from rendernet_amd import ops
-    monkeypatch.setattr(ops, "WINO_GEMM", request.param)
+    monkeypatch.setattr(ops._MODE, "mode", request.param, raising=False)      # = `with ops.gemm_mode(...)` around the test
     return request.param

@@ -391,7 +391,7 @@ def test_conv2d_winograd63(case, monkeypatch):
     same test in tests/test_gpu_wino_split.py.)"""
     from rendernet_amd import ops
     from rendernet_amd import _lib as L
-    monkeypatch.setattr(ops, "WINO_GEMM", "f32")
+    monkeypatch.setattr(ops._MODE, "mode", "f32", raising=False)
     B, H, W, Cin, Cout = case
     rng = np.random.default_rng(hash(case) % 2**31)
     x = _rand(rng, B, H, W, Cin)
@@ -799,7 +799,7 @@ def test_res_stack_chain_is_bit_equal_to_the_layers(case, monkeypatch):
         blocks.append((ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1), _dev(rng.uniform(0, 0.25, C).astype(np.float32)),
                        ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1)))
     skip = (ops.pack_conv(_dev(_xavier(rng, (3, 3, C, C)))), _dev(_rand(rng, C) * 0.1), x) if with_skip else None
-    monkeypatch.setattr(ops, "WINO_GEMM", "f32")           # the chain exists for the exact-fp32 stage only (opt-in, measured slower)
+    monkeypatch.setattr(ops._MODE, "mode", "f32", raising=False)           # the chain exists for the exact-fp32 stage only (opt-in, measured slower)
     with torch.no_grad():
         monkeypatch.setattr(ops, "RES_STACK_FUSED", False)
         want = ops.res_stack_2d(x, blocks, skip)

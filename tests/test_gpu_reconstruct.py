@@ -336,7 +336,7 @@ def test_full_size_inverse_rendering_gradients_agree_across_multiply_stage_modes
     target = torch.from_numpy(rng.uniform(0, 1, (5, 512, 512, 3)).astype(np.float32)).cuda()
 
     def run(mode, gain=None):
-        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        monkeypatch.setattr(ops._MODE, "mode", mode, raising=False)
         if gain is not None:
             monkeypatch.setattr(ops, "WINO63_MIN_GAIN", gain)
         rec = RC.Reconstructor(batch_size=5)

@@ -111,6 +111,22 @@ def test_argument_errors():
         ops.resample(vox.cpu(), pose.cpu(), new_size=16)  # no CPU path
 
 
+def test_five_column_poses_render_like_their_first_three_columns(fixtures_vox):
+    """tf_rotation_translation_resampling (tools/resampling_voxel_grid.py:634-650) documents [B,5] poses (azimuth, elevation, scale,
+    shiftX, shiftY) and reads columns 0..2 only: the mirror accepts any [B,>=3] and ignores the rest, like the reference; two
+    columns fail in the reference at graph construction (column 2 is indexed unconditionally) and raise here."""
+    from rendernet_amd.tools.resampling_voxel_grid import tf_rotation_resampling, tf_rotation_translation_resampling, rotation_resampling_to_image
+    vox = _dev(fixtures_vox[:2])
+    p3 = np.stack([demo_pose(250, 60, 3.3), demo_pose(40, 20, 2.8)]).astype(np.float32)
+    p5 = np.concatenate([p3, np.array([[3.0, -7.0], [0.5, 11.0]], np.float32)], 1)
+    want = tf_rotation_resampling(vox, _dev(p3), 64, 128)
+    assert torch.equal(tf_rotation_translation_resampling(vox, _dev(p5), 64, 128), want)
+    assert torch.equal(tf_rotation_resampling(vox, _dev(p5), 64, 128), want)
+    assert torch.equal(rotation_resampling_to_image(vox, _dev(p5), 64, 128), rotation_resampling_to_image(vox, _dev(p3), 64, 128))
+    with pytest.raises(ValueError):
+        tf_rotation_translation_resampling(vox, _dev(p3[:, :2].copy()), 64, 128)
+
+
 def test_every_path_of_the_tiled_resampler_is_bit_exact(fixtures_vox):
     """The tiled kernel has data-dependent paths: occupancy-grid fast path (taps read from the bitmap) vs float
     gathers, per-sample bit test vs the fallback for boxes too large for the LDS window (zoomed-out poses), occupied

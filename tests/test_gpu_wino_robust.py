@@ -71,7 +71,7 @@ def test_wino63_self_check_demotes_and_passes(monkeypatch, gemm_mode):
     b = torch.as_tensor((0.1 * rng.standard_normal(256)).astype(np.float32)).cuda()
     y43 = RU.conv_with_scheme(x, w, b, "f43")                                   # exact fp32: what a demoted filter computes
     y63 = RU.conv_with_scheme(x, w, b, "f63" + {"f32": "", "split": "s", "split16": "h"}[gemm_mode])
-    assert ops.WINO_GEMM == gemm_mode                                           # (conv_with_scheme restores the mode)
+    assert ops.gemm_mode_now() == gemm_mode                                     # (conv_with_scheme leaves the mode alone)
     assert not torch.equal(y43, y63)
     with torch.no_grad():
         # impossible tolerance -> demoted
@@ -131,13 +131,8 @@ def test_f44_layers_on_hostile_statistics(k):
             pw.wino43 = None
         if scheme == "direct":
             pw.wino4 = None
-        old = ops.WINO_GEMM
-        ops.WINO_GEMM = "split" if scheme == "f44s" else "f32"
-        try:
-            with torch.no_grad():
-                got = ops.conv2d(xd, pw, bd)
-        finally:
-            ops.WINO_GEMM = old
+        with torch.no_grad(), ops.gemm_mode("split" if scheme == "f44s" else "f32"):
+            got = ops.conv2d(xd, pw, bd)
         errs[scheme] = float((got.cpu().double() - want).abs().max()) / ymax
     print("%s (4x4 filter): max|y| %.3g  " % (name, ymax) + "  ".join("%s %.2e" % kv for kv in errs.items()))
     assert errs["f44"] <= 1e-4 and errs["f44s"] <= 1e-4 and errs["f22x4"] <= 3e-5 and errs["direct"] <= 3e-5, errs

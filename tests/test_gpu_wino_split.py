@@ -99,6 +99,10 @@ def test_split_input_transform_is_the_fp32_transform_in_three_pieces(which, B, H
     want = V.cpu().numpy().reshape(nxi, T, C).astype(np.float64)
     assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
     assert np.array_equal(got.astype(np.float32).astype(np.float64), got)        # the sum of the pieces IS an fp32 number
+    # the channel contract is the GEMM stage's (Cin >= 32, Cin % 32 == 0; include/rendernet_hip.h): a count the GEMM would refuse is refused here
+    assert lib.rn_winograd_split_v_bytes(sid, T, 48) == 0 and lib.rn_winograd_split_v_bytes(sid, T, 16) == 0
+    x48 = torch.zeros((B, H, W, 48), device="cuda")
+    assert lib.rn_winograd_split_input_transform(sid, L.ptr(x48), ctypes.c_void_p(Vs.data_ptr()), B, H, W, 48, 1, L.stream_ptr()) != 0
 
 
 CASES = [   # (which, B, H, W, Cin, Cout): ragged planes, 1 .. many tiles (below / across / above the 256-row block, the 128-row
@@ -114,7 +118,7 @@ CASES = [   # (which, B, H, W, Cin, Cout): ragged planes, 1 .. many tiles (below
 @pytest.mark.parametrize("smode", ["split", "split16"])
 @pytest.mark.parametrize("case", CASES)
 def test_conv2d_split_vs_oracle(case, smode):
-    """ops.conv2d with ops.WINO_GEMM = "split" (three bf16 pieces, six products) and "split16" (two fp16 pieces of the scaled value,
+    """ops.conv2d under ops.gemm_mode("split") (three bf16 pieces, six products) and "split16" (two fp16 pieces of the scaled value,
     three products) vs the oracle conv (bias / PReLU / residual / pre-activation / sigmoid epilogues), vs the exact-fp32 route on
     the same filter, and the input gradient through the transposed pack."""
     from rendernet_amd import ops
@@ -127,18 +131,17 @@ def test_conv2d_split_vs_oracle(case, smode):
     w = _xavier(rng, (R, R, Cin, Cout))
     b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
     alpha = rng.uniform(0, 0.25, Cout).astype(np.float32)
-    old_min, old_mode = ops.WINO43_MIN_PIXELS, ops.WINO_GEMM
+    old_min = ops.WINO43_MIN_PIXELS
     ops.WINO43_MIN_PIXELS = 1
     try:
         y0 = OL.conv2d(x, w, b, (1, 1))
         res = rng.standard_normal(y0.shape).astype(np.float32)
         outs = {}
         for mode in ("f32", smode):
-            ops.WINO_GEMM = mode
             pw = ops.pack_conv(_dev(w))
             if which != "f44":
                 pw.force_scheme = which
-            with torch.no_grad():
+            with torch.no_grad(), ops.gemm_mode(mode):
                 outs["split" if mode == smode else mode] = ops.conv2d(_dev(x), pw, _dev(b), _dev(alpha), _dev(res))
                 if mode == smode:
                     _close(ops.conv2d(_dev(x), pw, _dev(b)), y0, "split %s" % which)
@@ -162,12 +165,12 @@ def test_conv2d_split_vs_oracle(case, smode):
             dx = torch.empty((B, H, W, Cin), device="cuda")
             if which != "f44":
                 dp.force_scheme = which
-            ops.WINO_GEMM = smode
             dzd = _dev(dz)
-            L.check(ops._wino43_fwd(dzd, dp, (None, None, None, L.ptr(dx), None), B, H, W, Cout, Cin, 0), "split dgrad")
+            with ops.gemm_mode(smode):
+                L.check(ops._wino43_fwd(dzd, dp, (None, None, None, L.ptr(dx), None), B, H, W, Cout, Cin, 0), "split dgrad")
             _close(dx, OL.conv2d_transpose(dz, w, None, (1, 1)), "split dgrad vs oracle")
     finally:
-        ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
+        ops.WINO43_MIN_PIXELS = old_min
 
 
 @pytest.mark.parametrize("smode", ["split", "split16"])
@@ -180,16 +183,16 @@ def test_conv2d_transpose_s1_split(smode):
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     wt = _xavier(rng, (4, 4, Cout, Cin))
     b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
-    old_min, old_mode = ops.WINO43_MIN_PIXELS, ops.WINO_GEMM
-    ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = 1, smode
+    old_min = ops.WINO43_MIN_PIXELS
+    ops.WINO43_MIN_PIXELS = 1
     try:
         pt = ops.pack_conv_transpose(_dev(wt), 1)
         assert pt.split("f44") is not None
-        with torch.no_grad():
+        with torch.no_grad(), ops.gemm_mode(smode):
             got = ops.conv2d_transpose(_dev(x), pt, _dev(b), None, None, (1, 1))
         _close(got, OL.conv2d_transpose(x, wt, b, (1, 1)), "split convT s1")
     finally:
-        ops.WINO43_MIN_PIXELS, ops.WINO_GEMM = old_min, old_mode
+        ops.WINO43_MIN_PIXELS = old_min
 
 
 @pytest.mark.parametrize("smode", ["split", "split16"])
@@ -204,14 +207,9 @@ def test_bench_frames_match_golden_split(fixtures_vox, smode):
     idx = [int(i) for i in g["frames"]]
     vox, poses = synthetic_batch(24)
     spec = ShaderSpec().check()
-    r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True))
-    old = ops.WINO_GEMM
-    ops.WINO_GEMM = smode
-    try:
-        taps = {}
-        out = r.render(vox[idx], poses[idx], taps=taps).cpu().numpy()
-    finally:
-        ops.WINO_GEMM = old
+    r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True), gemm=smode)       # the mode is the renderer's own
+    taps = {}
+    out = r.render(vox[idx], poses[idx], taps=taps).cpu().numpy()
     for k in range(5):
         e4 = taps["enc4"][k, 3::8, 5::8, :].cpu().numpy()
         assert np.abs(e4 - g["enc4_%d" % k]).max() <= 2e-4 * np.abs(g["enc4_%d" % k]).max() + 1e-6
@@ -224,7 +222,7 @@ def test_bench_frames_match_golden_split(fixtures_vox, smode):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The fused 3x3x3 32 -> 32 kernel in bf16x3 (csrc/conv3d_wino_bf3.hip; on with ops.WINO_GEMM = "split", ops.CONV3D_SPLIT forces it).  The layers:
+# The fused 3x3x3 32 -> 32 kernel in bf16x3 (csrc/conv3d_wino_bf3.hip; on in the "split" modes of ops.gemm_mode, ops.CONV3D_SPLIT forces it).  The layers:
 # res_block_3d's two slim.conv3d [3,3,3] 32 -> 32 (tools/layer_util.py:60-75, RenderNet_Shader.py:61-68).
 C3_CASES = [
     (1, 4, 32, 2),       # one item, D = 2: both slices have a padded neighbour
@@ -266,7 +264,7 @@ def test_conv3d_split(case, smode, monkeypatch):
     formats (split16: max|x| by a pass here -- the chained hand-over is what the bench-frame and training tests exercise)."""
     from rendernet_amd import _lib as L, ops
     monkeypatch.setattr(ops, "CONV3D_SPLIT", True)
-    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    monkeypatch.setattr(ops._MODE, "mode", smode, raising=False)
     fmt = 1 if smode == "split16" else 0
     B, H, W, D = case
     rng = np.random.default_rng(hash(case) % 2**31)
@@ -461,7 +459,7 @@ def test_conv2d_1x1_split_vs_oracle(case, smode, monkeypatch):
     lib = L.lib()
     assert lib.rn_winograd_split_supported(sid | fmt, Cin, Cout) == 1 and lib.rn_conv2d_wino43_supported(Cin, Cout) in (0, 1)
     monkeypatch.setattr(ops, "SPLIT11_MIN_PIXELS", 1)
-    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    monkeypatch.setattr(ops._MODE, "mode", smode, raising=False)
     pw = ops.pack_conv(_dev(w))
     assert pw._split11 and pw.split("f11", fmt) is not None
     xd, bd, ad, rd = _dev(x), _dev(b), _dev(alpha), _dev(res)
@@ -476,9 +474,9 @@ def test_conv2d_1x1_split_vs_oracle(case, smode, monkeypatch):
         got = ops.conv2d(xd, pw, bd, ad, rd)                                  # the dispatcher takes the same route ...
         assert torch.equal(got, yy)
         _close(ops.conv2d(xd, pw, None, sigmoid=True), torch.sigmoid(OL.conv2d(x, w, None, (1, 1))), "1x1 split + sigmoid")
-        monkeypatch.setattr(ops, "WINO_GEMM", "f32")                          # ... and the exact mode the implicit-GEMM kernel
+        monkeypatch.setattr(ops._MODE, "mode", "f32", raising=False)                          # ... and the exact mode the implicit-GEMM kernel
         exact = ops.conv2d(xd, pw, bd, ad, rd)
-        monkeypatch.setattr(ops, "WINO_GEMM", smode)
+        monkeypatch.setattr(ops._MODE, "mode", smode, raising=False)
     assert float((got - exact).abs().max()) <= 1e-4 * float(exact.abs().max()) and not torch.equal(got, exact)
     # the input gradient: the same TF tensor packed the other way round (needs Cin % 256 == 0: the channel roles swap)
     if Cin % 256 == 0:
@@ -508,7 +506,7 @@ def test_projection_unit_on_the_split_stage(smode, monkeypatch):
     pw = ops.pack_conv(_dev(w))
     out = {}
     for mode in ("f32", smode):
-        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        monkeypatch.setattr(ops._MODE, "mode", mode, raising=False)
         with torch.no_grad():
             out[mode] = ops.projection(_dev(x), pw, _dev(b), _dev(al))
         _close(out[mode], want, "projection unit, %s" % mode)
@@ -516,7 +514,7 @@ def test_projection_unit_on_the_split_stage(smode, monkeypatch):
     # under autograd: forward + input gradient on the split stage (the filter gradient stays on the shared exact kernel).  The gradients are
     # compared on the LINEAR unit (no PReLU): among 8 M pre-activations a few lie within rounding of zero and take the other PReLU branch on the
     # two sides, which moves single entries of dx by a whole filter coefficient -- the epilogue backward has its own tests (test_gpu_train.py)
-    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    monkeypatch.setattr(ops._MODE, "mode", smode, raising=False)
     xd, wd, ad, bd = _dev(x).requires_grad_(True), pw.w_tf, _dev(al), _dev(b)
     tc = _TrainStub(wd, ad, bd)
     monkeypatch.setattr(ops, "TRAIN", tc)
@@ -683,7 +681,7 @@ def test_full_width_training_step_against_the_float64_golden(mode, monkeypatch):
     from rendernet_amd import ops
     from rendernet_amd.shader import ShaderSpec, init_shader_weights
     from rendernet_amd.train import Trainer
-    monkeypatch.setattr(ops, "WINO_GEMM", mode)
+    monkeypatch.setattr(ops._MODE, "mode", mode, raising=False)
     spec = ShaderSpec().check()
     tr = Trainer(spec, init_shader_weights(spec, seed=1234, perturb=True), device="cuda:0")
     got = bench.train_parity(tr, spec, 1)
@@ -740,7 +738,7 @@ def test_hipgraph_replay_of_the_split_routes(fixtures_vox, smode, monkeypatch):
     from rendernet_amd import ops
     from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
     from bench import synthetic_batch
-    monkeypatch.setattr(ops, "WINO_GEMM", smode)
+    monkeypatch.setattr(ops._MODE, "mode", smode, raising=False)
     spec = ShaderSpec().check()
     r = Renderer(spec, init_shader_weights(spec, seed=1234, perturb=True), device="cuda:0")
     vox, poses = synthetic_batch(24)
@@ -759,7 +757,7 @@ def test_split16_amax_handover_and_its_guard(monkeypatch):
     """fp16x2 route: a layer's launch leaves max|y| on its output (ops: y._rn_amax = (device word, tensor version)); the next layer takes
     its scale from it instead of a pass over x -- unless the tensor was changed in place since, which the version counter shows."""
     from rendernet_amd import ops
-    monkeypatch.setattr(ops, "WINO_GEMM", "split16")
+    monkeypatch.setattr(ops._MODE, "mode", "split16", raising=False)
     monkeypatch.setattr(ops, "WINO43_MIN_PIXELS", 1)
     rng = np.random.default_rng(3)
     x = rng.standard_normal((2, 24, 24, 256)).astype(np.float32)
@@ -779,3 +777,33 @@ def test_split16_amax_handover_and_its_guard(monkeypatch):
         assert len(misses) == 2                                       # version changed: the launcher looked again
         assert bool(torch.isfinite(y2).all())
         _close(y2, OL.conv2d(h.cpu().numpy(), w2, None, (1, 1)), "split16 conv after an in-place change")
+
+
+def test_two_renderers_of_one_process_run_different_modes():
+    """Review item 10 (round 5): the multiply-stage mode is a Renderer attribute.  Two full-width renderers over the SAME weights, one
+    exact fp32 and one bf16x3 split, rendered alternately in one process: each reproduces what a process running only that mode
+    computes (the `with ops.gemm_mode(...)` render of a third, mode-less renderer), the two differ (different routes, not one), and
+    both sit inside the 1e-3 bar of each other."""
+    from rendernet_amd import ops
+    from rendernet_amd.shader import Renderer, ShaderSpec, init_shader_weights
+    from bench import synthetic_batch
+    spec = ShaderSpec().check()
+    w = init_shader_weights(spec, seed=1234, perturb=True)
+    vox, poses = synthetic_batch(24)
+    vox, poses = vox[:2], poses[:2]
+    r32, rsp, rdef = Renderer(spec, w, gemm="f32"), Renderer(spec, w, gemm="split"), Renderer(spec, w)
+    assert (r32.gemm, rsp.gemm, rdef.gemm) == ("f32", "split", None)
+    a1, b1 = r32.render(vox, poses).clone(), rsp.render(vox, poses).clone()
+    a2, b2 = r32.render(vox, poses).clone(), rsp.render(vox, poses).clone()              # interleaved again: nothing leaks between them
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert not torch.equal(a1, b1) and float((a1 - b1).abs().max()) <= 1e-3
+    with ops.gemm_mode("f32"):
+        want32 = rdef.render(vox, poses).clone()
+    with ops.gemm_mode("split"):
+        wantsp = rdef.render(vox, poses).clone()
+    assert torch.equal(a1, want32) and torch.equal(b1, wantsp)
+    with ops.gemm_mode("split16"):                                                       # the renderer's own mode wins over the caller's context
+        assert torch.equal(r32.render(vox, poses), a1)
+    del r32, rsp, rdef
+    torch.cuda.empty_cache()
+

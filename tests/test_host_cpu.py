@@ -519,24 +519,91 @@ def test_default_multiply_stage_mode_and_bench_blocks():
     assert "peak_name" in rs and "peak_name" not in r32
 
 
+def test_multiply_stage_mode_is_a_per_call_context_not_module_state():
+    """Round 6 (review item 10): the mode of a launch is the innermost `with ops.gemm_mode(m)` of the CALLING THREAD, else the process
+    default (env RN_WINO_GEMM); Renderer / TextureRenderer / Trainer / Reconstructor carry it as the attribute `gemm` and enter the
+    context around what they launch.  No library code writes ops.WINO_GEMM (checked on the sources), so two renderers of one process
+    can run different modes (GPU side: tests/test_gpu_wino_split.py::test_two_renderers_of_one_process_run_different_modes)."""
+    import threading
+    from rendernet_amd import ops
+    from rendernet_amd.shader import Renderer
+    from rendernet_amd.texture import TextureRenderer
+    from rendernet_amd.train import Trainer
+    from rendernet_amd.reconstruct import Reconstructor
+    default = ops.gemm_mode_now()
+    assert default == ops.WINO_GEMM
+    seen = {}
+    with ops.gemm_mode("f32"):
+        assert ops.gemm_mode_now() == "f32"
+        with ops.gemm_mode("split16"):
+            assert ops.gemm_mode_now() == "split16"
+            with ops.gemm_mode(None):                                   # None: whatever is in force
+                assert ops.gemm_mode_now() == "split16"
+            t = threading.Thread(target=lambda: seen.setdefault("other", ops.gemm_mode_now()))
+            t.start(); t.join()
+        assert ops.gemm_mode_now() == "f32"
+        with pytest.raises(ValueError):
+            with ops.gemm_mode("bf16"):
+                pass
+        assert ops.gemm_mode_now() == "f32"                             # a refused mode leaves the context as it was
+    assert ops.gemm_mode_now() == default and seen["other"] == default   # another thread never sees this thread's context
+    for cls in (Renderer, TextureRenderer, Trainer, Reconstructor):
+        with pytest.raises(ValueError, match="gemm="):                  # validated before anything touches a device
+            cls(gemm="bf16")
+    for name in ("ops.py", "shader.py", "texture.py", "train.py", "reconstruct.py", "parallel.py"):
+        src = open(os.path.join(ROOT, "rendernet_amd", name)).read()
+        assert not re.search(r"(?<![A-Za-z_])WINO_GEMM\s*=(?!=)", src.replace('WINO_GEMM = os.environ.get("RN_WINO_GEMM", "split")', "")), name
+    for name in ("bench.py", "RenderNet_demo.py", "RenderNet_Shader.py", "RenderNet_Texture_Face_Normal.py", "Reconstruct_RenderNet_Face.py"):
+        assert not re.search(r"ops\.WINO_GEMM\s*=(?!=)", open(os.path.join(ROOT, name)).read()), name
+
+
+def test_train_context_refuses_unregistered_parameters_and_skips_marked_constants():
+    """Advisor finding (round 5): TrainContext.grad_if_param / ready skipped ANY tensor that was not registered, so a PReLU slope whose
+    registration was forgotten silently never trained.  Constants that ride in a parameter slot are now marked (ops.mark_constant: the
+    all-zero slope of tools/layer_util.py:_relu_slope); everything else must be registered or the call raises."""
+    import torch
+    from rendernet_amd import ops
+    from rendernet_amd._lib import RenderNetHipError
+    from rendernet_amd.tools.layer_util import _relu_slope
+    alpha, stray = torch.zeros(8), torch.zeros(8)
+    g = torch.zeros(8)
+    done = []
+    tc = ops.TrainContext({alpha.data_ptr(): g}, on_ready=done.append, device="cpu")
+    assert tc.grad_if_param(alpha) is g and tc.grad_if_param(None) is None
+    slope = _relu_slope(8, "cpu")
+    assert ops.is_constant(slope) and not ops.is_constant(alpha) and float(slope.abs().max()) == 0.0
+    assert tc.grad_if_param(slope) is None
+    with pytest.raises(RenderNetHipError, match="mark_constant"):
+        tc.grad_if_param(stray)
+    tc.ready(alpha, None, slope)
+    assert done == [alpha.data_ptr()]
+    with pytest.raises(RenderNetHipError):
+        tc.ready(stray)
+    frozen = ops.TrainContext(frozen=True, device="cpu")                # inverse rendering: no parameter gradients at all
+    assert frozen.grad_if_param(stray) is None and frozen.grad(stray) is None
+
+
 def test_conv3d_split_rule_and_factored_input_transform(monkeypatch):
-    """Two host-side facts of round 5's late changes.  (1) ops._conv3d_split: the split 3-D kernel takes every launch of at least 64 rows of
-    tiles (one 64 x 64 image) in the split modes -- its depth segments keep 256 workgroups busy from there on -- never in exact mode, and
-    RN_CONV3D_SPLIT forces it either way.  (2) the factored form of F(6x6,3x3)'s B^T that the split input transforms apply
+    """Two host-side facts of round 5's late changes.  (1) ops._conv3d_split: in the split modes the split 3-D kernel takes every map of at least 8 rows of
+    tiles PER IMAGE (round 6: the gate no longer looks at the batch size, so a frame is routed alike alone and in a batch; round 5 asked
+    for 64 rows in the launch) -- its depth segments keep the workgroups busy for few rows -- never in exact mode, and RN_CONV3D_SPLIT
+    forces it either way.  (2) the factored form of F(6x6,3x3)'s B^T that the split input transforms apply
     (csrc/conv_wino_bf3.hip: bt_apply -- rows 1..6 as +/- pairs over the even and the odd inputs, 26 operations instead of 44) is the matrix
     of csrc/wino_mats.h (WinoF63::BT), exactly in float64, and its nesting A^T [(G g G^T) . (B^T d B)] A is the 3x3 correlation."""
     from rendernet_amd import ops
     monkeypatch.setattr(ops, "CONV3D_SPLIT", None)
     for mode, want in (("split", True), ("split16", True), ("f32", False)):
-        monkeypatch.setattr(ops, "WINO_GEMM", mode)
+        monkeypatch.setattr(ops._MODE, "mode", mode, raising=False)
         assert ops._conv3d_split(1, 64, 64) is want and ops._conv3d_split(24, 64, 64) is want and ops._conv3d_split() is want
-        assert ops._conv3d_split(1, 32, 32) is False and ops._conv3d_split(3, 32, 32) is False          # 16 / 48 rows: the fp32 kernel's finer items
-        assert ops._conv3d_split(4, 32, 32) is want                                                        # 64 rows
-    monkeypatch.setattr(ops, "WINO_GEMM", "f32")
+        # round 6: a per-image gate (>= 8 rows of tiles per image) -- the batch size never changes the route of a frame
+        for B in (1, 3, 4, 24):
+            assert ops._conv3d_split(B, 32, 32) is want and ops._conv3d_split(B, 16, 16) is want            # 16 / 8 rows per image
+            assert ops._conv3d_split(B, 8, 8) is False and ops._conv3d_split(B, 14, 32) is False             # 4 / 7 rows
+    monkeypatch.setattr(ops._MODE, "mode", "f32", raising=False)
     monkeypatch.setattr(ops, "CONV3D_SPLIT", True)
     assert ops._conv3d_split(1, 8, 8) is True
     monkeypatch.setattr(ops, "CONV3D_SPLIT", False)
-    monkeypatch.setattr(ops, "WINO_GEMM", "split")
+    monkeypatch.setattr(ops._MODE, "mode", "split", raising=False)
     assert ops._conv3d_split(24, 64, 64) is False
 
     BT = np.array([[-1, 0, 21 / 4, 0, -21 / 4, 0, 1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0], [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0],
