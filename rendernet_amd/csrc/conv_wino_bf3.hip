@@ -28,6 +28,21 @@
 #include "wino_mats.h"
 #include <stdlib.h>
 
+// Cache-policy switches of the stage's streams, for same-box A/B builds (scripts/build_variant.py -D...; the product builds with the
+// defaults).  aux of the buffer instructions: 0 default, 2 = nt, 16 = sc1 (write-through / L1-bypassing), 17 = sc0 sc1.
+#ifndef RN_BF3_M_AUX
+#define RN_BF3_M_AUX 0          // the GEMM's stores of M (written once, read once by the output transform of another launch)
+#endif
+#ifndef RN_BF3_VLOAD_AUX
+#define RN_BF3_VLOAD_AUX 0      // the GEMM's LDS-DMA loads of V (a slab is read by the 4 CUs of one XCD that share the row block)
+#endif
+#ifndef RN_BF3_ULOAD_AUX
+#define RN_BF3_ULOAD_AUX 0      // ... of U (read by the 8 CUs of an XCD that share the channel block, and again every round)
+#endif
+#ifndef RN_BF3_VSTORE_NT
+#define RN_BF3_VSTORE_NT 0      // the input transform's stores of V as non-temporal stores
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -253,7 +268,11 @@ void wino_input_bf3_kernel(const float* __restrict__ x, char* __restrict__ Vs, i
             const char* lb = buf + j * (4 * IB_SEG);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                if (cok[k]) *reinterpret_cast<u32x4*>(gb + goff[k]) = *reinterpret_cast<const u32x4*>(lb + loff[k]);
+                if (cok[k]) {
+                    const u32x4 vv = *reinterpret_cast<const u32x4*>(lb + loff[k]);
+                    if (RN_BF3_VSTORE_NT) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(gb + goff[k]));
+                    else *reinterpret_cast<u32x4*>(gb + goff[k]) = vv;
+                }
         }
     }
 }
@@ -491,7 +510,11 @@ void wino_input_h2_kernel(const float* __restrict__ x, char* __restrict__ Vs, co
             const char* lb = buf + j * (4 * IH_SEG);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                if (cok[k]) *reinterpret_cast<u32x4*>(gb + goff[k]) = *reinterpret_cast<const u32x4*>(lb + loff[k]);
+                if (cok[k]) {
+                    const u32x4 vv = *reinterpret_cast<const u32x4*>(lb + loff[k]);
+                    if (RN_BF3_VSTORE_NT) __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(gb + goff[k]));
+                    else *reinterpret_cast<u32x4*>(gb + goff[k]) = vv;
+                }
         }
     }
 }
@@ -655,11 +678,11 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
             if (VP % 8 != 0 && j == NV - 1 && !vextra) return;
             const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
             const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * j) * 1024), 16, vo + j * 8192, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 8 * j) * 1024), 16, vo + j * 8192, 0, 0, RN_BF3_VLOAD_AUX);
         } else {
             const int i = j - NV;
             const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, RN_BF3_ULOAD_AUX);
         }
     };
     auto issue = [&](const Item& it, int s, int buf) {
@@ -794,7 +817,7 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 o = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), mrsrc,
-                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, 0);
+                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, RN_BF3_M_AUX);
                     }
             static_assert(NSTORE == 2 * NT2 * 4, "the counted waits assume this many stores per wave");
             after_store = true;
@@ -867,11 +890,11 @@ void wino_gemm_bf3_w4_kernel(const Bf3GemmArgs a)
         if (j < NVP) {
             const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.vplane + (size_t)s * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
             const unsigned vo = (unsigned)(it.m0 * SB_ROW) + dma_lane;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 4 * j) * 1024), 16, (vo + j * 4096) | oob, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sb + (wave + 4 * j) * 1024), 16, (vo + j * 4096) | oob, 0, 0, RN_BF3_VLOAD_AUX);
         } else {
             const int i = j - NVP;
             const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(it.upanel + (size_t)s * SB_UB), 0, SB_UB, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 4 * i) * 1024), 16, (dma_lane + i * 4096) | oob, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sb + VB + (wave + 4 * i) * 1024), 16, (dma_lane + i * 4096) | oob, 0, 0, RN_BF3_ULOAD_AUX);
         }
     };
     auto issue = [&](const Item& it, int s, int buf) {
@@ -981,7 +1004,7 @@ void wino_gemm_bf3_w4_kernel(const Bf3GemmArgs a)
                         f32x4 o = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
                         if constexpr (F::ID == 1) o *= sc;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), mrsrc,
-                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, 0);
+                                                               mo + (unsigned)(mt * 32 * a.Cout * 4) + nt * 128 + g * 32, 0, RN_BF3_M_AUX);
                     }
             static_assert(NSTORE == 64, "the counted waits assume this many stores per wave");
             after_store = true;
