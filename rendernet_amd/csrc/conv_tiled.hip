@@ -534,6 +534,130 @@ static int launch_stem(const RnConvProblem& p, hipStream_t st)
     return rn_check_launch("conv_stem");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The tail of the decoder: e_conv11 -- slim.conv2d_transpose 4x4 stride 1, 16 -> 1 | 3 channels, + sigmoid (RenderNet_Shader.py:125-131;
+// as a gridded problem: 4x4 taps over [B,H,W,16], pad_lo (2,2)).  403 MB read and 25 MB written at B = 24: an HBM kernel.  The LDS-tiled
+// form above (one output per thread, the 19 x 19 x 16 input box staged per 16 x 16 tile) took 0.30 ms = 0.18 of HBM speed: 256 broadcast
+// filter reads and 256 scalar LDS reads per output.  Here a WAVE owns a strip of 16 output columns and walks down the rows:
+//   * lane = (pixel g of the 16, channel quad q): a wave load is 16 pixels x 64 B = 1 KiB contiguous, four of them (the four column
+//     taps) per input row, the next row's in flight while this one multiplies;
+//   * an input row feeds the FOUR output rows it belongs to (row taps t0 = 0..3): four running accumulators per output channel, the
+//     slot of an output row = row % 4 -- compile-time, the row loop is unrolled by four;
+//   * when an output row has its fourth input row, the four quads of a pixel are summed with two DPP-class shuffles and lane q = 0 of
+//     every pixel stores: 64 contiguous bytes per wave and row at one output channel.
+template <int CO>
+__global__ __launch_bounds__(256)
+void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
+{
+    __shared__ f32x4s wl[16 * 4 * CO];                    // [tap][quad][n] = the packed filter's (K quad, n) element: k = tap * 16 + 4 quad + e
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 16 * 4 * CO; i += 256) {
+        const int n = i % CO, tq = i / CO;
+        wl[i] = (n < a.Cout) ? *reinterpret_cast<const f32x4s*>(a.w + ((size_t)tq * a.Npad + n) * 4) : f32x4s{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    long long id = (long long)blockIdx.x * 4 + wave;                  // strip: (image, row strip, column strip)
+    if (id >= (long long)a.B * nrs * ncs) return;
+    const int cs = (int)(id % ncs); id /= ncs;
+    const int rs = (int)(id % nrs); const int b = (int)(id / nrs);
+    const int g = lane >> 2, q = lane & 3;
+    const int col = cs * 16 + g, row0 = rs * R;                       // R % 4 == 0, so row0 % 4 == 0
+    const int H = a.I0, W = a.I1;
+    const float* xb = a.x + (size_t)b * H * W * 16 + 4 * q;
+    // column taps: input column col - P1 + t1
+    bool cok[4];
+    int coff[4];
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1) {
+        const int ic = col - a.P1 + t1;
+        cok[t1] = (unsigned)ic < (unsigned)W;
+        coff[t1] = (cok[t1] ? ic : 0) * 16;
+    }
+    auto load_row = [&](int u, f32x4s (&xv)[4]) {                     // u = input row + P0
+        const int ir = u - a.P0;
+        const bool rok = (unsigned)ir < (unsigned)H && u < row0 + R + 3;
+        const float* xr = xb + (size_t)(rok ? ir : 0) * W * 16;
+#pragma unroll
+        for (int t1 = 0; t1 < 4; ++t1)
+            xv[t1] = (rok && cok[t1]) ? *reinterpret_cast<const f32x4s*>(xr + coff[t1]) : f32x4s{0.f, 0.f, 0.f, 0.f};
+    };
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    f32x2s acc[4][CO];                                                // two partial sums per accumulator: packed FMAs (v_pk_fma_f32) on channel pairs
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[sl][n] = f32x2s{0.f, 0.f};
+    const bool colok = col < a.O1;
+    // input rows u .. u + 3 live in a ring of four register rows (row u in xr[u % 4], compile-time after unrolling): while row u
+    // multiplies, rows u + 1 .. u + 3 are in flight -- with one row ahead the waves waited on memory 70 % of their cycles (0.205 ms)
+    f32x4s xr[4][4];
+    load_row(row0, xr[0]);
+    load_row(row0 + 1, xr[1]);
+    load_row(row0 + 2, xr[2]);
+    const int uend = row0 + R + 3;                                    // u = row0 .. row0 + R + 2 (output rows u - t0 inside the strip only)
+    for (int u0 = row0; u0 < uend; u0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = u0 + j;
+            if (u >= uend) break;                                     // uniform
+            load_row(u + 3, xr[(j + 3) & 3]);                         // (rows beyond the strip's last input row load nothing)
+#pragma unroll
+            for (int t0 = 0; t0 < 4; ++t0) {
+                const int o0 = u - t0;
+                if (o0 < row0 || o0 >= row0 + R) continue;            // uniform: the strip's first / last three input rows
+                const int sl = (j - t0) & 3;                          // = o0 % 4, compile-time after unrolling
+#pragma unroll
+                for (int t1 = 0; t1 < 4; ++t1)
+#pragma unroll
+                    for (int n = 0; n < CO; ++n) {
+                        const f32x4s w = wl[((t0 * 4 + t1) * 4 + q) * CO + n];
+                        acc[sl][n] = __builtin_elementwise_fma(f32x2s{xr[j][t1][0], xr[j][t1][1]}, f32x2s{w[0], w[1]}, acc[sl][n]);
+                        acc[sl][n] = __builtin_elementwise_fma(f32x2s{xr[j][t1][2], xr[j][t1][3]}, f32x2s{w[2], w[3]}, acc[sl][n]);
+                    }
+            }
+            // output row u - 3 has all four of its input rows
+            const int od = u - 3;
+            if (od >= row0) {                                         // uniform
+                const int sl = (j + 1) & 3;                           // = (j - 3) & 3
+#pragma unroll
+                for (int n = 0; n < CO; ++n) {
+                    float v = acc[sl][n][0] + acc[sl][n][1];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    acc[sl][n] = f32x2s{0.f, 0.f};
+                    if (q == 0 && colok && od < a.O0 && n < a.Cout) {
+                        const size_t oo = (((size_t)b * a.O0 + od) * a.O1 + col) * a.Cout + n;
+                        v += a.bias ? a.bias[n] : 0.f;
+                        if (a.z) a.z[oo] = v;
+                        if (a.act & RN_ACT_PRELU) v = fmaxf(v, 0.f) + (a.alpha ? a.alpha[n] : 0.f) * fminf(v, 0.f);
+                        if (a.act & RN_ACT_ELU) v = v > 0.f ? v : expf(v) - 1.f;
+                        if (a.res) v += a.res[oo];
+                        if (a.act & RN_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                        a.y[oo] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CO>
+static int launch_tail(const RnConvProblem& p, hipStream_t st)
+{
+    TiledArgs2 a;
+    a.x = p.x; a.w = p.w; a.bias = p.bias; a.alpha = p.alpha; a.res = p.residual; a.y = p.y; a.z = p.preact;
+    a.B = p.B; a.I0 = p.I[0]; a.I1 = p.I[1]; a.I2 = 1; a.O0 = p.O[0]; a.O1 = p.O[1]; a.O2 = 1;
+    a.Cout = p.Cout; a.Npad = p.Npad; a.P0 = p.P[0]; a.P1 = p.P[1]; a.P2 = 0;
+    a.nt0 = a.nt1 = a.nt2 = 0; a.act = p.act;
+    static const int r_env = getenv("RN_TAIL_ROWS") ? atoi(getenv("RN_TAIL_ROWS")) : 0;
+    const int R = (r_env >= 4 && r_env % 4 == 0) ? r_env : 32;        // rows per strip (three halo rows re-read per strip; measured 8: 0.210, 16: 0.196, 32: 0.191, 64: 0.215 ms)
+    const int ncs = (p.O[1] + 15) / 16, nrs = (p.O[0] + R - 1) / R;
+    const long long nw = (long long)p.B * nrs * ncs;
+    if (nw <= 0 || (nw + 3) / 4 > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_tail: bad grid %lld", nw);
+    hipLaunchKernelGGL(conv_tail_kernel<CO>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, a, R, ncs, nrs);
+    return rn_check_launch("conv_tail");
+}
+
 static bool is_plain(const RnConvProblem& p)
 {
     // contiguous channels-last output covering the whole grid (no sub-pixel phase addressing)
@@ -577,7 +701,11 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     if (tiled_e2 && p.K[0] == 3 && p.K[1] == 3 && p.K[2] == 3 && p.S[0] == 1 && p.S[1] == 1 && p.S[2] == 2 && p.Cin == 8 && p.Cout == 16)
         return launch_tiled<3, 3, 3, 1, 1, 2, 8, 16, 4, 4, 16>(p, st);
     const bool k44 = p.K[0] == 4 && p.K[1] == 4 && p.K[2] == 1 && p.S[0] == 1 && p.S[1] == 1 && p.S[2] == 1 && p.I[2] == 1;
-    if (k44 && p.Cin == 16 && p.Cout == 1) return launch_tiled<4, 4, 1, 1, 1, 1, 16, 1, 16, 16, 1>(p, st);
-    if (k44 && p.Cin == 16 && p.Cout == 3) return launch_tiled<4, 4, 1, 1, 1, 1, 16, 3, 16, 16, 1>(p, st);
+    // e_conv11: the strip kernel (RN_NO_TAIL_KERNEL=1: the LDS-tiled one); it needs 16-byte aligned pixels and the output grid = the input grid
+    static const bool no_tail = getenv("RN_NO_TAIL_KERNEL") != nullptr;
+    const bool tail_ok = !no_tail && p.O[0] == p.I[0] && p.O[1] == p.I[1] && p.P[0] >= 0 && p.P[0] <= 3 && p.P[1] >= 0 && p.P[1] <= 3 &&
+                         (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
+    if (k44 && p.Cin == 16 && p.Cout == 1) return tail_ok ? launch_tail<1>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 1, 16, 16, 1>(p, st);
+    if (k44 && p.Cin == 16 && p.Cout == 3) return tail_ok ? launch_tail<3>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 3, 16, 16, 1>(p, st);
     return RN_E_UNSUPPORTED;
 }
