@@ -696,7 +696,10 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     }
     if (k555s2 && p.Cout == 8 && p.Cin == 5) return launch_rows<5, 5, 5, 2, 2, 2, 5, 8, 4>(p, st);
     // (e_conv2 -- 3^3 stride (1,1,2), 8 -> 16 -- measured 0.98 ms tiled vs 0.79 ms with the generic direct kernel: its 8-float
-    //  channel runs already coalesce, and 16 accumulators x 216 taps leave the tile's 4 waves per CU latency-bound.  Not routed here.)
+    //  channel runs already coalesce, and 16 accumulators x 216 taps leave the tile's 4 waves per CU latency-bound.  Not routed here.
+    //  Round 6 built two more forms, both parity-green and neither faster than the generic kernel's 0.57 ms in the step: an fp32-MFMA
+    //  kernel with LDS-staged depth lines (0.53-0.55 ms, launch-bound) and a packed-FMA strip kernel, one wave per pair of output
+    //  depth lines (0.59-0.63 ms at 254 registers): profiles/r06e_econv2_mfma.txt.)
     static const bool tiled_e2 = getenv("RN_TILED_ECONV2") != nullptr;
     if (tiled_e2 && p.K[0] == 3 && p.K[1] == 3 && p.K[2] == 3 && p.S[0] == 1 && p.S[1] == 1 && p.S[2] == 2 && p.Cin == 8 && p.Cout == 16)
         return launch_tiled<3, 3, 3, 1, 1, 2, 8, 16, 4, 4, 16>(p, st);

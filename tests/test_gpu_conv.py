@@ -131,6 +131,9 @@ CONVT2D_CASES = [
     (2, 16, 16, 16, 1, 1),     # e_conv11 greyscale (direct)
     (1, 16, 16, 16, 3, 1),     # e_conv11 RGB (direct)
     (1, 8, 8, 16, 3, 2),       # texture heads: stride-2 to 3 channels (direct, phases)
+    (1, 37, 21, 16, 1, 1),     # e_conv11 strip kernel (csrc/conv_tiled.hip: conv_tail_kernel): two row strips of 32, two column strips of 16, both ragged
+    (2, 70, 50, 16, 3, 1),     # ... RGB, three row strips, four column strips (the last one 2 pixels wide), two images
+    (1, 3, 5, 16, 1, 1),       # ... a map smaller than one strip and than the filter's reach
 ]
 
 
