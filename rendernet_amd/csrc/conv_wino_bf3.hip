@@ -1247,14 +1247,20 @@ static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const vo
     const int full = (int)(T / SB_BM), ragged = (int)(T % SB_BM);    // whole 256-row blocks; rows of the last, partial one
     if ((long long)nxi * (full + 1) * a.nblocks * 2 > 0x3fffffff) return rn_set_error(RN_E_UNSUPPORTED, "wino_gemm_bf3: too many items");
     a.mrows = SB_BM;
-    // One workgroup per CU takes items id, id + 256, ...  Costs below are in half rounds (a whole item = 2, a 128-row half item = 1).
-    auto tail_cost = [](int rem) { if (rem == 0) return 0; const int half = (2 * rem + 255) / 256; return half < 2 ? half : 2; };
+    // One workgroup per CU takes items id, id + 256, ...  Costs below are in sixteenths of a round of whole (256-row) items.  A round of 128-row
+    // half items costs 9, not 8 -- a half item loads the same 256-channel U panel for half the rows -- and every further launch about 4 (drain,
+    // launch, pipeline fill), fitted on the res2 shape at batch 2 and 3 (profiles/r06l_halfcost.txt: batch 2 as one round of whole items 7.98 ms
+    // per step against 8.29 as two rounds of half items; batch 3 as three rounds of half items in one launch 12.17 against a round of whole items
+    // + a launch of half items 12.47).  RN_WINO_BF3_HALF_COST overrides the 9 (measurement).
+    static const int HC = getenv("RN_WINO_BF3_HALF_COST") ? atoi(getenv("RN_WINO_BF3_HALF_COST")) : 9;
+    constexpr int WC = 16, LC = 4;
+    auto tail_cost = [](int rem) { if (rem == 0) return 0; const int half = (2 * rem + 255) / 256; return half < 2 ? half * HC : WC; };
     // the ragged block's rows as whole items or as 1 .. 2 half items per (xi, n-block)
     auto ragged_plan = [&](int& wm, int& parts) {
         const int nit = nxi * a.nblocks;
         wm = 4; parts = 1;
-        int best = (nit + 255) / 256 * 2;
-        const int hp = (ragged + 127) / 128, hc = (nit * hp + 255) / 256;
+        int best = (nit + 255) / 256 * WC;
+        const int hp = (ragged + 127) / 128, hc = (nit * hp + 255) / 256 * HC;
         if (!notail && hc < best) { best = hc; wm = 2; parts = hp; }
         return best;
     };
@@ -1262,10 +1268,12 @@ static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const vo
     // several items per CU back to back, whenever that costs no more than whole blocks + a ragged tail.
     if (!notail && full <= 1) {
         const int nfull = nxi * full * a.nblocks;
-        int cost_split = nfull / 256 * 2 + tail_cost(nfull % 256);
-        if (ragged > 0) { int wm, parts; cost_split += ragged_plan(wm, parts); }
+        const int tc = tail_cost(nfull % 256);                               // (a tail at whole-item cost stays in the main launch)
+        int cost_split = nfull / 256 * WC + tc, launches = (nfull >= 256 || tc == WC) + (tc != 0 && tc < WC);
+        if (ragged > 0) { int wm, parts; cost_split += ragged_plan(wm, parts); ++launches; }
+        cost_split += LC * (launches - 1);
         const long long items = (long long)nxi * a.nblocks * ((T + 127) / 128);
-        const int ucost = (int)((items + 255) / 256);
+        const int ucost = (int)((items + 255) / 256) * HC;
         if (ucost <= cost_split) {
             a.mb_begin = 0; a.mrows = 128; a.mblocks = (int)((T + 127) / 128);
             return wino_gemm_bf3_launch(fmt, 2, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
@@ -1275,7 +1283,7 @@ static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const vo
         a.mb_begin = 0; a.mblocks = full;
         const int nitems = nxi * full * a.nblocks;
         const int rem = nitems % 256;
-        const bool half_tail = !notail && rem != 0 && tail_cost(rem) < 2;       // the last, partial round as half items: half a round
+        const bool half_tail = !notail && rem != 0 && tail_cost(rem) < WC;       // the last, partial round as half items: half a round
         const int tail = half_tail ? rem : 0;
         if (nitems - tail > 0) {
             const int rc = wino_gemm_bf3_launch(fmt, 4, tag, a, 0, nitems - tail, 0, st);
