@@ -1279,9 +1279,23 @@ static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const vo
             return wino_gemm_bf3_launch(fmt, 2, tag, a, 0, nxi * a.mblocks * a.nblocks, 1, st);
         }
     }
-    if (full > 0) {
-        a.mb_begin = 0; a.mblocks = full;
-        const int nitems = nxi * full * a.nblocks;
+    // the whole blocks in one launch of whole items (+ a launch of half items for a last round that is at most half full); the ragged block
+    // either as a launch of its own (ragged_plan) or -- when that is cheaper by the costs above -- as one more block of the main launch
+    // (RN_WINO_BF3_NOMERGE: never): the 512-channel layers at batch 24 become 6 full rounds instead of 5 + two half-empty launches.
+    auto main_cost = [&](int nitems) {
+        const int rem = nitems % 256, tc = tail_cost(rem);
+        return nitems / 256 * WC + tc + (tc != 0 && tc < WC && nitems >= 256 ? LC : 0);
+    };
+    static const bool nomerge = getenv("RN_WINO_BF3_NOMERGE") != nullptr;
+    int blocks = full, left = ragged;
+    if (ragged > 0 && !notail && !nomerge) {
+        int wm, parts;
+        const int separate = main_cost(nxi * full * a.nblocks) + ragged_plan(wm, parts) + (full > 0 ? LC : 0);
+        if (main_cost(nxi * (full + 1) * a.nblocks) < separate) { blocks = full + 1; left = 0; }
+    }
+    if (blocks > 0) {
+        a.mb_begin = 0; a.mblocks = blocks;
+        const int nitems = nxi * blocks * a.nblocks;
         const int rem = nitems % 256;
         const bool half_tail = !notail && rem != 0 && tail_cost(rem) < WC;       // the last, partial round as half items: half a round
         const int tail = half_tail ? rem : 0;
@@ -1294,7 +1308,7 @@ static int gemm_split_planes(int fmt, int nxi, int tag, const void* Vs, const vo
             if (rc != RN_OK) return rc;
         }
     }
-    if (ragged > 0) {
+    if (left > 0) {
         a.mb_begin = full; a.mblocks = 1;
         int wm, parts;
         ragged_plan(wm, parts);
