@@ -547,8 +547,8 @@ def gemm_roofline(gemm_events, layer_events, wtrunk, hw, nloc, mode, gemm_mode):
             peak, peak_name = PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 MFMA dense peak / 3 (three fp16 products per fp32 product)"
             tkey = "wino63_gemm_h2_res2" if which == "f63" else "wino43_gemm_h2_res2"
         elif gemm_mode == "split":
-            name = ("wino_gemm_bf3_kernel (GEMM stage of Winograd %s on split operands: 256x256x16 blocks, six 32x32x16 bf16 MFMAs per "
-                    "fp32 product tile, fp32 accumulate, LDS-DMA 3 stages, persistent)" % fname)
+            name = ("wino_gemm_bf3_kernel (GEMM stage of Winograd %s on split operands: 256x256x16 blocks, the six bf16 piece products of an fp32 "
+                    "product as three 16x16x32 bf16 MFMAs per 16x16 tile (K = 16 channels x 2 pieces), fp32 accumulate, LDS-DMA 3 stages, persistent)" % fname)
             basis = ("fp32-equivalent FLOPs = 2*%d*T*Cin*Cout, T = B*ceil(H/%d)*ceil(W/%d) tiles; every one executed as 6 bf16 "
                      "piece products (x0y0, x0y1, x1y0, x0y2, x1y1, x2y0)" % (nxi, m, m))
             peak, peak_name = PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 MFMA dense peak / 6 (six bf16 products per fp32 product)"

@@ -20,10 +20,12 @@
 // verbatim (48 wave instructions of 1 KiB, lane-linear on both sides).  The two 16-byte chunks of a plane are stored
 // swapped when bit 3 of the row index is set: with 96-byte rows that makes the ds_read_b128 fragment reads (lane = row,
 // 16 lanes per LDS cycle) conflict-free.
-// GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), a wave = 2 x 4 MFMA tiles of 32 x 32 (128 accumulators),
+// GEMM: 512 threads = 8 waves (4 along tiles x 2 along channels), a wave = 64 tiles x 128 channels (128 accumulators),
 // U is the A operand (accumulator registers = 4 consecutive output channels: 16-byte stores), three LDS stages of 48 KiB,
 // DMA two K steps ahead with counted vmcnt (the loads stay in flight across the one barrier of a step), persistent grid
-// with the XCD-contiguous item order of the fp32 kernel.
+// with the XCD-contiguous item order of the fp32 kernel.  Format B3 multiplies on v_mfma_f32_16x16x32_bf16 with the K = 32 of an
+// instruction = 16 channels x two pieces (three instructions per 16 x 16 tile and K step, round 6: the shape the chip sustains 13 %
+// faster at its power limit); format H2 and RN_WINO_BF3_P16=0 on v_mfma_f32_32x32x16_bf16, one product per instruction.
 #include "rn_common.h"
 #include "wino_mats.h"
 #include <stdlib.h>
@@ -624,7 +626,7 @@ struct Bf3GemmArgs {
 // accumulators); 2 -> block 128 x 256 (waves 2 x 4, wave tile 64 x 64 = 2 x 2 tiles): the launcher runs ragged row blocks, the
 // items of a last partial round and small batches as half items.
 // TAG only names the kernel per layer class in profiler tables (0: F43, 1: F44, 2: F63 Cin >= 1024, 3: F63 narrower, 4: filter gradient, 5: 1x1 filter)
-template <class F, int WM, int TAG>
+template <class F, int WM, int TAG, bool P16 = false>
 __global__ __launch_bounds__(512, 2)
 void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
 {
@@ -704,6 +706,126 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
         }
     };
 
+    if constexpr (P16) {
+        // ---- format B3 on v_mfma_f32_16x16x32_bf16, the K = 32 of one instruction = the 16 channels of a K step x TWO pieces: with
+        // A = [u_p | u_q] and B = [v_r | v_s] (lanes 0..31 read the first piece's plane, lanes 32..63 the second's) one MFMA is
+        // u_p.v_r + u_q.v_s, so the six products are three instructions per 16 x 16 tile:
+        //     [u0|u2].[v2|v0]   (the two smallest terms first)      [u0|u1].[v1|v1]      [u0|u1].[v0|v0]
+        // Same LDS stages, DMA schedule and item walk as the 32 x 32 x 16 form below; per K step a wave reads 4 x 3 V fragments (held for
+        // the step) + 2 per 16-channel group of U (double-buffered) = 28 | 20 ds_read_b128 for 96 | 48 MFMAs of 16 cycles.
+        // Why: on random data the chip sustains 1978 TFLOP/s of 16x16x32 against 1754 of 32x32x16 (scripts/mfma_power_probe.hip,
+        // profiles/r06p_mfma_power_probe.txt: half the accumulator traffic per MAC), and this stage runs at that power ceiling.
+        static_assert(F::ID == 0, "paired 16x16x32 products: format B3 only");
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        constexpr int TT = 4, CT = NT2 * 2;                           // 16-row tile groups of the wave's 64 rows; 16-channel groups of its 128 | 64 channels
+        // lane (i, g4) of an operand holds row i, k group g4 (8 values).  A ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15,
+        // 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- i.e. rows {0-3, 12-15} of one chunk with rows {4-11} of the other; with the stage's
+        // row layout (96-byte rows, chunks swapped in rows with bit 3 set) that is a 2-way bank conflict on every read (SQ_LDS_BANK_CONFLICT =
+        // half of SQ_LDS_IDX_ACTIVE) unless operand row i is LDS row pi(i), pi = swap of the quads 8-11 and 12-15: then both chunk sets are
+        // closed under row + 8 and the 16 lanes of a group hit 16 different bank quads.  The outputs move with it: D row 4 g4 + e is channel
+        // 4 sigma(g4) + e, sigma = (0, 1, 3, 2), D column i is tile row pi(i).
+        const int i16 = lane & 15, g4 = lane >> 4;
+        const int r16 = i16 < 8 ? i16 : i16 ^ 4, gs = g4 < 2 ? g4 : g4 ^ 1;
+        const unsigned sw = (unsigned)(((g4 & 1) ^ ((r16 >> 3) & 1)) << 4);   // 16-byte chunk of the plane (swapped in rows with bit 3 set)
+        const bool second = g4 >= 2;                                   // this lane's 8 values belong to the second piece of the pair
+        const unsigned vrow = (unsigned)((wm * 64 + r16) * SB_ROW) + sw, urow = (unsigned)(VB + (wn * (NT2 * 32) + r16) * SB_ROW) + sw;
+        const unsigned vo_a = vrow, vo_b = vrow + 32u, vo_c = vrow + (second ? 0u : 64u);     // [v0|v0], [v1|v1], [v2|v0]
+        const unsigned uo_a = urow + (second ? 32u : 0u), uo_b = urow + (second ? 64u : 0u);  // [u0|u1], [u0|u2]
+        f32x4_ acc[TT][CT];
+        frag va[TT], vb[TT], vc[TT], ua[2], ub[2];
+        auto ldu = [&](const char* sb, int ct, int slot) {
+            ua[slot] = *reinterpret_cast<const frag*>(sb + uo_a + ct * (16 * SB_ROW));
+            ub[slot] = *reinterpret_cast<const frag*>(sb + uo_b + ct * (16 * SB_ROW));
+        };
+        Item cur, nxt;
+        if (!decode(0, cur)) return;
+        bool have_next = decode(1, nxt);
+        issue(cur, 0, 0);
+        issue(cur, 1, 1);
+        wait_stage(true, false);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            va[tt] = *reinterpret_cast<const frag*>(smem + vo_a + tt * (16 * SB_ROW));
+            vb[tt] = *reinterpret_cast<const frag*>(smem + vo_b + tt * (16 * SB_ROW));
+            vc[tt] = *reinterpret_cast<const frag*>(smem + vo_c + tt * (16 * SB_ROW));
+        }
+        ldu(smem, 0, 0);
+        int buf = 0;
+        bool after_store = false;
+        auto step = [&](int s) {
+            const char* sb = smem + buf * STAGE;
+            const int bn = buf == SB_NSTAGE - 1 ? 0 : buf + 1;
+            const int b2 = bn == SB_NSTAGE - 1 ? 0 : bn + 1;
+            const int s2 = s + 2;
+            const bool in_item = s2 < a.ksteps;
+            const bool issued = !(a.probe & 1) && (in_item || have_next);
+            const Item& src = in_item ? cur : nxt;
+            const int ss = in_item ? s2 : s2 - a.ksteps;
+            auto dma = [&](int j) { if (issued && j < NPIECE) issue_piece(src, ss, b2, j); };
+            const bool more = s + 1 < a.ksteps || have_next;
+            const char* sn = smem + bn * STAGE;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int slot = ct & 1;
+                const bool last = ct == CT - 1;
+                if (!last) ldu(sb, ct + 1, slot ^ 1);
+                if (CT == 8) { if (ct < CT - 1) dma(ct); }
+                else { if (ct < CT - 1) { dma(ct); dma(ct + 3); } }
+                if (last) {
+                    // every DMA piece of the stage after next is out: wait for the NEXT stage (counted), barrier, then this step's last
+                    // channel group runs while the next step's first operands replace the fragments it has finished with
+                    wait_stage(issued, after_store);
+                    if (more) ldu(sn, 0, slot ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);                    // (the reads of the next group's U fragments stay AHEAD of this group's MFMAs)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ub[slot], vc[tt], acc[tt][ct], 0, 0, 0);
+                if (last && more) {
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) vc[tt] = *reinterpret_cast<const frag*>(sn + vo_c + tt * (16 * SB_ROW));
+                }
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[slot], vb[tt], acc[tt][ct], 0, 0, 0);
+                if (last && more) {
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) vb[tt] = *reinterpret_cast<const frag*>(sn + vo_b + tt * (16 * SB_ROW));
+                }
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[slot], va[tt], acc[tt][ct], 0, 0, 0);
+                if (last && more) {
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) va[tt] = *reinterpret_cast<const frag*>(sn + vo_a + tt * (16 * SB_ROW));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf = bn;
+            after_store = false;
+        };
+        for (int r = 0;; ++r) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[tt][ct] = f32x4_{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.ksteps; ++s) step(s);
+            // D (16 x 16) = U group (rows: channels) x V group (cols: tile rows): register e of lane (i, g4) is channel 4 sigma(g4) + e, tile row pi(i)
+            if (!(a.probe & 2)) {
+                const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(cur.mplane, 0, a.m_bytes, 0x00020000);
+                const unsigned mo = (unsigned)(((cur.m0 + wm * 64 + r16) * a.Cout + cur.nb * SB_BN + wn * (NT2 * 32) + gs * 4) * 4);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[tt][ct]), mrsrc,
+                                                               mo + (unsigned)(tt * 16 * a.Cout * 4) + ct * 64, 0, RN_BF3_M_AUX);
+                static_assert(NSTORE == TT * CT, "the counted waits assume this many stores per wave");
+                after_store = true;
+            }
+            if (!have_next) break;
+            cur = nxt;
+            have_next = decode(r + 2, nxt);
+        }
+        return;
+    }
     f32x16 acc[2][NT2];
     auto ldv = [&](const char* sb, int mt, frag (&v)[NP]) {
 #pragma unroll
@@ -1159,12 +1281,17 @@ int rn_launch_wino_input_bf3_ex(int scheme, const float* x, void* Vs, int B, int
 }
 
 // items [begin, end) of the block range the args name, `parts` BM-row parts of each (0: all 4 / WM of them)
+// RN_WINO_BF3_P16: 1 (default) = format B3 on v_mfma_f32_16x16x32_bf16 with paired pieces (see the kernel), 0 = on v_mfma_f32_32x32x16_bf16
+// (rounds 4-6; kept for the A/B of profiles/r06p_* and as the reference of the four-wave variant's bit-identity test)
+static bool p16_mode() { static const bool m = getenv("RN_WINO_BF3_P16") ? atoi(getenv("RN_WINO_BF3_P16")) != 0 : true; return m; }
+
 template <class F, int WM, int TAG>
 static int wino_gemm_bf3_launch_t(Bf3GemmArgs a, int begin, int end, int parts, hipStream_t st)
 {
     a.item_begin = begin; a.item_end = end; a.parts = parts > 0 ? parts : 4 / WM;
     const size_t lds = (size_t)SB_NSTAGE * (WM * 64 * F::ROW + SB_BN * F::ROW);
     auto kern = wino_gemm_bf3_kernel<F, WM, TAG>;
+    if constexpr (F::ID == 0) { if (p16_mode()) kern = wino_gemm_bf3_kernel<F, WM, TAG, true>; }
     { const int rc_ = rn_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc_ != RN_OK) return rc_; }
     const int n = (end - begin) * a.parts;
     // RN_WINO_BF3_GRID (a multiple of 8, <= 256; measurement): workgroups = CUs the persistent kernel occupies (one workgroup per CU)

@@ -22,10 +22,10 @@ KERNELS = {   # key in traffic.json -> (pass-name prefix, kernel-name filter(s),
     "wino63_input_res2": ("wino63", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 4),
     "wino63_output_res2": ("wino63", ["wino_output_kernel"], 64 * 2904 * 1024 * 4 + 24 * 64 * 64 * 1024 * 4),
     # split (bf16x3) route, same shape: V and U are 6 bytes per element (three bf16 pieces), M stays fp32
-    "wino63_gemm_bf3_res2": ("bf3", ["rnf::FmtB3, 4, 2>", "rnf::FmtB3, 2, 2>"], 64 * 2904 * (1024 * 6 + 1024 * 4) + 64 * 1024 * 1024 * 6),
+    "wino63_gemm_bf3_res2": ("bf3", ["rnf::FmtB3, 4, 2,", "rnf::FmtB3, 2, 2,"], 64 * 2904 * (1024 * 6 + 1024 * 4) + 64 * 1024 * 1024 * 6),
     "wino63_input_bf3_res2": ("bf3", ["wino_input_bf3_kernel"], 24 * 64 * 64 * 1024 * 4 + 64 * 2904 * 1024 * 6),
     # fp16x2 route: V and U are 4 bytes per element (two fp16 pieces of the scaled value)
-    "wino63_gemm_h2_res2": ("bf3", ["rnf::FmtH2, 4, 2>", "rnf::FmtH2, 2, 2>"], 64 * 2904 * (1024 * 4 + 1024 * 4) + 64 * 1024 * 1024 * 4),
+    "wino63_gemm_h2_res2": ("bf3", ["rnf::FmtH2, 4, 2,", "rnf::FmtH2, 2, 2,"], 64 * 2904 * (1024 * 4 + 1024 * 4) + 64 * 1024 * 1024 * 4),
     "wino63_input_h2_res2": ("bf3", ["wino_input_h2_kernel", "absmax_kernel"], 24 * 64 * 64 * 1024 * 4 * 2 + 64 * 2904 * 1024 * 4),
     "wino43_gemm_res2": ("wino43", ["wino43_gemm_kernel<4, 0>", "wino43_gemm_kernel<2, 0>"], 36 * 6144 * (1024 + 1024) * 4 + 36 * 1024 * 1024 * 4),
     "wino43_input_res2": ("wino43", ["wino_input_kernel"], 24 * 64 * 64 * 1024 * 4 + 36 * 6144 * 1024 * 4),

@@ -393,12 +393,25 @@ def test_four_wave_gemm_variant_is_bit_identical(tmp_path):
     got = {}
     for w4 in ("0", "1"):
         out = str(tmp_path / ("w4_%s.npz" % w4))
-        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, RN_WINO_BF3_W4=w4), capture_output=True, text=True, timeout=600)
+        # (both on v_mfma_f32_32x32x16_bf16: the four-wave variant exists in that form only)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, RN_WINO_BF3_W4=w4, RN_WINO_BF3_P16="0"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[w4] = np.load(out)
     for k in got["0"].files:
         assert np.array_equal(got["0"][k], got["1"][k]), k
         assert np.isfinite(got["1"][k]).all() and np.abs(got["1"][k]).max() > 0
+    # The product form (round 6): the same six piece products per element on v_mfma_f32_16x16x32_bf16, two per instruction (K = 16 channels x
+    # two pieces).  Same terms, another grouping of the fp32 sums -> not the same bits; both sit within the split stage's bar of the oracle
+    # (every other test of this file runs the product form), and of each other within a few fp32 roundings of the K-long sum:
+    # |a - b| <= 8 * 2^-24 * sum_k |x_k u_k| per Winograd product, here bounded through max|y| with the measured ratio (< 3e-6 max|y|).
+    out = str(tmp_path / "p16.npz")
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, RN_WINO_BF3_P16="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    p16 = np.load(out)
+    for k in got["0"].files:
+        ref = got["0"][k]
+        assert np.abs(p16[k] - ref).max() <= 1e-5 * np.abs(ref).max(), (k, np.abs(p16[k] - ref).max(), np.abs(ref).max())
+        assert not np.array_equal(p16[k], ref), "RN_WINO_BF3_P16 did not select another kernel"
 
 
 @pytest.mark.parametrize("cin,cout,transposed", [(64, 256, 0), (1024, 512, 0), (256, 256, 1)])
