@@ -761,7 +761,22 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
             const bool issued = !(a.probe & 1) && (in_item || have_next);
             const Item& src = in_item ? cur : nxt;
             const int ss = in_item ? s2 : s2 - a.ksteps;
-            auto dma = [&](int j) { if (issued && j < NPIECE) issue_piece(src, ss, b2, j); };
+            // the two buffer descriptors and the row offset of the stage's source once per step (issue_piece derives them per piece: ~20 scalar
+            // instructions each, between MFMA groups)
+            const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src.vplane + (size_t)ss * a.v_step_bytes), 0, a.v_step_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src.upanel + (size_t)ss * SB_UB), 0, SB_UB, 0x00020000);
+            const unsigned vo = (unsigned)(src.m0 * SB_ROW) + dma_lane;
+            char* const sd = smem + b2 * STAGE;
+            auto dma = [&](int j) {
+                if (!issued || j >= NPIECE) return;
+                if (j < NV) {
+                    if (VP % 8 != 0 && j == NV - 1 && !vextra) return;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lds_void*)(sd + (wave + 8 * j) * 1024), 16, vo + j * 8192, 0, 0, RN_BF3_VLOAD_AUX);
+                } else {
+                    const int i = j - NV;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ursrc, (lds_void*)(sd + VB + (wave + 8 * i) * 1024), 16, dma_lane + i * 8192, 0, 0, RN_BF3_ULOAD_AUX);
+                }
+            };
             const bool more = s + 1 < a.ksteps || have_next;
             const char* sn = smem + bn * STAGE;
 #pragma unroll
@@ -794,7 +809,9 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
                 for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua[slot], va[tt], acc[tt][ct], 0, 0, 0);
                 if (last && more) {
 #pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) va[tt] = *reinterpret_cast<const frag*>(sn + vo_a + tt * (16 * SB_ROW));
+                    for (int tt = 0; tt < TT; ++tt) {
+                        va[tt] = *reinterpret_cast<const frag*>(sn + vo_a + tt * (16 * SB_ROW));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
