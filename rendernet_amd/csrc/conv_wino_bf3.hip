@@ -41,6 +41,9 @@
 #ifndef RN_BF3_ULOAD_AUX
 #define RN_BF3_ULOAD_AUX 0      // ... of U (read by the 8 CUs of an XCD that share the channel block, and again every round)
 #endif
+#ifndef RN_P16_SCHED
+#define RN_P16_SCHED 2          // 16x16x32 form, placement of a channel group's U reads + DMA piece: 0 ahead of its MFMAs (pinned), 1 compiler's choice, 2 behind its first four MFMAs
+#endif
 #ifndef RN_BF3_VSTORE_NT
 #define RN_BF3_VSTORE_NT 0      // the input transform's stores of V as non-temporal stores
 #endif
@@ -783,6 +786,25 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
             for (int ct = 0; ct < CT; ++ct) {
                 const int slot = ct & 1;
                 const bool last = ct == CT - 1;
+#if RN_P16_SCHED == 2
+                // the group's U reads + DMA piece go out BEHIND its first four MFMAs (a wave that starts a group with ~10 scalar / memory instructions
+                // leaves the matrix pipe to the other wave of the SIMD for that long: +2.3 % on the stage, profiles/r06s_*; the DMA behind the second
+                // four, or the last group's wait + barrier behind its first four, measured slower)
+                if (last) {
+                    // every DMA piece of the stage after next is out: wait for the NEXT stage (counted), barrier, then this step's last
+                    // channel group runs while the next step's first operands replace the fragments it has finished with
+                    wait_stage(issued, after_store);
+                    if (more) ldu(sn, 0, slot ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ub[slot], vc[tt], acc[tt][ct], 0, 0, 0);
+                if (!last) {
+                    ldu(sb, ct + 1, slot ^ 1);
+                    if (CT == 8) dma(ct); else { dma(ct); dma(ct + 3); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 if (!last) ldu(sb, ct + 1, slot ^ 1);
                 if (CT == 8) { if (ct < CT - 1) dma(ct); }
                 else { if (ct < CT - 1) { dma(ct); dma(ct + 3); } }
@@ -792,9 +814,12 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
                     wait_stage(issued, after_store);
                     if (more) ldu(sn, 0, slot ^ 1);
                 }
+#if RN_P16_SCHED == 0
                 __builtin_amdgcn_sched_barrier(0);                    // (the reads of the next group's U fragments stay AHEAD of this group's MFMAs)
+#endif
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ub[slot], vc[tt], acc[tt][ct], 0, 0, 0);
+#endif
                 if (last && more) {
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) vc[tt] = *reinterpret_cast<const frag*>(sn + vo_c + tt * (16 * SB_ROW));
@@ -813,7 +838,9 @@ void wino_gemm_bf3_kernel(const Bf3GemmArgs a)
                         va[tt] = *reinterpret_cast<const frag*>(sn + vo_a + tt * (16 * SB_ROW));
                     }
                 }
+#if RN_P16_SCHED != 1
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             buf = bn;
             after_store = false;
