@@ -582,6 +582,10 @@ CONV3D_SPLIT = {"": None, "0": False}.get(os.environ.get("RN_CONV3D_SPLIT", ""),
 
 # The filter gradients of the wide 2-D convs in split mode too (RN_WGRAD_SPLIT=0: keep them on the exact-fp32 route)
 WGRAD_SPLIT = os.environ.get("RN_WGRAD_SPLIT", "1") not in ("", "0")
+CARRY_SKIP_GRADIENT = os.environ.get("RN_NO_CARRY", "") in ("", "0")      # res blocks: the skip path's gradient is added inside conv1's input-gradient launch (see _conv_apply)
+# the wider of (Cin, Cout) from which the 2-D Winograd filter gradient takes the split GEMM stage.  Measured at crop 64: 1024 -> 1024 1.10 -> 0.79 ms, 1024 -> 512 (4x4)
+# 0.92 -> 0.65; 512 -> 512 no gain on the 32x32x16 form of the stage, on the 16x16x32 form the training step goes 87.1 -> 85.9 ms (profiles/r06z_wgrad_min_ch.txt)
+WGRAD_SPLIT_MIN_CH = int(os.environ.get("RN_WGRAD_SPLIT_MIN_CH", "512"))
 
 
 def _conv3d_split(B=None, H=None, W=None):
@@ -785,7 +789,7 @@ class _Conv(torch.autograd.Function):
     forward (plus the saved pre-activation when training), three backward (epilogue, dgrad, wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False, amax_box=None):
+    def forward(ctx, x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, anchor, elu=False, amax_box=None, carry=False):
         _chk_dev(x, pw.w_tf, bias, alpha, residual)
         ev = LAUNCH_HOOK(mode, tuple(x.shape), pw) if LAUNCH_HOOK is not None else None
         if ev is not None:
@@ -808,15 +812,22 @@ class _Conv(torch.autograd.Function):
             ctx.save_for_backward(x, z, y if (sigmoid or elu) else None)
             ctx.cfg = (pw, bias, alpha, residual is not None, tuple(ksize), tuple(stride), act, mode, TRAIN)
             ctx.gemm = gemm_mode_now()                # the backward runs on autograd's thread: it takes the forward's mode along
+            ctx.carry = bool(carry)
+        if carry:
+            # training only (conv*(..., carry=True)): x rides along as a second output.  A res block hands THAT to its second conv as the
+            # residual, so the skip path's gradient comes back into THIS node (as the gradient of the second output) and is added to dx
+            # in the epilogue of the input-gradient launch -- instead of a separate read-modify-write add_ by the autograd engine
+            # (27 per training step of the shader net, 100 MB tensors)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dcarry=None):
         with gemm_mode(ctx.gemm):
-            return _Conv._backward(ctx, dy)
+            return _Conv._backward(ctx, dy, dcarry)
 
     @staticmethod
-    def _backward(ctx, dy):
+    def _backward(ctx, dy, dcarry=None):
         x, z, y = ctx.saved_tensors
         pw, bias, alpha, has_res, ksize, stride, act, mode, tc = ctx.cfg
         lib, st = L.lib(), L.stream_ptr()
@@ -852,7 +863,7 @@ class _Conv(torch.autograd.Function):
         elif mode == "conv3d":
             rc = lib.rn_conv3d_wgrad(L.ptr(x), L.ptr(dz), L.ptr(dw), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
         elif (mode == "conv2d" and unit and tuple(ksize) in ((3, 3), (4, 4)) and _use_wino43(pw, H, W) and _gemm_mode(pw) in ("split", "split16") and WGRAD_SPLIT
-              and max(Cin, pw.cout) >= 1024              # measured at crop 64: 1024 -> 1024 1.10 -> 0.79 ms, 1024 -> 512 (4x4) 0.92 -> 0.65; 512 -> 512: no gain
+              and max(Cin, pw.cout) >= WGRAD_SPLIT_MIN_CH
               and lib.rn_winograd_split_wgrad_supported(L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44, Cin, pw.cout)):
             # the reduction over the tiles on the bf16 pipe (csrc/conv_wino_bf3_wgrad.hip)
             sch = L.RN_WINO_F43 if ksize[0] == 3 else L.RN_WINO_F44
@@ -891,22 +902,28 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             dp = pw.dgrad_pack(unit)
+            # the gradient that came in through the carried copy of x (a res block's skip path): added by the launch's residual epilogue where
+            # the route has one, by one add_ otherwise
+            rp, fused = None, False
+            if dcarry is not None:
+                dcarry = dcarry.contiguous()
+                rp = L.ptr(dcarry)
             if mode == "conv3d" and unit and _conv3d_split(B, H, W) and dp.has_split3d():
-                rc = _conv3d_split_launch(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, D, pw.cout, Cin, 0, st)
+                rc = _conv3d_split_launch(dz, dp, (None, None, rp, L.ptr(dx), None), B, H, W, D, pw.cout, Cin, 0, st); fused = True
             elif mode == "conv3d" and unit and dp.wino is not None:
-                rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
-                                            B, H, W, D, pw.cout, Cin, 0, st)
+                rc = lib.rn_conv3d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, rp, L.ptr(dx), None,
+                                            B, H, W, D, pw.cout, Cin, 0, st); fused = True
             elif mode == "conv3d":
                 rc = lib.rn_conv3d_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, L.ivec(ksize), L.ivec(stride), st)
             elif mode in ("conv2d", "conv2d_transpose") and unit and _use_wino43(dp, H, W):
-                rc = _wino43_fwd(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0)
+                rc = _wino43_fwd(dz, dp, (None, None, rp, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0); fused = True
             elif mode == "conv2d" and unit and _use_split11(dp, H * W):
                 # 1x1: the input gradient is the GEMM with the transposed filter (the same TF tensor packed the other way round)
                 rc = _wino43_run(dz, dp, (None, None, None, L.ptr(dx), None), B, H, W, pw.cout, Cin, 0, "f11")
             elif mode == "conv2d" and unit and dp.wino is not None:
                 # stride-1 3x3: the input gradient is the same conv with the flipped, transposed filter
-                rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, None, L.ptr(dx), None,
-                                            B, H, W, pw.cout, Cin, 0, st)
+                rc = lib.rn_conv2d_wino_fwd(L.ptr(dz), L.ptr(dp.wino), None, None, rp, L.ptr(dx), None,
+                                            B, H, W, pw.cout, Cin, 0, st); fused = True
             elif mode == "conv2d" and unit and dp.wino4 is not None:
                 # stride-1 4x4: the input gradient is the stride-1 transposed conv of the same filter
                 rc = lib.rn_conv2d_wino4_fwd(L.ptr(dz), L.ptr(dp.wino4), None, None, None, L.ptr(dx), None,
@@ -922,9 +939,11 @@ class _Conv(torch.autograd.Function):
             else:
                 rc = lib.rn_conv3d_transpose_dgrad(L.ptr(dz), L.ptr(dp.data), L.ptr(dx), B, H, W, D, Cin, pw.cout, ksize[0], stride[0], st)
             L.check(rc, "rn_%s_dgrad" % mode)
+            if dcarry is not None and not fused:
+                dx.add_(dcarry)
         if not tc.frozen:
             tc.ready(pw.w_tf, bias, alpha)
-        return dx, None, None, None, d_res, None, None, None, None, None, None, None
+        return dx, None, None, None, d_res, None, None, None, None, None, None, None, None
 
 
 def _prep(x, pw, mode_cin):
@@ -934,27 +953,34 @@ def _prep(x, pw, mode_cin):
     return x
 
 
-def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, elu=False):
+def _conv_apply(x, pw, bias, alpha, residual, ksize, stride, sigmoid, mode, elu=False, carry=False):
+    """carry=True: returns (y, x') with x' = x; under an ops.training context x' is a second output of the conv's graph node, and a gradient
+    that reaches it (the skip path of a res block that uses x' as its residual) is added to dx inside the input-gradient launch."""
     anchor = TRAIN.anchor if (TRAIN is not None and torch.is_grad_enabled()) else None
     if anchor is None and not torch.is_grad_enabled():
         # inference: no graph to record -- skip the autograd.Function machinery (at batch 1 the 80 launches of a render
         # are host-bound; this is a fifth of the per-launch cost)
-        return _Conv.forward(None, x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, None, elu)
+        y = _Conv.forward(None, x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, None, elu)
+        return (y, x) if carry else y
     box = []
-    out = _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu, box)
+    fuse = bool(carry) and anchor is not None and CARRY_SKIP_GRADIENT
+    out = _Conv.apply(x, pw, bias, alpha, residual, tuple(ksize), tuple(stride), sigmoid, mode, anchor, elu, box, fuse)
+    xc = x
+    if fuse:
+        out, xc = out
     if box and getattr(out, "_rn_amax", None) is None:
         _tag_amax(out, box[-1])                                     # autograd returned another tensor object for the same storage
-    return out
+    return (out, xc) if carry else out
 
 
-def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False, elu=False):
+def conv3d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 1), sigmoid=False, elu=False, carry=False):
     x = _prep(x, pw, 4)
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d", elu)
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv3d", elu, carry)
 
 
-def conv2d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False, elu=False):
+def conv2d(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False, elu=False, carry=False):
     x = _prep(x, pw, 3)
-    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d", elu)
+    return _conv_apply(x, pw, bias, alpha, residual, pw.kdims, stride, sigmoid, "conv2d", elu, carry)
 
 
 def conv2d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1), sigmoid=False, elu=False):
@@ -972,7 +998,7 @@ def conv3d_transpose(x, pw, bias=None, alpha=None, residual=None, stride=(1, 1, 
 def _res_stack_unfused(x, blocks, skip):
     net = x
     for pw1, b1, a1, pw2, b2 in blocks:
-        h = conv2d(net, pw1, b1, a1)
+        h, net = conv2d(net, pw1, b1, a1, carry=True)      # (training: the skip path's gradient joins dx inside this conv's input-gradient launch)
         net = conv2d(h, pw2, b2, None, net)
     if skip is not None:
         net = conv2d(net, skip[0], skip[1], None, skip[2])

@@ -67,25 +67,25 @@ def _conv_vars(scope, wshape, if_bias, weight_initializer, bias_initializer, wei
 def conv3d(input_, num_outputs, pad="SAME", reuse=False, kernel_size=[4, 4, 4], stride=[2, 2, 2], if_bias=True,
            trainable=True, scope="conv3d", weight_initializer=None, bias_initializer=None,
            weight_initializer_type=random_normal_initializer(stddev=0.02),
-           activation_alpha=None, residual=None, sigmoid=False):
-    """tools/layer_util.py:228-265."""
+           activation_alpha=None, residual=None, sigmoid=False, _carry=False):
+    """tools/layer_util.py:228-265.  (_carry: see ops._conv_apply -- res_block_3d's first conv)"""
     assert pad == "SAME", "only SAME padding is used by the reference nets"
     w, wname, b = _conv_vars(scope, list(kernel_size) + [input_.shape[-1], num_outputs], if_bias,
                              weight_initializer, bias_initializer, weight_initializer_type, num_outputs)
     pw = _store().packed(wname, lambda: ops.pack_conv(w))
-    return ops.conv3d(input_, pw, b, activation_alpha, residual, tuple(stride), sigmoid)
+    return ops.conv3d(input_, pw, b, activation_alpha, residual, tuple(stride), sigmoid, carry=_carry)
 
 
 def conv2d(input_, num_outputs, kernel_size=[4, 4], stride=[1, 1], pad='SAME', if_bias=True, trainable=True,
            reuse=False, scope='conv2d', weight_initializer=None, bias_initializer=None,
            weight_initializer_type=random_normal_initializer(stddev=0.02),
-           activation_alpha=None, residual=None, sigmoid=False, default_bias=0.001):
-    """tools/layer_util.py:147-183."""
+           activation_alpha=None, residual=None, sigmoid=False, default_bias=0.001, _carry=False):
+    """tools/layer_util.py:147-183.  (_carry: see ops._conv_apply -- res_block_2d's first conv)"""
     assert pad == "SAME"
     w, wname, b = _conv_vars(scope, list(kernel_size) + [input_.shape[-1], num_outputs], if_bias,
                              weight_initializer, bias_initializer, weight_initializer_type, num_outputs, default_bias)
     pw = _store().packed(wname, lambda: ops.pack_conv(w))
-    return ops.conv2d(input_, pw, b, activation_alpha, residual, tuple(stride), sigmoid)
+    return ops.conv2d(input_, pw, b, activation_alpha, residual, tuple(stride), sigmoid, carry=_carry)
 
 
 def conv2d_transpose(x, num_outputs, kernel_size=(4, 4), stride=(1, 1), pad='SAME', if_bias=True, reuse=False,
@@ -145,10 +145,12 @@ def res_block_3d(input, out_channels=64, scope='res_block', kernel=[3, 3, 3], st
     wd = weight_dict
     with _store().variable_scope(scope):
         alpha = _alpha_var(out_channels) if wd is None else _relu_slope(out_channels, input.device)
-        net = conv3d(input, out_channels, kernel_size=kernel, stride=stride, pad="SAME", scope="con1_3X3",
-                     weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
-                     bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
-                     weight_initializer_type=xavier_initializer(), activation_alpha=alpha)
+        # (the block's input comes back from the first conv as a second output: the skip path's gradient then joins dx inside that conv's
+        # input-gradient launch instead of through a separate add)
+        net, input = conv3d(input, out_channels, kernel_size=kernel, stride=stride, pad="SAME", scope="con1_3X3",
+                            weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
+                            bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
+                            weight_initializer_type=xavier_initializer(), activation_alpha=alpha, _carry=True)
         net = conv3d(net, out_channels, kernel_size=kernel, stride=stride, pad="SAME", scope="conv2_3x3",
                      weight_initializer=get_weight(scope + '_conv2_3x3_weights', wd),
                      bias_initializer=get_weight(scope + '_conv2_3x3_biases', wd),
@@ -165,10 +167,10 @@ def res_block_2d(input, out_channels=64, scope='res_block', kernel=[3, 3], strid
     with _store().variable_scope(scope):
         alpha = _alpha_var(out_channels) if wd is None else _relu_slope(out_channels, input.device)
         db = 0.0 if wd is None else 0.001
-        net = conv2d(input, out_channels, kernel_size=kernel, stride=stride, scope="con1_3X3",
-                     weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
-                     bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
-                     weight_initializer_type=xavier_initializer(), activation_alpha=alpha, default_bias=db)
+        net, input = conv2d(input, out_channels, kernel_size=kernel, stride=stride, scope="con1_3X3",
+                            weight_initializer=get_weight(scope + '_con1_3X3_weights', wd),
+                            bias_initializer=get_weight(scope + '_con1_3X3_biases', wd),
+                            weight_initializer_type=xavier_initializer(), activation_alpha=alpha, default_bias=db, _carry=True)
         net = conv2d(net, out_channels, kernel_size=kernel, stride=stride, scope="conv2_3x3",
                      weight_initializer=get_weight(scope + '_conv2_3x3_weights', wd),
                      bias_initializer=get_weight(scope + '_conv2_3x3_biases', wd),
