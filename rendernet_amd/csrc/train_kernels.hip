@@ -274,7 +274,10 @@ extern "C" int rn_adam_step(float* param, const float* grad, float* m, float* v,
         return rn_set_error(RN_E_INVALID, "rn_adam_step: buffers must be 16-byte aligned");
     const size_t n4 = n / 4;
     size_t nb = (n4 + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    // one float4 per thread (no grid-stride loop): 237 M parameters 1.22 ms = 5.4 TB/s over the seven streams; capped at 4096 workgroups 1.42 ms
+    // (scripts/adam_bench.py; RN_ADAM_WGS = cap, measurement)
+    static const size_t cap = getenv("RN_ADAM_WGS") ? (size_t)atoi(getenv("RN_ADAM_WGS")) : (size_t)0x7fffffff;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, m, v,
                        n4, n, lr_t, beta1, beta2, eps, grad_scale);
