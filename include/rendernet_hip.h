@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RN_VERSION 191            /* 0.1.91: + the multiply stages on the 16-bit pipe at fp32-class accuracy (rn_winograd_split_*, rn_conv2d_winograd_split_fwd / _wgrad, rn_conv3d_winograd_split_*; RN_SPLIT_FMT_H2, the *_ex entries, rn_absmax) */
+#define RN_VERSION 192            /* 0.1.92: + rn_epilogue_bwd_ws; 0.1.91: + the multiply stages on the 16-bit pipe at fp32-class accuracy (rn_winograd_split_*, rn_conv2d_winograd_split_fwd / _wgrad, rn_conv3d_winograd_split_*; RN_SPLIT_FMT_H2, the *_ex entries, rn_absmax) */
 
 /* error codes */
 #define RN_OK              0
@@ -437,6 +437,14 @@ int rn_fully_connected_bwd(const float* x, const float* w, const float* dz, floa
  * dz may alias dy or be NULL; dbias / dalpha are ACCUMULATED (atomics) and may be NULL. */
 int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
                     float* dz, float* dbias, float* dalpha, size_t M, int C, int act, void* stream);
+/* The same with a caller-owned workspace of rn_epilogue_bwd_workspace_floats(M, C) floats (contents need not survive the call; one per
+ * stream): on large tensors the per-channel sums then go through per-row-block partials and a second small launch instead of
+ * ~2 C x 512 same-address atomics -- a serialised tail of ~20 us per call on the 1024-channel layers (the backward of
+ * tools/layer_util.py:27-45 under RenderNet_Shader.py:165-167; the training step of the shader net 85.4 -> 81.0 ms).  ws = NULL: rn_epilogue_bwd. */
+size_t rn_epilogue_bwd_workspace_floats(size_t M, int C);
+int rn_epilogue_bwd_ws(const float* dy, const float* z, const float* y, const float* alpha,
+                       float* dz, float* dbias, float* dalpha, size_t M, int C, int act,
+                       float* ws, size_t ws_floats, void* stream);
 
 /* Input gradients (tf.nn.conv*_backprop_input).  H,W(,D) are the FORWARD INPUT sizes of the layer.
  *   rn_conv{2,3}d_dgrad            dz [B,ceil(H/s)..,Cout] -> dx [B,H,W(,D),Cin].  stride 1: pack the

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rn_fully_connected_fwd_train": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp]),
     "rn_fully_connected_bwd": (_c_int, [_c_vp] * 5 + [_c_int] * 3 + [_c_vp]),
     "rn_epilogue_bwd": (_c_int, [_c_vp] * 7 + [ctypes.c_size_t, _c_int, _c_int, _c_vp]),
+    "rn_epilogue_bwd_workspace_floats": (ctypes.c_size_t, [ctypes.c_size_t, _c_int]),
+    "rn_epilogue_bwd_ws": (_c_int, [_c_vp] * 7 + [ctypes.c_size_t, _c_int, _c_int, _c_vp, ctypes.c_size_t, _c_vp]),
     "rn_conv3d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 6 + [_ip, _ip, _c_vp]),
     "rn_conv2d_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [_ip, _ip, _c_vp]),
     "rn_conv2d_transpose_dgrad": (_c_int, [_c_vp] * 3 + [_c_int] * 7 + [_c_vp]),

@@ -18,6 +18,7 @@ struct EpiBwdArgs {
     const float* dy; const float* z; const float* y; const float* alpha;
     float* dz; float* dbias; float* dalpha;
     long long M; int C; int act; int rows_per_block;
+    float* ws;                                     // null: atomics onto dbias / dalpha; else [row block][2][C] partial sums (rn_epilogue_bwd_ws)
 };
 
 // fast path: C % 4 == 0 and (256 % (C/4) == 0 or (C/4) % 256 == 0): a thread owns one float4 channel
@@ -98,6 +99,14 @@ void epilogue_bwd_vec_kernel(const EpiBwdArgs a)
                 tb[q] += red[0][(s * gper + threadIdx.x) * 4 + q];
                 ta[q] += red[1][(s * gper + threadIdx.x) * 4 + q];
             }
+        if (a.ws) {
+            // the row block's partial sums, summed over the blocks by epilogue_bwd_reduce_kernel: 512 row blocks x 2 C atomics onto 2 C addresses
+            // cost ~20 us of serialised tail per call (a third of a 100 MB reduce-only call)
+            float* wp = a.ws + ((size_t)blockIdx.x * 2) * a.C + g * 4;
+            *reinterpret_cast<float4*>(wp) = make_float4(tb[0], tb[1], tb[2], tb[3]);
+            *reinterpret_cast<float4*>(wp + a.C) = make_float4(ta[0], ta[1], ta[2], ta[3]);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (a.dbias) unsafeAtomicAdd(a.dbias + g * 4 + q, tb[q]);
@@ -143,13 +152,35 @@ void epilogue_bwd_gen_kernel(const EpiBwdArgs a)
     }
 }
 
-extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
-                               float* dz, float* dbias, float* dalpha, size_t M, int C, int act, void* stream)
+// sums the row-block partials [nb][2][C] of epilogue_bwd_vec_kernel: thread = one channel of one of the two sums, blockIdx.y = a slice of the
+// row blocks; nslice atomics per address
+__global__ __launch_bounds__(256)
+void epilogue_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias, float* __restrict__ dalpha, int C, int nb, int per_slice)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    float* dst = i < C ? dbias : dalpha;
+    if (!dst) return;
+    const int b0 = blockIdx.y * per_slice, b1 = b0 + per_slice < nb ? b0 + per_slice : nb;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += ws[(size_t)b * 2 * C + i];
+        s1 += ws[(size_t)(b + 1) * 2 * C + i];
+        s2 += ws[(size_t)(b + 2) * 2 * C + i];
+        s3 += ws[(size_t)(b + 3) * 2 * C + i];
+    }
+    for (; b < b1; ++b) s0 += ws[(size_t)b * 2 * C + i];
+    if (b0 < b1) unsafeAtomicAdd(dst + (i < C ? i : i - C), (s0 + s1) + (s2 + s3));
+}
+
+static int epilogue_bwd_impl(const float* dy, const float* z, const float* y, const float* alpha,
+                             float* dz, float* dbias, float* dalpha, size_t M, int C, int act, float* ws, size_t ws_floats, void* stream)
 {
     if (!dy || M < 1 || C < 1) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: bad arguments");
     if ((act & RN_ACT_PRELU) && (!z || !alpha)) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: PReLU needs z and alpha");
     if ((act & (RN_ACT_SIGMOID | RN_ACT_ELU)) && !y) return rn_set_error(RN_E_INVALID, "rn_epilogue_bwd: sigmoid / ELU need y");
-    EpiBwdArgs a{dy, z, y, alpha, dz, dbias, dalpha, (long long)M, C, act, 0};
+    EpiBwdArgs a{dy, z, y, alpha, dz, dbias, dalpha, (long long)M, C, act, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int G = C / 4;
     if (C % 4 == 0 && ((G <= 256 && 256 % G == 0) || G % 256 == 0)) {
@@ -168,8 +199,16 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
         if (rpb < 4 * rstep) rpb = 4 * rstep;
         a.rows_per_block = (int)rpb;
         const long long nb = ((long long)M + rpb - 1) / rpb;
+        const bool sums = dbias || ((act & RN_ACT_PRELU) && dalpha);
+        const bool two_stage = ws && sums && nb >= 32 && (size_t)nb * 2 * C <= ws_floats;      // (few row blocks: the atomics are no tail worth a launch)
+        if (two_stage) a.ws = ws;
         if (NT == 1024) hipLaunchKernelGGL(epilogue_bwd_vec_kernel<1024>, dim3((unsigned)nb, gy), dim3(1024), 0, st, a);
         else hipLaunchKernelGGL(epilogue_bwd_vec_kernel<256>, dim3((unsigned)nb, gy), dim3(256), 0, st, a);
+        if (two_stage) {
+            const int nslice = 16, per = (int)((nb + nslice - 1) / nslice);
+            hipLaunchKernelGGL(epilogue_bwd_reduce_kernel, dim3((unsigned)((2 * C + 255) / 256), nslice), dim3(256), 0, st,
+                               ws, dbias, (act & RN_ACT_PRELU) ? dalpha : nullptr, C, (int)nb, per);
+        }
     } else {
         if (C > 1024) return rn_set_error(RN_E_UNSUPPORTED, "rn_epilogue_bwd: C=%d", C);
         long long rpb = ((long long)M + 4095) / 4096;
@@ -179,6 +218,25 @@ extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, 
         hipLaunchKernelGGL(epilogue_bwd_gen_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
     }
     return rn_check_launch("rn_epilogue_bwd");
+}
+
+extern "C" int rn_epilogue_bwd(const float* dy, const float* z, const float* y, const float* alpha,
+                               float* dz, float* dbias, float* dalpha, size_t M, int C, int act, void* stream)
+{
+    return epilogue_bwd_impl(dy, z, y, alpha, dz, dbias, dalpha, M, C, act, nullptr, 0, stream);
+}
+
+extern "C" size_t rn_epilogue_bwd_workspace_floats(size_t M, int C)
+{
+    (void)M;
+    return C >= 1 ? (size_t)512 * 2 * (size_t)C : 0;          // at most 512 row blocks x [2][C]
+}
+
+extern "C" int rn_epilogue_bwd_ws(const float* dy, const float* z, const float* y, const float* alpha,
+                                  float* dz, float* dbias, float* dalpha, size_t M, int C, int act,
+                                  float* ws, size_t ws_floats, void* stream)
+{
+    return epilogue_bwd_impl(dy, z, y, alpha, dz, dbias, dalpha, M, C, act, ws, ws_floats, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -784,6 +784,20 @@ def _out_shape(mode, x, pw, stride):
     return (x.shape[0],) + tuple(int(n) * int(stride[0]) for n in sp) + (pw.cout,)
 
 
+_EPI_WS = {}
+
+
+def _epilogue_ws(device, C):
+    """The partial-sum workspace of rn_epilogue_bwd_ws: one per (device, stream) -- its contents live only inside a call, calls on one
+    stream are ordered -- grown to the widest layer seen (512 row blocks x [2][C] floats: 4 MiB at C = 1024)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    n = L.lib().rn_epilogue_bwd_workspace_floats(0, int(C))
+    ws = _EPI_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _EPI_WS[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return ws
+
+
 class _Conv(torch.autograd.Function):
     """y = sigmoid?( prelu?( conv(x, w) + bias ) + residual ) for the four conv flavours; one HIP launch
     forward (plus the saved pre-activation when training), three backward (epilogue, dgrad, wgrad)."""
@@ -837,10 +851,11 @@ class _Conv(torch.autograd.Function):
         # 1. epilogue backward: dz (new buffer only when the values change), dbias, dalpha
         dz = torch.empty_like(dy) if act else dy
         if act or (bias is not None and not tc.frozen):
-            L.check(lib.rn_epilogue_bwd(L.ptr(dy), L.ptr(z), L.ptr(y), L.ptr(alpha), L.ptr(dz) if act else None,
-                                        L.ptr(tc.grad(bias)) if bias is not None else None,
-                                        L.ptr(tc.grad_if_param(alpha)),
-                                        M, C, act, st), "rn_epilogue_bwd")
+            ws = _epilogue_ws(dy.device, C)
+            L.check(lib.rn_epilogue_bwd_ws(L.ptr(dy), L.ptr(z), L.ptr(y), L.ptr(alpha), L.ptr(dz) if act else None,
+                                           L.ptr(tc.grad(bias)) if bias is not None else None,
+                                           L.ptr(tc.grad_if_param(alpha)),
+                                           M, C, act, L.ptr(ws), ws.numel(), st), "rn_epilogue_bwd_ws")
         d_res = None
         if has_res and ctx.needs_input_grad[4]:
             if act & L.RN_ACT_SIGMOID:

@@ -248,6 +248,54 @@ def test_epilogue_bwd(C, act):
         _close(da, at.grad, "dalpha")
 
 
+@pytest.mark.parametrize("M,C,act", [(24 * 32 * 32, 1024, 1), (24 * 32 * 32, 1024, 0), (24 * 32 * 32, 512, 1), (3000, 256, 3), (40 * 1024, 32, 1), (700, 1024, 1)])
+def test_epilogue_bwd_with_workspace_sums_through_partials(M, C, act):
+    """rn_epilogue_bwd_ws: the per-channel sums go through per-row-block partials in the caller's workspace + a second launch instead of
+    atomics from every row block (the training step's shapes: 24576 x 1024 rows; a reduce-only call, act = 0; shapes below the two-stage
+    threshold fall back to the atomics).  dz bit-equal to rn_epilogue_bwd; the sums against float64, ACCUMULATED onto what is there (the
+    second stage still ends in 16 atomics per channel: no bit-level run-to-run claim)."""
+    from rendernet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(M + C + act)
+    dy, z = _rand(rng, M, C), _rand(rng, M, C)
+    alpha = rng.uniform(0.05, 0.3, C).astype(np.float32)
+    y = 1.0 / (1.0 + np.exp(-np.where(z > 0, z, alpha * z))) if act & 2 else None
+    dyd, zd, ald = _dev(dy), _dev(z), _dev(alpha)
+    yd = _dev(y.astype(np.float32)) if y is not None else None
+    ws = torch.full((lib.rn_epilogue_bwd_workspace_floats(M, C),), float("nan"), device="cuda")
+    assert ws.numel() == 512 * 2 * C
+    outs = []
+    for use_ws in (False, True, True):
+        dz = torch.empty(M, C, device="cuda")
+        db, da = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.25, device="cuda")
+        if use_ws:
+            L.check(lib.rn_epilogue_bwd_ws(L.ptr(dyd), L.ptr(zd), L.ptr(yd), L.ptr(ald), L.ptr(dz) if act else None, L.ptr(db), L.ptr(da), M, C, act,
+                                           L.ptr(ws), ws.numel(), L.stream_ptr()), "epi_ws")
+        else:
+            L.check(lib.rn_epilogue_bwd(L.ptr(dyd), L.ptr(zd), L.ptr(yd), L.ptr(ald), L.ptr(dz) if act else None, L.ptr(db), L.ptr(da), M, C, act,
+                                        L.stream_ptr()), "epi")
+        outs.append((dz.cpu().numpy() if act else None, db.cpu().numpy(), da.cpu().numpy()))
+    d64 = dy.astype(np.float64)
+    if act & 2:
+        yy = y.astype(np.float32).astype(np.float64)
+        d64 = d64 * yy * (1 - yy)
+    ref_da = -0.25 + (d64 * np.minimum(z.astype(np.float64), 0)).sum(0) if act & 1 else np.full(C, -0.25)
+    if act & 1:
+        d64 = np.where(z > 0, d64, d64 * alpha.astype(np.float64))
+    ref_db = 0.5 + d64.sum(0)
+    scale_b, scale_a = np.abs(d64).sum(0).max(), max(np.abs(ref_da).max(), 1.0)
+    for dzv, dbv, dav in outs:
+        assert np.abs(dbv - ref_db).max() <= 2e-6 * scale_b
+        assert np.abs(dav - ref_da).max() <= 2e-5 * scale_a
+    if act:
+        assert np.array_equal(outs[0][0], outs[1][0])                       # dz: the same kernel either way
+    # a workspace that is too small is not an error: the atomics take over
+    small = torch.empty(16, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    L.check(lib.rn_epilogue_bwd_ws(L.ptr(dyd), L.ptr(zd), L.ptr(yd), L.ptr(ald), None, L.ptr(db), None, M, C, 0, L.ptr(small), small.numel(), L.stream_ptr()), "epi_ws small")
+    assert np.abs(db.cpu().numpy() - dy.astype(np.float64).sum(0)).max() <= 2e-6 * np.abs(dy.astype(np.float64)).sum(0).max()
+
+
 @pytest.mark.parametrize("mode,ch", [(0, 1), (1, 3)])
 def test_loss(mode, ch):
     from rendernet_amd import _lib as L

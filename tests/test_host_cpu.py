@@ -58,7 +58,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()
-    assert L.rn_version() == 191  # bump with the header
+    assert L.rn_version() == 192  # bump with the header
     # geometry helper is pure host code: [phase][ceil(K/4)][Npad][4]
     n = L.rn_packed_weight_floats(_lib.RN_PACK_CONV, 3, _lib.ivec([5, 5, 5]), 1, 8)
     assert n == 1 * 32 * 32 * 4                               # K=125 -> 32 quads, Npad 32
