@@ -545,13 +545,16 @@ static int launch_stem(const RnConvProblem& p, hipStream_t st)
 //     slot of an output row = row % 4 -- compile-time, the row loop is unrolled by four;
 //   * when an output row has its fourth input row, the four quads of a pixel are summed with two DPP-class shuffles and lane q = 0 of
 //     every pixel stores: 64 contiguous bytes per wave and row at one output channel.
-template <int CO>
+// NQ = Cin / 4 channel quads per pixel (4: the 16-channel tail of the 64^3 -> 512^2 nets; 8: the 32-channel one of the 128^3 -> 1024^2 config, which ran on
+// the generic direct kernel at 13.3 ms per call until round 6): a wave covers 64 / NQ output columns.
+template <int CO, int NQ>
 __global__ __launch_bounds__(256)
 void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
 {
-    __shared__ f32x4s wl[16 * 4 * CO];                    // [tap][quad][n] = the packed filter's (K quad, n) element: k = tap * 16 + 4 quad + e
+    constexpr int CIN = 4 * NQ, PW = 64 / NQ;                // input channels; pixels (output columns) per wave
+    __shared__ f32x4s wl[16 * NQ * CO];                   // [tap][quad][n] = the packed filter's (K quad, n) element: k = tap * CIN + 4 quad + e
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 16 * 4 * CO; i += 256) {
+    for (int i = tid; i < 16 * NQ * CO; i += 256) {
         const int n = i % CO, tq = i / CO;
         wl[i] = (n < a.Cout) ? *reinterpret_cast<const f32x4s*>(a.w + ((size_t)tq * a.Npad + n) * 4) : f32x4s{0.f, 0.f, 0.f, 0.f};
     }
@@ -560,10 +563,10 @@ void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
     if (id >= (long long)a.B * nrs * ncs) return;
     const int cs = (int)(id % ncs); id /= ncs;
     const int rs = (int)(id % nrs); const int b = (int)(id / nrs);
-    const int g = lane >> 2, q = lane & 3;
-    const int col = cs * 16 + g, row0 = rs * R;                       // R % 4 == 0, so row0 % 4 == 0
+    const int g = lane / NQ, q = lane % NQ;
+    const int col = cs * PW + g, row0 = rs * R;                       // R % 4 == 0, so row0 % 4 == 0
     const int H = a.I0, W = a.I1;
-    const float* xb = a.x + (size_t)b * H * W * 16 + 4 * q;
+    const float* xb = a.x + (size_t)b * H * W * CIN + 4 * q;
     // column taps: input column col - P1 + t1
     bool cok[4];
     int coff[4];
@@ -571,12 +574,12 @@ void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
     for (int t1 = 0; t1 < 4; ++t1) {
         const int ic = col - a.P1 + t1;
         cok[t1] = (unsigned)ic < (unsigned)W;
-        coff[t1] = (cok[t1] ? ic : 0) * 16;
+        coff[t1] = (cok[t1] ? ic : 0) * CIN;
     }
     auto load_row = [&](int u, f32x4s (&xv)[4]) {                     // u = input row + P0
         const int ir = u - a.P0;
         const bool rok = (unsigned)ir < (unsigned)H && u < row0 + R + 3;
-        const float* xr = xb + (size_t)(rok ? ir : 0) * W * 16;
+        const float* xr = xb + (size_t)(rok ? ir : 0) * W * CIN;
 #pragma unroll
         for (int t1 = 0; t1 < 4; ++t1)
             xv[t1] = (rok && cok[t1]) ? *reinterpret_cast<const f32x4s*>(xr + coff[t1]) : f32x4s{0.f, 0.f, 0.f, 0.f};
@@ -610,7 +613,7 @@ void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
                 for (int t1 = 0; t1 < 4; ++t1)
 #pragma unroll
                     for (int n = 0; n < CO; ++n) {
-                        const f32x4s w = wl[((t0 * 4 + t1) * 4 + q) * CO + n];
+                        const f32x4s w = wl[((t0 * 4 + t1) * NQ + q) * CO + n];
                         acc[sl][n] = __builtin_elementwise_fma(f32x2s{xr[j][t1][0], xr[j][t1][1]}, f32x2s{w[0], w[1]}, acc[sl][n]);
                         acc[sl][n] = __builtin_elementwise_fma(f32x2s{xr[j][t1][2], xr[j][t1][3]}, f32x2s{w[2], w[3]}, acc[sl][n]);
                     }
@@ -624,6 +627,7 @@ void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
                     float v = acc[sl][n][0] + acc[sl][n][1];
                     v += __shfl_xor(v, 1);
                     v += __shfl_xor(v, 2);
+                    if (NQ == 8) v += __shfl_xor(v, 4);
                     acc[sl][n] = f32x2s{0.f, 0.f};
                     if (q == 0 && colok && od < a.O0 && n < a.Cout) {
                         const size_t oo = (((size_t)b * a.O0 + od) * a.O1 + col) * a.Cout + n;
@@ -641,7 +645,7 @@ void conv_tail_kernel(const TiledArgs2 a, int R, int ncs, int nrs)
     }
 }
 
-template <int CO>
+template <int CO, int NQ>
 static int launch_tail(const RnConvProblem& p, hipStream_t st)
 {
     TiledArgs2 a;
@@ -651,10 +655,11 @@ static int launch_tail(const RnConvProblem& p, hipStream_t st)
     a.nt0 = a.nt1 = a.nt2 = 0; a.act = p.act;
     static const int r_env = getenv("RN_TAIL_ROWS") ? atoi(getenv("RN_TAIL_ROWS")) : 0;
     const int R = (r_env >= 4 && r_env % 4 == 0) ? r_env : 32;        // rows per strip (three halo rows re-read per strip; measured 8: 0.210, 16: 0.196, 32: 0.191, 64: 0.215 ms)
-    const int ncs = (p.O[1] + 15) / 16, nrs = (p.O[0] + R - 1) / R;
+    constexpr int PW = 64 / NQ;
+    const int ncs = (p.O[1] + PW - 1) / PW, nrs = (p.O[0] + R - 1) / R;
     const long long nw = (long long)p.B * nrs * ncs;
     if (nw <= 0 || (nw + 3) / 4 > 0x7fffffffLL) return rn_set_error(RN_E_INVALID, "conv_tail: bad grid %lld", nw);
-    hipLaunchKernelGGL(conv_tail_kernel<CO>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, a, R, ncs, nrs);
+    hipLaunchKernelGGL((conv_tail_kernel<CO, NQ>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, a, R, ncs, nrs);
     return rn_check_launch("conv_tail");
 }
 
@@ -708,7 +713,9 @@ int rn_launch_conv_tiled(const RnConvProblem& p, hipStream_t st)
     static const bool no_tail = getenv("RN_NO_TAIL_KERNEL") != nullptr;
     const bool tail_ok = !no_tail && p.O[0] == p.I[0] && p.O[1] == p.I[1] && p.P[0] >= 0 && p.P[0] <= 3 && p.P[1] >= 0 && p.P[1] <= 3 &&
                          (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
-    if (k44 && p.Cin == 16 && p.Cout == 1) return tail_ok ? launch_tail<1>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 1, 16, 16, 1>(p, st);
-    if (k44 && p.Cin == 16 && p.Cout == 3) return tail_ok ? launch_tail<3>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 3, 16, 16, 1>(p, st);
+    if (k44 && p.Cin == 16 && p.Cout == 1) return tail_ok ? launch_tail<1, 4>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 1, 16, 16, 1>(p, st);
+    if (k44 && p.Cin == 16 && p.Cout == 3) return tail_ok ? launch_tail<3, 4>(p, st) : launch_tiled<4, 4, 1, 1, 1, 1, 16, 3, 16, 16, 1>(p, st);
+    if (k44 && p.Cin == 32 && p.Cout == 1 && tail_ok) return launch_tail<1, 8>(p, st);            // (the 128^3 -> 1024^2 config's tail; else: the generic direct kernel)
+    if (k44 && p.Cin == 32 && p.Cout == 3 && tail_ok) return launch_tail<3, 8>(p, st);
     return RN_E_UNSUPPORTED;
 }

@@ -134,6 +134,9 @@ CONVT2D_CASES = [
     (1, 37, 21, 16, 1, 1),     # e_conv11 strip kernel (csrc/conv_tiled.hip: conv_tail_kernel): two row strips of 32, two column strips of 16, both ragged
     (2, 70, 50, 16, 3, 1),     # ... RGB, three row strips, four column strips (the last one 2 pixels wide), two images
     (1, 3, 5, 16, 1, 1),       # ... a map smaller than one strip and than the filter's reach
+    (1, 37, 21, 32, 1, 1),     # the 32-channel tail of the 128^3 -> 1024^2 config on the same kernel (8 channel quads, 8 columns per wave): ragged strips
+    (2, 70, 50, 32, 3, 1),     # ... RGB, seven column strips (the last one 2 pixels wide), two images
+    (1, 3, 5, 32, 1, 1),       # ... smaller than one strip
 ]
 
 
