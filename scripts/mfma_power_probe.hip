@@ -55,6 +55,45 @@ __global__ __launch_bounds__(512, 1) void k16(const bf16x8* __restrict__ src, fl
     if (s == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512, 1) void kf32_32(const float* __restrict__ src, float* __restrict__ out, int iters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a[4], b[2];
+    for (int i = 0; i < 4; ++i) a[i] = src[(wave * 6 + i) * 64 + lane];
+    for (int j = 0; j < 2; ++j) b[j] = src[(wave * 6 + 4 + j) * 64 + lane];
+    f32x16_ acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(512, 1) void kf32_16(const float* __restrict__ src, float* __restrict__ out, int iters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a[8], b[4];
+    for (int i = 0; i < 8; ++i) a[i] = src[(wave * 12 + i) * 64 + lane];
+    for (int j = 0; j < 4; ++j) b[j] = src[(wave * 12 + 8 + j) * 64 + lane];
+    f32x4 acc[8][4];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+    if (s == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 static unsigned short bf16_of(float x)
 {
     unsigned u; memcpy(&u, &x, 4);
@@ -97,6 +136,24 @@ int main()
             const double fl = 256.0 * 8 * (double)iters * 8 * 32768.0;
             if (rep == 2) printf("%-40s %8.3f ms  %7.1f TFLOP/s  (%.3f of 2500)  MFMA-pipe cycles %.3g -> %.3f GHz if the pipe never idles\n", c.name, ms, fl / ms * 1e-9, fl / ms * 1e-9 / 2500.0,
                                  (double)iters * 8 * 32 * 2, (double)iters * 8 * 32 * 2 / (ms * 1e-3) * 1e-9);
+        }
+    }
+    {   // fp32 MFMA shapes on random fp32 operands: 32x32x2 (the exact GEMM stage) vs 16x16x4
+        std::vector<float> fr(8 * 12 * 64);
+        for (size_t i = 0; i < fr.size(); ++i) fr[i] = 0.05f * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        float* df; hipMalloc(&df, fr.size() * 4);
+        hipMemcpy(df, fr.data(), fr.size() * 4, hipMemcpyHostToDevice);
+        const int it32 = 40000;
+        for (int which = 0; which < 4; ++which) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0, 0);
+                if (which % 2 == 0) hipLaunchKernelGGL(kf32_32, dim3(256), dim3(512), 0, 0, (const float*)df, out, it32);
+                else hipLaunchKernelGGL(kf32_16, dim3(256), dim3(512), 0, 0, (const float*)df, out, it32 / 2);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                const double fl = 256.0 * 8 * (double)it32 * 8 * (32.0 * 32 * 2 * 2);      // 8 MFMAs of 32x32x2 per wave-iteration (= 32 of 16x16x4 per two)
+                if (rep == 2) printf("%-40s %8.3f ms  %7.1f TFLOP/s  (%.3f of 157.3)\n", which % 2 == 0 ? "F 32x32x2 f32, random" : "G 16x16x4 f32, random", ms, fl / ms * 1e-9, fl / ms * 1e-9 / 157.3);
+            }
         }
     }
     return 0;
