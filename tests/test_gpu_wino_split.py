@@ -414,6 +414,40 @@ def test_four_wave_gemm_variant_is_bit_identical(tmp_path):
         assert not np.array_equal(p16[k], ref), "RN_WINO_BF3_P16 did not select another kernel"
 
 
+def test_split_gemm_launch_plan_never_changes_a_bit(tmp_path):
+    """The split GEMM stage picks whole items, half items, a merged or a separate ragged block and one or several launches by a cost model
+    (csrc/conv_wino_bf3.hip: gemm_split_planes; RN_WINO_BF3_NOTAIL / _NOMERGE / _HALF_COST move its decisions).  Whatever it picks, every
+    output element sums the same piece products over the same K steps in the same order: the plans must agree BIT FOR BIT -- on shapes
+    with whole blocks + ragged rows, a partial last round, few tiles (the small-batch branch) and a 512-channel layer."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rendernet_amd import ops\n"
+        "rng = np.random.default_rng(5)\n"
+        "outs = []\n"
+        "for (B, hw, cin, cout, k) in ((3, 64, 64, 1024, 3), (4, 64, 32, 1024, 3), (5, 64, 64, 512, 3), (9, 64, 32, 256, 3), (2, 32, 64, 512, 4), (6, 64, 32, 1024, 3)):\n"
+        "    x = torch.as_tensor(rng.standard_normal((B, hw, hw, cin)).astype(np.float32)).cuda()\n"
+        "    w = torch.as_tensor((0.05 * rng.standard_normal((k, k, cin, cout))).astype(np.float32)).cuda()\n"
+        "    with torch.no_grad(), ops.gemm_mode('split'):\n"
+        "        outs.append(ops.conv2d(x, ops.pack_conv(w)).cpu().numpy())\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    plans = {"default": {}, "notail": {"RN_WINO_BF3_NOTAIL": "1"}, "nomerge": {"RN_WINO_BF3_NOMERGE": "1"},
+             "cheap_halves": {"RN_WINO_BF3_HALF_COST": "1"}, "dear_halves": {"RN_WINO_BF3_HALF_COST": "40"}}
+    got = {}
+    for name, env in plans.items():
+        out = str(tmp_path / ("%s.npz" % name))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = np.load(out)
+    for name in plans:
+        for k in got["default"].files:
+            assert np.array_equal(got["default"][k], got[name][k]), (name, k)
+    assert all(np.isfinite(got["default"][k]).all() and np.abs(got["default"][k]).max() > 0 for k in got["default"].files)
+
+
 @pytest.mark.parametrize("cin,cout,transposed", [(64, 256, 0), (1024, 512, 0), (256, 256, 1)])
 def test_1x1_split_pack_and_row_format_are_the_fp32_values_in_three_pieces(cin, cout, transposed):
     """RN_WINO_F11 layouts stated in NumPy: the pack Us [1][Cout/256][Cin/16][256][3][16] holds w[c][n] (transposed: w[n][c] of the TF
